@@ -1,0 +1,232 @@
+"""tests/ipm_model.py -- NumPy model of the algorithm the HIP solve kernel runs (test aid, not product).
+
+Structure-exploiting primal-dual interior point (Mehrotra predictor-corrector) for the LMPC /
+LTV-MPC QP of the reference (PredictiveControllers.py:166-257, 340-362):
+  * inequality rows handled by the barrier (slack t = b - F w is recomputed, so r_i = 0),
+  * equalities (dynamics, terminal convex-hull, sum(lambda)=1) kept as constraints, true residuals
+    r_d, r_e are re-evaluated every iteration (self-correcting, inexact Newton tolerated),
+  * Newton system = block-banded KKT, solved by a Riccati recursion on the augmented state
+    xi_k = (x_k, u_{k-1}) (input-rate cost), lane slacks eliminated analytically,
+    terminal block (lambda, s_T) eliminated through a 7x7 square-root (MGS-QR) factor.
+The kernel in racinglmpc_amd/csrc/lmpc_kernels.hip follows this file step by step.
+"""
+import numpy as np
+
+
+class StructQP:
+    """Structured data of one QP: what K1/K2 hand to K3."""
+
+    def __init__(self, par, A, B, C, x0, uOld, SS=None, Qsel=None):
+        self.par, self.A, self.B, self.C, self.x0, self.uOld = par, A, B, C, np.asarray(x0, float), np.asarray(uOld, float).reshape(-1)
+        self.N = par.N
+        self.term = SS is not None
+        self.SS, self.Qsel = SS, Qsel
+        self.S = SS.shape[1] if self.term else 0
+
+
+def mgs_QR(Mt, passes=2):
+    """Modified Gram-Schmidt, run `passes` times (re-orthogonalisation): Mt = Q R."""
+    V = Mt.copy(); n = V.shape[1]; Rtot = np.eye(n)
+    for _ in range(passes):
+        R = np.zeros((n, n))
+        for i in range(n):
+            R[i, i] = np.sqrt(V[:, i] @ V[:, i])
+            V[:, i] = V[:, i] / R[i, i]
+            for j in range(i + 1, n):
+                R[i, j] = V[:, i] @ V[:, j]
+                V[:, j] -= R[i, j] * V[:, i]
+        Rtot = R @ Rtot
+    return V, Rtot
+
+
+def tri_inv_upper(R):
+    n = R.shape[0]; X = np.zeros((n, n))
+    for j in range(n):
+        X[j, j] = 1.0 / R[j, j]
+        for i in range(j - 1, -1, -1):
+            X[i, j] = -(R[i, i + 1:j + 1] @ X[i + 1:j + 1, j]) / R[i, i]
+    return X
+
+
+class Factor:
+    pass
+
+
+def kkt_factor(qp, th_lane, th_u, th_s, th_l, reg_l=0.0):
+    """Riccati backward matrix pass. th_*: barrier weights mu/t per inequality row class."""
+    par = qp.par; N = qp.N; Fx, Fu = par.Fx, par.Fu; dR2 = 2 * par.dR; a = 2 * par.Qslack[0]
+    Q2, Qf2, R2 = 2 * par.Q, 2 * par.Qf, 2 * par.R
+    f = Factor()
+    f.Ds = a + th_lane + th_s
+    f.kap = th_lane * (a + th_s) / f.Ds
+    Pi = np.zeros((8, 8)); Pi[:6, :6] = Qf2
+    if qp.term:
+        T = np.diag(2 * par.QterminalSlack)
+        f.D = th_l + reg_l
+        E = np.vstack([qp.SS, np.ones(qp.S)])
+        Mt = np.vstack([(E / np.sqrt(f.D)).T, np.diag(np.concatenate([1 / np.sqrt(T), [0]]))[:6]])
+        f.Qm, R = mgs_QR(Mt)
+        f.Ri = tri_inv_upper(R); f.W7i = f.Ri @ f.Ri.T; f.E = E; f.T = T; f.sqD = np.sqrt(f.D)
+        Pi[:6, :6] += f.W7i[:6, :6]
+    f.Kx = np.zeros((N, 2, 6)); f.Ku = np.zeros((N, 2, 2)); f.Mi = np.zeros((N, 2, 2)); f.Hx = np.zeros((N, 6, 6))
+    f.PiNext = np.zeros((N, 8, 8))
+    for k in range(N - 1, -1, -1):
+        A, B = qp.A[k], qp.B[k]
+        f.PiNext[k] = Pi
+        Hx = Q2 + (Fx.T * f.kap[k]) @ Fx; f.Hx[k] = Hx
+        Hu = R2 + (Fu.T * th_u[k]) @ Fu
+        Pxx, Pxu, Puu = Pi[:6, :6], Pi[:6, 6:], Pi[6:, 6:]
+        T2 = Pxx @ B + Pxu
+        Mxx = Hx + A.T @ (Pxx @ A); Mxu = A.T @ T2
+        Muu = Hu + np.diag(dR2) + B.T @ T2 + Pxu.T @ B + Puu
+        Mi = np.linalg.inv(Muu); f.Mi[k] = Mi
+        f.Kx[k] = Mi @ Mxu.T; f.Ku[k] = Mi @ (-np.diag(dR2))
+        Pn = np.zeros((8, 8))
+        Pn[:6, :6] = Mxx - Mxu @ f.Kx[k]; Pn[:6, 6:] = -Mxu @ f.Ku[k]; Pn[6:, :6] = Pn[:6, 6:].T
+        Pn[6:, 6:] = np.diag(dR2) + np.diag(dR2) @ f.Ku[k]
+        Pi = Pn
+    return f
+
+
+def kkt_solve(qp, f, th_lane, th_s, gx, gu, gs, h_lane, h_u, h_s, gl, re_dyn, re_sum):
+    """Solve the Newton system for one right-hand side.
+       (P + F'ThF) dw + G'dnu = -(g) + F'h ,  G dw = -r_e   (dx_0 = 0, du_{-1} = 0)
+    gx (N+1,6), gu (N,2), gs (N,2): gradient part; h_*: barrier rhs per row; gl (S): gradient + (-h) for lambda
+    (already combined: gl = g_lambda + h_lambda since F_lambda = -I); re_dyn (N,6): residual of row k+1.
+    Terminal slack s_T is eliminated (s_T = SS lam - x_N), so its gradient enters through the caller."""
+    par = qp.par; N = qp.N; Fx, Fu = par.Fx, par.Fu; dR2 = 2 * par.dR
+    e = -(gs + h_lane + h_s)
+    eta = h_lane + th_lane * e / f.Ds
+    pv = np.zeros(8); pv[:6] = gx[N]
+    if qp.term:
+        ct = np.concatenate([gl / f.sqD, np.zeros(6)])
+        y7 = f.Qm.T @ ct
+        d0 = np.concatenate([np.zeros(6), [-re_sum]])
+        pv[:6] += (f.Ri @ (f.Ri.T @ d0 + y7))[:6]
+    k0 = np.zeros((N, 2))
+    for k in range(N - 1, -1, -1):
+        A, B = qp.A[k], qp.B[k]; Pi = f.PiNext[k]
+        c = -re_dyn[k]                                   # dx_{k+1} = A dx + B du + c
+        z = Pi[:6, :6] @ c + pv[:6]
+        zu = Pi[6:, :6] @ c + pv[6:]
+        mx = gx[k] - Fx.T @ eta[k] + A.T @ z
+        mu_ = gu[k] - Fu.T @ h_u[k] + B.T @ z + zu
+        k0[k] = f.Mi[k] @ mu_
+        pn = np.zeros(8); pn[:6] = mx - f.Kx[k].T @ mu_; pn[6:] = -f.Ku[k].T @ mu_
+        pv = pn
+    dx = np.zeros((N + 1, 6)); du = np.zeros((N, 2)); up = np.zeros(2)
+    for k in range(N):
+        du[k] = -f.Kx[k] @ dx[k] - f.Ku[k] @ up - k0[k]
+        dx[k + 1] = qp.A[k] @ dx[k] + qp.B[k] @ du[k] - re_dyn[k]; up = du[k]
+    fl = dx[:N] @ Fx.T
+    ds = (th_lane * fl + e) / f.Ds
+    dl = None
+    if qp.term:
+        d7 = np.concatenate([dx[N], [-re_sum]])
+        v = -(ct - f.Qm @ y7) + f.Qm @ (f.Ri.T @ d7)
+        dl = v[:qp.S] / f.sqD
+    return dx, du, ds, dl
+
+
+def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=False):
+    """Returns dict(x,u,s,lam,sT, mu (ineq duals in reference row order), iters, gap, rd, re)."""
+    par = qp.par; N = qp.N; S = qp.S; Fx, Fu = par.Fx, par.Fu; bx, bu = par.bx, par.bu
+    dR2 = 2 * par.dR; a = 2 * par.Qslack[0]; c1 = par.Qslack[1]
+    Q2, Qf2, R2 = 2 * par.Q, 2 * par.Qf, 2 * par.R; xRef = par.xRef
+    A, B, C = qp.A, qp.B, qp.C
+    T = np.diag(2 * par.QterminalSlack) if qp.term else None
+    # ---- strictly interior start
+    x = np.zeros((N + 1, 6)); u = np.zeros((N, 2)); x[0] = qp.x0
+    for k in range(N):
+        x[k + 1] = A[k] @ x[k] + B[k] @ u[k] + C[k]
+    s = np.maximum(x[:N] @ Fx.T - bx, 0) + 1.0
+    lam = np.ones(S) / S if qp.term else np.zeros(0)
+    nu = np.zeros((N, 6)); eta_m = 0.0
+    def slacks():
+        fl = x[:N] @ Fx.T
+        return bx - (fl - s), bu - u @ Fu.T, s.copy(), lam.copy()
+    t_lane, t_u, t_s, t_l = slacks()
+    mu0 = max(1.0, 0.01 * (np.max(np.abs(qp.Qsel)) if qp.term else 1.0))
+    m_lane, m_u, m_s, m_l = mu0 / t_lane, mu0 / t_u, mu0 / t_s, (mu0 / t_l if qp.term else np.zeros(0))
+    mtot = 8 * N + S
+    info = {}
+    for it in range(maxit):
+        t_lane, t_u, t_s, t_l = slacks()
+        gap = (t_lane.ravel() @ m_lane.ravel() + t_u.ravel() @ m_u.ravel() + t_s.ravel() @ m_s.ravel() + t_l @ m_l) / mtot
+        # ---- residuals
+        sT = qp.SS @ lam - x[N] if qp.term else None
+        rx = np.zeros((N + 1, 6))
+        for k in range(1, N):
+            rx[k] = Q2 @ (x[k] - xRef) + Fx.T @ m_lane[k] + nu[k - 1] - A[k].T @ nu[k]
+        rx[N] = Qf2 @ (x[N] - xRef) + nu[N - 1] - (T * sT if qp.term else 0)
+        ru = np.zeros((N, 2))
+        for k in range(N):
+            upv = u[k - 1] if k > 0 else qp.uOld
+            ru[k] = R2 @ u[k] + dR2 * (u[k] - upv) + Fu.T @ m_u[k] - B[k].T @ nu[k]
+            if k < N - 1:
+                ru[k] += dR2 * (u[k] - u[k + 1])
+        rs = a * s + c1 - m_lane - m_s
+        rl = (qp.Qsel - m_l + qp.SS.T @ (T * sT) + eta_m) if qp.term else np.zeros(0)
+        re_dyn = np.array([x[k + 1] - A[k] @ x[k] - B[k] @ u[k] - C[k] for k in range(N)])
+        re_sum = (lam.sum() - 1.0) if qp.term else 0.0
+        rd = max(np.abs(rx[1:]).max(), np.abs(ru).max(), np.abs(rs).max(), np.abs(rl).max() if qp.term else 0)
+        re = max(np.abs(re_dyn).max(), abs(re_sum))
+        if verbose:
+            print("it %2d gap %.2e rd %.2e re %.2e" % (it, gap, rd, re))
+        info = dict(iters=it, gap=gap, rd=rd, re=re)
+        if gap < tol_gap and rd < tol_res and re < tol_res:
+            break
+        th_lane, th_u, th_s, th_l = m_lane / t_lane, m_u / t_u, m_s / t_s, (m_l / t_l if qp.term else np.zeros(0))
+        f = kkt_factor(qp, th_lane, th_u, th_s, th_l, reg_l)
+        # terminal slack eliminated: its Hessian T enters W7 through T^-1 (kept in factor)
+        def solve(h_lane, h_u, h_s, h_l):
+            return kkt_solve(qp, f, th_lane, th_s, rx, ru, rs, h_lane, h_u, h_s, rl + h_l, re_dyn, re_sum)
+        # predictor: h = mu
+        dxa, dua, dsa, dla = solve(m_lane, m_u, m_s, m_l)
+        def ineq_steps(dx, du, ds, dl):
+            fl = dx[:N] @ Fx.T
+            return -(fl - ds), -(du @ Fu.T), ds, (dl if qp.term else np.zeros(0))
+        dt = ineq_steps(dxa, dua, dsa, dla)
+        ts = (t_lane, t_u, t_s, t_l); ms = (m_lane, m_u, m_s, m_l); ths = (th_lane, th_u, th_s, th_l)
+        dma = [-m - th * d for m, th, d in zip(ms, ths, dt)]
+        def maxstep(vs, dvs):
+            al = np.inf
+            for v, dv in zip(vs, dvs):
+                v = v.ravel(); dv = dv.ravel(); neg = dv < 0
+                if neg.any():
+                    al = min(al, np.min(-v[neg] / dv[neg]))
+            return al
+        aa = min(1.0, maxstep(ts, dt), maxstep(ms, dma))
+        gap_aff = sum(((t + aa * d).ravel() @ (m + aa * dm).ravel()) for t, d, m, dm in zip(ts, dt, ms, dma)) / mtot
+        sig = (gap_aff / gap) ** 3
+        rc = [t * m - sig * gap + d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]
+        hs = [r / t for r, t in zip(rc, ts)]
+        dx, du, ds, dl = solve(*hs)
+        dt = ineq_steps(dx, du, ds, dl)
+        dm = [(-r - m * d) / t for r, m, d, t in zip(rc, ms, dt, ts)]
+        al = min(1.0, 0.995 * min(maxstep(ts, dt), maxstep(ms, dm)))
+        # costates (delta): dnu_N from terminal, then backwards
+        dnu = np.zeros((N, 6))
+        # dnu_N (row x_N): stationarity of the Newton system in x_N
+        if qp.term:
+            dsT = qp.SS @ dl - dx[N]
+            g = rx[N] + Qf2 @ dx[N] - T * dsT
+        else:
+            g = rx[N] + Qf2 @ dx[N]
+        dnu[N - 1] = -g
+        for k in range(N - 1, 0, -1):
+            # row x_k: Hx dx_k + Fx'(dmu_lane) ... use eliminated form: (Q2) dx + Fx' dm_lane + dnu_{k-1} - A_k' dnu_k = -rx_k
+            dnu[k - 1] = -(rx[k] + Q2 @ dx[k] + Fx.T @ dm[0][k]) + A[k].T @ dnu[k]
+        deta = 0.0
+        if qp.term:
+            # row lambda_i: -dm_l + SS'(T dsT) + deta = -rl  -> average over rows for robustness
+            deta = np.mean(-rl + dm[3] - qp.SS.T @ (T * dsT))
+        x += al * dx; u += al * du; s += al * ds
+        if qp.term:
+            lam += al * dl
+        m_lane, m_u, m_s, m_l = [m + al * d for m, d in zip(ms, dm)]
+        nu += al * dnu; eta_m += al * deta
+    out = dict(x=x, u=u, s=s, lam=lam, sT=(qp.SS @ lam - x[N]) if qp.term else None,
+               mu=np.concatenate([m_lane.ravel(), m_u.ravel(), m_s.ravel(), m_l]), nu=nu, eta=eta_m)
+    out.update(info)
+    return out
