@@ -1,0 +1,152 @@
+/*
+ * include/lmpc_hip.h -- C ABI of liblmpc_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the per-time-step LMPC hot path of urosolia/RacingLMPC.  The reference has
+ * no FFI: its seam is Python duck typing (Simulator.sim -> Controller.solve(x0), SysModel.py:34).
+ * Each entry point below replaces the reference interface cited next to it (paths under
+ * /root/reference/src/fnc/controller/).  The Python side that binds these symbols with ctypes is
+ * racinglmpc_amd/_capi.py; the drop-in modules are racinglmpc_amd/PredictiveControllers.py and
+ * racinglmpc_amd/PredictiveModel.py.
+ *
+ * Conventions: extern "C"; every function returns 0 on success or a negative LMPC_E_* code and
+ * never throws; plain pointers and sizes only; all matrices row-major FP64 (NumPy C-contiguous);
+ * host pointers unless the name ends in _dev; caller owns every buffer; one lmpc_ctx per Python
+ * controller object; calls on one ctx are serialised by the caller.
+ */
+#ifndef LMPC_HIP_H
+#define LMPC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMPC_NX 6
+#define LMPC_NU 2
+#define LMPC_MAX_TRACK_ROWS 16
+#define LMPC_MAX_USED_LAPS 8       /* trToUse / numSS_it upper bound */
+#define LMPC_MAX_N 64
+
+/* error codes (function return values) */
+#define LMPC_OK 0
+#define LMPC_E_ARG (-1)            /* bad argument / unsupported configuration */
+#define LMPC_E_HIP (-2)            /* a HIP runtime call failed (see lmpc_last_error) */
+#define LMPC_E_CAPACITY (-3)       /* lap store / batch capacity exceeded */
+#define LMPC_E_STATE (-4)          /* call not valid in the current state (e.g. no laps stored) */
+
+/* per-problem status bits (status[] outputs); 0 == solved */
+#define LMPC_ST_MAXITER 1          /* interior-point iteration limit hit before tolerances met */
+#define LMPC_ST_REG_SINGULAR 2     /* local regression normal matrix not positive definite (reference: cvxopt raises) */
+#define LMPC_ST_NO_SEGMENT 4       /* curvature(): s on no track segment (reference: int(np.where) raises, Track.py:307) */
+#define LMPC_ST_WINDOW 8           /* safe-set window runs past the end of a stored lap (reference: IndexError, :497) */
+#define LMPC_ST_NUMERIC 16         /* NaN / non-positive pivot inside the KKT factorisation */
+#define LMPC_ST_NOT_INTERIOR 32    /* u = 0 is not strictly inside Fu u <= bu (solver start point) */
+
+typedef struct lmpc_ctx lmpc_ctx;
+
+/* Numeric content of MPCParams (PredictiveControllers.py:24-51), of PredictiveModel.__init__
+ * (PredictiveModel.py:12-32), of the LMPC constructor (PredictiveControllers.py:293-311) and of the
+ * track table Map.PointAndTangent (Track.py:54-133).                                              */
+typedef struct {
+    int N;                      /* horizon (reference main.py:43 uses 14; BASELINE metric uses 12) */
+    int numSS_it;               /* laps in the safe set per solve; 0 => plain MPC/LTV-MPC, no terminal set */
+    int numSS_points;           /* total safe-set columns (reference: 12 * numSS_it = 48); <= 58 */
+    int trToUse;                /* laps used by the regression (PredictiveModel usedIt) */
+    int maxNumPoint;            /* 7   (PredictiveModel.py:18) */
+    double h, lamb, dt;         /* 5, 0.0, 0.1 (PredictiveModel.py:19-21) */
+    double scaling[5];          /* diag of PredictiveModel.py:22-26 */
+    double Q[36], R[4], Qf[36], dR[2], Qslack[2], QtermSlack[36], xRef[6];
+    double Fx[12], bx[2], Fu[8], bu[4];          /* 2 state rows, 4 input rows (reference shapes) */
+    double track[LMPC_MAX_TRACK_ROWS * 6]; int track_rows; double trackLength;
+    int device;                 /* HIP device ordinal */
+    int max_batch;              /* capacity of internal work buffers */
+    int max_laps, max_lap_len;  /* lap-store capacity (rows per lap include addPoint extensions) */
+    /* solver: structure-exploiting primal-dual interior point on the block-banded KKT system */
+    double tol_gap, tol_res, reg_lambda; int max_iter;
+} lmpc_config;
+
+typedef struct {
+    double ms_regress, ms_solve;      /* accumulated HIP-event time of the two kernels (profiling on) */
+    long long n_regress, n_solve;     /* launches accumulated */
+    long long qp_solved;              /* problems passed through the solve kernel */
+    long long ipm_iters;              /* interior-point iterations accumulated (last D2H of iters) */
+} lmpc_stats;
+
+int lmpc_config_default(lmpc_config *cfg);                       /* reference defaults, N = 12 */
+int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out);         /* MPC/LMPC.__init__, :63-107, :293-338 */
+int lmpc_destroy(lmpc_ctx *ctx);
+const char *lmpc_last_error(void);
+int lmpc_version(void);
+
+/* ---- lap stores -------------------------------------------------------------------------------
+ * Two separate stores, as in the reference: the regression store (PredictiveModel.xStored/uStored)
+ * and the safe set (LMPC.SS/uSS/Qfun).  Device layout: [lap][column][row], FP64, row stride
+ * max_lap_len, so that a wave scanning one column of one lap reads contiguous memory.           */
+int lmpc_model_add_trajectory(lmpc_ctx *, const double *x /*T x 6*/, const double *u /*T x 2*/, int T);
+        /* PredictiveModel.addTrajectory, PredictiveModel.py:35-46: sorted insert, ascending T, ties append */
+int lmpc_model_num_laps(lmpc_ctx *, int *n);
+int lmpc_model_replace_lap(lmpc_ctx *, int pos /*position in sorted order*/, const double *x, const double *u, int T);
+int lmpc_ss_add_trajectory(lmpc_ctx *, const double *x, const double *u, int T);
+        /* LMPC.addTrajectory + computeCost, PredictiveControllers.py:418-464 (it += 1) */
+int lmpc_ss_add_point(lmpc_ctx *, const double *x /*6*/, const double *u /*2*/);
+        /* LMPC.addPoint, :466-474: append x + [0,0,0,0,TrackLength,0] to lap it-1, Qfun[-1]-1 */
+int lmpc_ss_replace_lap(lmpc_ctx *, int lap, const double *x, const double *u, const double *qfun, int T);
+int lmpc_ss_set_selected(lmpc_ctx *, const int *laps, int n);
+        /* override of argsort(LapTime)[0:numSS_it] (:395,402); n = 0 restores the built-in stable sort */
+int lmpc_ss_num_laps(lmpc_ctx *, int *n);
+int lmpc_ss_get_qfun(lmpc_ctx *, int lap, double *qfun /*T*/, int *T);
+
+/* ---- batched compute, host buffers --------------------------------------------------------- */
+int lmpc_regress_batch(lmpc_ctx *, int B, const double *xLin /*B x N x 6 (first N rows used)*/, int xLinRowStride /* (N+1)*6 or N*6 */,
+                       const double *uLin /*B x N x 2*/,
+                       double *A /*B x N x 36*/, double *Bm /*B x N x 12*/, double *C /*B x N x 6*/, int *status /*B x N*/);
+        /* MPC.computeLTVdynamics -> PredictiveModel.regressionAndLinearization, :140-145 / PredictiveModel.py:48-197 */
+
+int lmpc_select_batch(lmpc_ctx *, int B, const double *x0 /*B x 6*/, const double *zt /*B x 6*/,
+                      const double *xPredPrev /*B x (N+1) x 6*/, const int *hasPred /*B*/, const int *timeStep /*B*/,
+                      double *ssSel /*B x S x 6*/, double *qSel /*B x S*/, double *succ /*B x S x 6*/, double *succU /*B x S x 2*/,
+                      double *ztUsed /*B x 6*/, int *status /*B*/);
+        /* LMPC.addTerminalComponents (selection part) + selectPoints, :386-412, :478-514 */
+
+int lmpc_qp_solve_batch(lmpc_ctx *, int B, const double *A, const double *Bm, const double *C,
+                        const double *x0 /*B x 6*/, const double *uOld /*B x 2*/,
+                        const double *ssSel /*B x S x 6 or NULL*/, const double *qSel /*B x S or NULL*/,
+                        double *xPred /*B x (N+1) x 6*/, double *uPred /*B x N x 2*/, double *slack /*B x 2N*/,
+                        double *lambda /*B x S*/, double *sTerm /*B x 6*/, double *mu /*B x (8N+S) ineq duals, reference row order*/,
+                        int *status /*B*/, int *iters /*B*/, double *resid /*B x 3: gap, dual res, eq res*/);
+        /* buildCost/buildEqConstr/addSafeSet* + osqp_solve_qp + unpackSolution, :200-283, :340-379 */
+
+int lmpc_step_batch(lmpc_ctx *, int B, const double *x0, const double *xLin /*B x (N+1) x 6*/, const double *uLin /*B x N x 2*/,
+                    const double *uOld, const double *zt, const double *xPredPrev, const int *hasPred, const int *timeStep,
+                    double *xPred, double *uPred, double *slack, double *lambda, double *sTerm,
+                    double *ztNext /*B x 6*/, double *ztuNext /*B x 2*/, double *ssSel /*B x S x 6*/,
+                    double *Aout /*B x N x 36 or NULL*/, double *Bout, double *Cout,
+                    int *status, int *iters, double *resid);
+        /* one full MPC.solve(x0) per problem, :110-137 (a3 -> a19 of SURVEY section 8) */
+
+int lmpc_assemble_batch(lmpc_ctx *, int B, const double *A, const double *Bm, const double *C, const double *x0, const double *uOld,
+                        const double *ssSel, const double *qSel,
+                        double *Pdense /*B x nz x nz*/, double *q /*B x nz*/, double *Adense /*B x m x nz*/, double *l /*B x m*/, double *u /*B x m*/);
+        /* the reference's explicit OSQP-form matrices (H_FTOCP,q_FTOCP,[F;G],l,u of :259-273), for parity checks only */
+int lmpc_qp_dims(lmpc_ctx *, int *nz, int *m_ineq, int *m_eq);
+
+/* ---- device-resident path (bench / rollouts): buffers live in HBM ---------------------------- */
+int lmpc_dev_alloc(lmpc_ctx *, long long bytes, void **dptr);
+int lmpc_dev_free(lmpc_ctx *, void *dptr);
+int lmpc_dev_upload(lmpc_ctx *, void *dptr, const void *host, long long bytes);
+int lmpc_dev_download(lmpc_ctx *, void *host, const void *dptr, long long bytes);
+int lmpc_dev_sync(lmpc_ctx *);
+typedef struct {          /* all device pointers, layouts as in lmpc_step_batch */
+    const double *x0, *xLin, *uLin, *uOld, *zt, *xPredPrev; const int *hasPred, *timeStep;
+    double *xPred, *uPred, *slack, *lambda, *sTerm, *ztNext, *ztuNext, *ssSel, *A, *Bm, *C, *mu, *resid;
+    int *status, *iters;
+} lmpc_step_dev_args;
+int lmpc_step_batch_dev(lmpc_ctx *, int B, const lmpc_step_dev_args *args);   /* async on the ctx stream */
+
+int lmpc_set_profiling(lmpc_ctx *, int on);       /* HIP events around each kernel launch */
+int lmpc_get_stats(lmpc_ctx *, lmpc_stats *out);  /* drains pending events */
+int lmpc_reset_stats(lmpc_ctx *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMPC_HIP_H */

@@ -1,0 +1,295 @@
+"""ctypes binding of liblmpc_hip.so (C ABI: include/lmpc_hip.h).  NumPy in, NumPy out; no torch.
+
+The library is the only compute path: importing this module without a built .so, or calling into it
+without a working HIP device, raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblmpc_hip.so")
+
+MAX_TRACK_ROWS = 16
+MAX_USED_LAPS = 8
+
+ST_MAXITER, ST_REG_SINGULAR, ST_NO_SEGMENT, ST_WINDOW, ST_NUMERIC, ST_NOT_INTERIOR = 1, 2, 4, 8, 16, 32
+
+
+class LmpcConfig(C.Structure):
+    _fields_ = [
+        ("N", C.c_int), ("numSS_it", C.c_int), ("numSS_points", C.c_int), ("trToUse", C.c_int), ("maxNumPoint", C.c_int),
+        ("h", C.c_double), ("lamb", C.c_double), ("dt", C.c_double), ("scaling", C.c_double * 5),
+        ("Q", C.c_double * 36), ("R", C.c_double * 4), ("Qf", C.c_double * 36), ("dR", C.c_double * 2), ("Qslack", C.c_double * 2),
+        ("QtermSlack", C.c_double * 36), ("xRef", C.c_double * 6),
+        ("Fx", C.c_double * 12), ("bx", C.c_double * 2), ("Fu", C.c_double * 8), ("bu", C.c_double * 4),
+        ("track", C.c_double * (MAX_TRACK_ROWS * 6)), ("track_rows", C.c_int), ("trackLength", C.c_double),
+        ("device", C.c_int), ("max_batch", C.c_int), ("max_laps", C.c_int), ("max_lap_len", C.c_int),
+        ("tol_gap", C.c_double), ("tol_res", C.c_double), ("reg_lambda", C.c_double), ("max_iter", C.c_int),
+    ]
+
+
+class LmpcStats(C.Structure):
+    _fields_ = [("ms_regress", C.c_double), ("ms_solve", C.c_double), ("n_regress", C.c_longlong), ("n_solve", C.c_longlong),
+                ("qp_solved", C.c_longlong), ("ipm_iters", C.c_longlong)]
+
+
+class StepDevArgs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("x0", "xLin", "uLin", "uOld", "zt", "xPredPrev", "hasPred", "timeStep",
+                                          "xPred", "uPred", "slack", "lambda_", "sTerm", "ztNext", "ztuNext", "ssSel",
+                                          "A", "Bm", "C", "mu", "resid", "status", "iters")]
+
+
+EXPORTS = [
+    "lmpc_config_default", "lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_version",
+    "lmpc_model_add_trajectory", "lmpc_model_num_laps", "lmpc_model_replace_lap",
+    "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun",
+    "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
+    "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
+    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats",
+]
+
+_lib = None
+
+
+class LmpcError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen liblmpc_hip.so (built by racinglmpc_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LmpcError("liblmpc_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                            "There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(lib, name)          # raises AttributeError if a declared symbol is missing
+        lib.lmpc_last_error.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise LmpcError("liblmpc_hip error %d: %s" % (rc, load().lmpc_last_error().decode()))
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def default_config():
+    cfg = LmpcConfig()
+    _chk(load().lmpc_config_default(C.byref(cfg)))
+    return cfg
+
+
+def set_arr(field, values):
+    v = np.asarray(values, dtype=np.float64).reshape(-1)
+    assert len(v) == len(field), (len(v), len(field))
+    for i, x in enumerate(v):
+        field[i] = float(x)
+
+
+class Context:
+    """One lmpc_ctx: device lap stores + batched solver for a fixed (N, safe-set size) configuration."""
+
+    def __init__(self, cfg):
+        self.lib = load()
+        self.cfg = cfg
+        self.N = cfg.N
+        self.S = cfg.numSS_points if cfg.numSS_it > 0 else 0
+        self.M = 8 * self.N + self.S
+        self._h = C.c_void_p()
+        _chk(self.lib.lmpc_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self.lib.lmpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stores
+    def model_add_trajectory(self, x, u):
+        x = _f64(x); u = _f64(u)
+        _chk(self.lib.lmpc_model_add_trajectory(self._h, _d(x), _d(u), C.c_int(x.shape[0])))
+
+    def model_replace_lap(self, pos, x, u):
+        x = _f64(x); u = _f64(u)
+        _chk(self.lib.lmpc_model_replace_lap(self._h, C.c_int(pos), _d(x), _d(u), C.c_int(x.shape[0])))
+
+    def ss_add_trajectory(self, x, u):
+        x = _f64(x); u = _f64(u)
+        _chk(self.lib.lmpc_ss_add_trajectory(self._h, _d(x), _d(u), C.c_int(x.shape[0])))
+
+    def ss_add_point(self, x, u):
+        x = _f64(x); u = _f64(u)
+        _chk(self.lib.lmpc_ss_add_point(self._h, _d(x), _d(u)))
+
+    def ss_replace_lap(self, lap, x, u, qfun):
+        x = _f64(x); u = _f64(u); q = _f64(qfun)
+        _chk(self.lib.lmpc_ss_replace_lap(self._h, C.c_int(lap), _d(x), _d(u), _d(q), C.c_int(x.shape[0])))
+
+    def ss_set_selected(self, laps):
+        laps = _i32(laps)
+        _chk(self.lib.lmpc_ss_set_selected(self._h, _d(laps), C.c_int(len(laps))))
+
+    def ss_get_qfun(self, lap):
+        T = C.c_int()
+        _chk(self.lib.lmpc_ss_get_qfun(self._h, C.c_int(lap), None, C.byref(T)))
+        q = np.zeros(T.value)
+        _chk(self.lib.lmpc_ss_get_qfun(self._h, C.c_int(lap), _d(q), C.byref(T)))
+        return q
+
+    # ---- batched compute (host buffers)
+    def regress_batch(self, xLin, uLin):
+        N = self.N
+        xLin = _f64(xLin); uLin = _f64(uLin)
+        B = xLin.shape[0]
+        stride = xLin.shape[1] * 6
+        A = np.zeros((B, N, 6, 6)); Bm = np.zeros((B, N, 6, 2)); Cc = np.zeros((B, N, 6)); st = np.zeros((B, N), np.int32)
+        _chk(self.lib.lmpc_regress_batch(self._h, C.c_int(B), _d(xLin), C.c_int(stride), _d(uLin), _d(A), _d(Bm), _d(Cc), _d(st)))
+        return A, Bm, Cc, st
+
+    def select_batch(self, x0, zt, xPredPrev=None, hasPred=None, timeStep=None):
+        N, S = self.N, self.S
+        x0 = _f64(x0); zt = _f64(zt); B = x0.shape[0]
+        xpp = None if xPredPrev is None else _f64(xPredPrev)
+        hp = None if hasPred is None else _i32(hasPred)
+        ts = None if timeStep is None else _i32(timeStep)
+        ss = np.zeros((B, S, 6)); q = np.zeros((B, S)); succ = np.zeros((B, S, 6)); succU = np.zeros((B, S, 2)); ztu = np.zeros((B, 6))
+        st = np.zeros(B, np.int32)
+        _chk(self.lib.lmpc_select_batch(self._h, C.c_int(B), _d(x0), _d(zt), _d(xpp), _d(hp), _d(ts), _d(ss), _d(q), _d(succ), _d(succU), _d(ztu), _d(st)))
+        return dict(ssSel=ss, qSel=q, succ=succ, succU=succU, ztUsed=ztu, status=st)
+
+    def qp_solve_batch(self, A, Bm, Cc, x0, uOld, ssSel=None, qSel=None):
+        N, S, M = self.N, self.S, self.M
+        A = _f64(A); Bm = _f64(Bm); Cc = _f64(Cc); x0 = _f64(x0); uOld = _f64(uOld); B = x0.shape[0]
+        ss = None if ssSel is None else _f64(ssSel); q = None if qSel is None else _f64(qSel)
+        out = dict(xPred=np.zeros((B, N + 1, 6)), uPred=np.zeros((B, N, 2)), slack=np.zeros((B, 2 * N)), lambd=np.zeros((B, S)),
+                   sTerm=np.zeros((B, 6)), mu=np.zeros((B, M)), status=np.zeros(B, np.int32), iters=np.zeros(B, np.int32), resid=np.zeros((B, 3)))
+        _chk(self.lib.lmpc_qp_solve_batch(self._h, C.c_int(B), _d(A), _d(Bm), _d(Cc), _d(x0), _d(uOld), _d(ss), _d(q),
+                                          _d(out["xPred"]), _d(out["uPred"]), _d(out["slack"]), _d(out["lambd"]), _d(out["sTerm"]), _d(out["mu"]),
+                                          _d(out["status"]), _d(out["iters"]), _d(out["resid"])))
+        return out
+
+    def step_batch(self, x0, xLin, uLin, uOld, zt=None, xPredPrev=None, hasPred=None, timeStep=None):
+        N, S = self.N, self.S
+        x0 = _f64(x0); xLin = _f64(xLin); uLin = _f64(uLin); uOld = _f64(uOld); B = x0.shape[0]
+        assert xLin.shape == (B, N + 1, 6) and uLin.shape == (B, N, 2), (xLin.shape, uLin.shape)
+        ztc = None if zt is None else _f64(zt)
+        xpp = None if xPredPrev is None else _f64(xPredPrev)
+        hp = None if hasPred is None else _i32(hasPred)
+        ts = None if timeStep is None else _i32(timeStep)
+        out = dict(xPred=np.zeros((B, N + 1, 6)), uPred=np.zeros((B, N, 2)), slack=np.zeros((B, 2 * N)), lambd=np.zeros((B, S)),
+                   sTerm=np.zeros((B, 6)), ztNext=np.zeros((B, 6)), ztuNext=np.zeros((B, 2)), ssSel=np.zeros((B, S, 6)),
+                   A=np.zeros((B, N, 6, 6)), B=np.zeros((B, N, 6, 2)), C=np.zeros((B, N, 6)),
+                   status=np.zeros(B, np.int32), iters=np.zeros(B, np.int32), resid=np.zeros((B, 3)))
+        _chk(self.lib.lmpc_step_batch(self._h, C.c_int(B), _d(x0), _d(xLin), _d(uLin), _d(uOld), _d(ztc), _d(xpp), _d(hp), _d(ts),
+                                      _d(out["xPred"]), _d(out["uPred"]), _d(out["slack"]), _d(out["lambd"]), _d(out["sTerm"]),
+                                      _d(out["ztNext"]), _d(out["ztuNext"]), _d(out["ssSel"]), _d(out["A"]), _d(out["B"]), _d(out["C"]),
+                                      _d(out["status"]), _d(out["iters"]), _d(out["resid"])))
+        return out
+
+    def qp_dims(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _chk(self.lib.lmpc_qp_dims(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def assemble_batch(self, A, Bm, Cc, x0, uOld, ssSel=None, qSel=None):
+        nz, mi, me = self.qp_dims(); m = mi + me
+        A = _f64(A); Bm = _f64(Bm); Cc = _f64(Cc); x0 = _f64(x0); uOld = _f64(uOld); B = x0.shape[0]
+        ss = None if ssSel is None else _f64(ssSel); q = None if qSel is None else _f64(qSel)
+        P = np.zeros((B, nz, nz)); qv = np.zeros((B, nz)); Ad = np.zeros((B, m, nz)); l = np.zeros((B, m)); u = np.zeros((B, m))
+        _chk(self.lib.lmpc_assemble_batch(self._h, C.c_int(B), _d(A), _d(Bm), _d(Cc), _d(x0), _d(uOld), _d(ss), _d(q), _d(P), _d(qv), _d(Ad), _d(l), _d(u)))
+        return P, qv, Ad, l, u
+
+    # ---- device-resident path
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        _chk(self.lib.lmpc_dev_alloc(self._h, C.c_longlong(int(nbytes)), C.byref(p)))
+        return p
+
+    def dev_free(self, p):
+        _chk(self.lib.lmpc_dev_free(self._h, p))
+
+    def dev_upload(self, p, arr):
+        arr = np.ascontiguousarray(arr)
+        _chk(self.lib.lmpc_dev_upload(self._h, p, _d(arr), C.c_longlong(arr.nbytes)))
+
+    def dev_download(self, p, arr):
+        assert arr.flags["C_CONTIGUOUS"]
+        _chk(self.lib.lmpc_dev_download(self._h, _d(arr), p, C.c_longlong(arr.nbytes)))
+        return arr
+
+    def dev_array(self, arr):
+        """Allocate HBM for `arr` and upload it; returns the device pointer."""
+        arr = np.ascontiguousarray(arr)
+        p = self.dev_alloc(max(arr.nbytes, 8))
+        if arr.nbytes:
+            self.dev_upload(p, arr)
+        return p
+
+    def sync(self):
+        _chk(self.lib.lmpc_dev_sync(self._h))
+
+    def step_batch_dev(self, B, args):
+        _chk(self.lib.lmpc_step_batch_dev(self._h, C.c_int(B), C.byref(args)))
+
+    def set_profiling(self, on):
+        _chk(self.lib.lmpc_set_profiling(self._h, C.c_int(1 if on else 0)))
+
+    def stats(self):
+        s = LmpcStats()
+        _chk(self.lib.lmpc_get_stats(self._h, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        _chk(self.lib.lmpc_reset_stats(self._h))
+
+
+def config_from(N, Q, R, Qf, dR, Qslack, Fx, bx, Fu, bu, xRef, QterminalSlack=None, numSS_Points=0, numSS_it=0, trToUse=0,
+                track=None, trackLength=0.0, max_batch=256, max_laps=64, max_lap_len=2048, device=0, **solver):
+    """Build an LmpcConfig from the numeric content of MPCParams / LMPC ctor args / Map."""
+    cfg = default_config()
+    cfg.N = int(N); cfg.numSS_it = int(numSS_it); cfg.numSS_points = int(numSS_Points) if numSS_it else 0; cfg.trToUse = int(trToUse)
+    set_arr(cfg.Q, np.asarray(Q, float)); set_arr(cfg.R, np.asarray(R, float)); set_arr(cfg.Qf, np.asarray(Qf, float))
+    set_arr(cfg.dR, np.asarray(dR, float)); set_arr(cfg.Qslack, np.asarray(Qslack, float)); set_arr(cfg.xRef, np.asarray(xRef, float))
+    Fx = np.asarray(Fx, float); Fu = np.asarray(Fu, float)
+    if Fx.shape != (2, 6) or Fu.shape != (4, 2):
+        raise LmpcError("only the reference's constraint shapes are supported: Fx (2,6), Fu (4,2); got %s %s" % (Fx.shape, Fu.shape))
+    set_arr(cfg.Fx, Fx); set_arr(cfg.Fu, Fu)
+    set_arr(cfg.bx, np.squeeze(np.asarray(bx, float))); set_arr(cfg.bu, np.squeeze(np.asarray(bu, float)))
+    if QterminalSlack is not None:
+        set_arr(cfg.QtermSlack, np.asarray(QterminalSlack, float))
+    if track is not None:
+        track = np.asarray(track, float)
+        if track.shape[0] > MAX_TRACK_ROWS:
+            raise LmpcError("track table too long")
+        for i, v in enumerate(track.reshape(-1)):
+            cfg.track[i] = float(v)
+        cfg.track_rows = track.shape[0]
+    cfg.trackLength = float(trackLength)
+    cfg.max_batch, cfg.max_laps, cfg.max_lap_len, cfg.device = int(max_batch), int(max_laps), int(max_lap_len), int(device)
+    for k, v in solver.items():
+        setattr(cfg, k, v)
+    return cfg

@@ -1,0 +1,23 @@
+"""Build liblmpc_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "lmpc_capi.hip")
+DEPS = [SRC, os.path.join(_HERE, "csrc", "lmpc_kernels.hip.h"), os.path.join(os.path.dirname(_HERE), "include", "lmpc_hip.h")]
+OUT = os.path.join(_HERE, "liblmpc_hip.so")
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT, SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

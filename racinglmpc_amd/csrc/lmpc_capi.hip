@@ -1,0 +1,425 @@
+// racinglmpc_amd/csrc/lmpc_capi.hip -- host side of liblmpc_hip.so: the C ABI declared in include/lmpc_hip.h.
+// Owns the device lap stores, work buffers, stream and HIP-event timers; launches the kernels of
+// lmpc_kernels.hip.h.  No CPU compute path exists here: if HIP fails, the call fails.
+#include "lmpc_kernels.hip.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int set_err(int code, const char *what, const char *detail) { g_err = std::string(what) + ": " + (detail ? detail : ""); return code; }
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(LMPC_E_HIP, #call, hipGetErrorString(e_)); } while (0)
+#define ARGCHK(cond) do { if (!(cond)) return set_err(LMPC_E_ARG, "argument check failed", #cond); } while (0)
+
+struct evpair { hipEvent_t a, b; int kind; };
+
+struct lmpc_ctx {
+    lmpc_config cfg;
+    lmpc_dev_params dp;
+    hipStream_t stream;
+    double *mstore, *sstore;                 // device lap stores [lap][col][row]
+    std::vector<int> m_order, m_len;         // model: sorted position -> slot ; length per slot
+    std::vector<int> s_len;                  // safe set: rows per lap (incl. addPoint extensions)
+    std::vector<int> s_laptime;              // LMPC.LapTime (rows at addTrajectory time)
+    std::vector<double> s_qlast, s_q0;       // last / first Qfun value per lap
+    std::vector<int> s_override;             // explicit selection (lmpc_ss_set_selected)
+    // device work buffers (host-pointer entry points), sized for max_batch
+    double *w_x0, *w_xLin, *w_uLin, *w_uOld, *w_zt, *w_xPP, *w_A, *w_B, *w_C, *w_ssSel, *w_qSel, *w_succ, *w_succU, *w_ztUsed;
+    double *w_xPred, *w_uPred, *w_slack, *w_lam, *w_sT, *w_mu, *w_ztN, *w_ztuN, *w_resid;
+    int *w_hasPred, *w_tstep, *w_status, *w_iters, *w_rstatus;
+    size_t lds_bytes;
+    int profiling; std::vector<evpair> events; lmpc_stats stats;
+};
+
+extern "C" {
+
+const char *lmpc_last_error(void) { return g_err.c_str(); }
+int lmpc_version(void) { return 100; }
+
+int lmpc_config_default(lmpc_config *c) {
+    if (!c) return LMPC_E_ARG;
+    memset(c, 0, sizeof(*c));
+    c->N = 12; c->numSS_it = 4; c->numSS_points = 48; c->trToUse = 4; c->maxNumPoint = 7;
+    c->h = 5.0; c->lamb = 0.0; c->dt = 0.1;
+    const double sc[5] = {0.1, 1, 1, 1, 1}; memcpy(c->scaling, sc, sizeof(sc));
+    c->dR[0] = 5.0; c->dR[1] = 50.0; c->Qslack[0] = 5.0; c->Qslack[1] = 25.0;       // initControllerParameters.py:50-54
+    for (int i = 0; i < 6; i++) c->QtermSlack[i * 7] = 500.0;
+    c->Fx[5] = 1.0; c->Fx[11] = -1.0; c->bx[0] = c->bx[1] = 0.4;
+    const double fu[8] = {1, 0, -1, 0, 0, 1, 0, -1}; memcpy(c->Fu, fu, sizeof(fu));
+    c->bu[0] = c->bu[1] = 0.5; c->bu[2] = c->bu[3] = 10.0;
+    c->track_rows = 0; c->trackLength = 0.0;
+    c->device = 0; c->max_batch = 256; c->max_laps = 64; c->max_lap_len = 2048;
+    c->tol_gap = 1e-11; c->tol_res = 1e-9; c->reg_lambda = 1e-6; c->max_iter = 40;
+    return LMPC_OK;
+}
+
+static void fill_params(lmpc_ctx *c) {
+    const lmpc_config &f = c->cfg; lmpc_dev_params &p = c->dp;
+    memset(&p, 0, sizeof(p));
+    p.N = f.N; p.L = f.numSS_it; p.S = f.numSS_it > 0 ? f.numSS_points : 0; p.ppl = f.numSS_it > 0 ? f.numSS_points / f.numSS_it : 0;
+    p.trToUse = f.trToUse; p.maxNumPoint = f.maxNumPoint; p.h = f.h; p.lamb = f.lamb; p.dt = f.dt;
+    memcpy(p.scaling, f.scaling, sizeof(p.scaling));
+    for (int i = 0; i < 36; i++) { p.Q2[i] = 2 * f.Q[i]; p.Qf2[i] = 2 * f.Qf[i]; }
+    for (int i = 0; i < 4; i++) p.R2[i] = 2 * f.R[i];
+    p.dR2[0] = 2 * f.dR[0]; p.dR2[1] = 2 * f.dR[1]; p.a_s = 2 * f.Qslack[0]; p.c_s = f.Qslack[1];
+    for (int i = 0; i < 6; i++) { p.T2[i] = 2 * f.QtermSlack[i * 7]; p.xRef[i] = f.xRef[i]; }
+    memcpy(p.Fx, f.Fx, sizeof(p.Fx)); memcpy(p.bx, f.bx, sizeof(p.bx)); memcpy(p.Fu, f.Fu, sizeof(p.Fu)); memcpy(p.bu, f.bu, sizeof(p.bu));
+    memcpy(p.track, f.track, sizeof(double) * 6 * f.track_rows); p.track_rows = f.track_rows; p.TL = f.trackLength;
+    p.tol_gap = f.tol_gap; p.tol_res = f.tol_res; p.reg = f.reg_lambda; p.max_iter = f.max_iter;
+    p.lap_stride = f.max_lap_len; p.mstore = c->mstore; p.sstore = c->sstore;
+}
+
+int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
+    ARGCHK(cfg && out);
+    ARGCHK(cfg->N >= 2 && cfg->N <= LMPC_MAX_N);
+    ARGCHK(cfg->numSS_it >= 0 && cfg->numSS_it <= LMPC_MAX_USED_LAPS && cfg->trToUse >= 0 && cfg->trToUse <= LMPC_MAX_USED_LAPS);
+    ARGCHK(cfg->maxNumPoint >= 1 && cfg->maxNumPoint <= 8);
+    if (cfg->numSS_it > 0) {
+        ARGCHK(cfg->numSS_points % cfg->numSS_it == 0 && cfg->numSS_points + 6 <= WAVE && cfg->numSS_points / cfg->numSS_it + 1 <= WAVE);
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) if (i != j) ARGCHK(cfg->QtermSlack[i * 6 + j] == 0.0);   // diagonal terminal-slack weight
+        for (int i = 0; i < 6; i++) ARGCHK(cfg->QtermSlack[i * 7] > 0.0);
+    }
+    ARGCHK(cfg->track_rows >= 0 && cfg->track_rows <= LMPC_MAX_TRACK_ROWS);
+    ARGCHK(cfg->max_batch >= 1 && cfg->max_laps >= 1 && cfg->max_lap_len >= 8);
+    lmpc_ctx *c = new lmpc_ctx();
+    c->cfg = *cfg; c->profiling = 0; memset(&c->stats, 0, sizeof(c->stats));
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) { delete c; return set_err(LMPC_E_HIP, "hipSetDevice", hipGetErrorString(e)); }
+    HIPCHK(hipStreamCreate(&c->stream));
+    const size_t store_elems = (size_t)cfg->max_laps * LMPC_COLS * cfg->max_lap_len;
+    HIPCHK(hipMalloc(&c->mstore, store_elems * sizeof(double)));
+    HIPCHK(hipMalloc(&c->sstore, store_elems * sizeof(double)));
+    HIPCHK(hipMemset(c->mstore, 0, store_elems * sizeof(double)));
+    HIPCHK(hipMemset(c->sstore, 0, store_elems * sizeof(double)));
+    const size_t B = cfg->max_batch, N = cfg->N, S = cfg->numSS_it > 0 ? cfg->numSS_points : 0, M = 8 * N + S;
+#define DALLOC(ptr, n) HIPCHK(hipMalloc(&c->ptr, std::max<size_t>((n), 1) * sizeof(*c->ptr)))
+    DALLOC(w_x0, B * 6); DALLOC(w_xLin, B * (N + 1) * 6); DALLOC(w_uLin, B * N * 2); DALLOC(w_uOld, B * 2); DALLOC(w_zt, B * 6);
+    DALLOC(w_xPP, B * (N + 1) * 6); DALLOC(w_A, B * N * 36); DALLOC(w_B, B * N * 12); DALLOC(w_C, B * N * 6);
+    DALLOC(w_ssSel, B * S * 6); DALLOC(w_qSel, B * S); DALLOC(w_succ, B * S * 6); DALLOC(w_succU, B * S * 2); DALLOC(w_ztUsed, B * 6);
+    DALLOC(w_xPred, B * (N + 1) * 6); DALLOC(w_uPred, B * N * 2); DALLOC(w_slack, B * N * 2); DALLOC(w_lam, B * S); DALLOC(w_sT, B * 6);
+    DALLOC(w_mu, B * M); DALLOC(w_ztN, B * 6); DALLOC(w_ztuN, B * 2); DALLOC(w_resid, B * 3);
+    DALLOC(w_hasPred, B); DALLOC(w_tstep, B); DALLOC(w_status, B); DALLOC(w_iters, B); DALLOC(w_rstatus, B * N);
+#undef DALLOC
+    c->lds_bytes = (size_t)make_layout((int)N, (int)S).tot * sizeof(double);
+    if (c->lds_bytes > 160 * 1024 - 64) { delete c; return set_err(LMPC_E_ARG, "horizon too long for the LDS-resident solver", ""); }
+    HIPCHK(hipFuncSetAttribute((const void *)lmpc_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    fill_params(c);
+    *out = c;
+    return LMPC_OK;
+}
+
+int lmpc_destroy(lmpc_ctx *c) {
+    if (!c) return LMPC_OK;
+    hipSetDevice(c->cfg.device);
+    hipStreamSynchronize(c->stream);
+    for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    void *ptrs[] = {c->mstore, c->sstore, c->w_x0, c->w_xLin, c->w_uLin, c->w_uOld, c->w_zt, c->w_xPP, c->w_A, c->w_B, c->w_C, c->w_ssSel, c->w_qSel,
+                    c->w_succ, c->w_succU, c->w_ztUsed, c->w_xPred, c->w_uPred, c->w_slack, c->w_lam, c->w_sT, c->w_mu, c->w_ztN, c->w_ztuN, c->w_resid,
+                    c->w_hasPred, c->w_tstep, c->w_status, c->w_iters, c->w_rstatus};
+    for (void *q : ptrs) if (q) hipFree(q);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return LMPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- stores
+static int upload_lap(lmpc_ctx *c, double *store, int slot, const double *x, const double *u, const double *qf, int T) {
+    if (T > c->cfg.max_lap_len) return set_err(LMPC_E_CAPACITY, "lap longer than max_lap_len", "");
+    std::vector<double> col((size_t)T);
+    double *base = store + (size_t)slot * LMPC_COLS * c->cfg.max_lap_len;
+    for (int cI = 0; cI < LMPC_COLS; cI++) {
+        if (cI == 8 && !qf) continue;
+        for (int t = 0; t < T; t++) col[t] = cI < 6 ? x[(size_t)t * 6 + cI] : (cI < 8 ? u[(size_t)t * 2 + (cI - 6)] : qf[t]);
+        HIPCHK(hipMemcpy(base + (size_t)cI * c->cfg.max_lap_len, col.data(), sizeof(double) * T, hipMemcpyHostToDevice));
+    }
+    return LMPC_OK;
+}
+
+int lmpc_model_add_trajectory(lmpc_ctx *c, const double *x, const double *u, int T) {
+    ARGCHK(c && x && u && T >= 2);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int slot = (int)c->m_len.size();
+    if (slot >= c->cfg.max_laps) return set_err(LMPC_E_CAPACITY, "model store full", "");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = upload_lap(c, c->mstore, slot, x, u, nullptr, T); if (rc) return rc;
+    c->m_len.push_back(T);
+    // PredictiveModel.addTrajectory (PredictiveModel.py:35-46): append if empty or T >= last, else insert before first longer lap
+    if (c->m_order.empty() || T >= c->m_len[c->m_order.back()]) c->m_order.push_back(slot);
+    else { size_t i = 0; while (i < c->m_order.size() && !(T < c->m_len[c->m_order[i]])) i++; c->m_order.insert(c->m_order.begin() + i, slot); }
+    return LMPC_OK;
+}
+int lmpc_model_num_laps(lmpc_ctx *c, int *n) { ARGCHK(c && n); *n = (int)c->m_order.size(); return LMPC_OK; }
+int lmpc_model_replace_lap(lmpc_ctx *c, int pos, const double *x, const double *u, int T) {
+    ARGCHK(c && x && u && pos >= 0 && pos < (int)c->m_order.size());
+    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    ARGCHK(T == c->m_len[c->m_order[pos]]);
+    return upload_lap(c, c->mstore, c->m_order[pos], x, u, nullptr, T);
+}
+
+int lmpc_ss_add_trajectory(lmpc_ctx *c, const double *x, const double *u, int T) {
+    ARGCHK(c && x && u && T >= 1);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int lap = (int)c->s_len.size();
+    if (lap >= c->cfg.max_laps) return set_err(LMPC_E_CAPACITY, "safe-set store full", "");
+    // LMPC.computeCost (PredictiveControllers.py:447-464)
+    std::vector<double> cost((size_t)T, 10000.0);
+    for (int i = 0; i < T; i++) {
+        const int r = T - 1 - i;
+        if (i == 0) cost[r] = 0;
+        else if (x[(size_t)r * 6 + 4] < c->cfg.trackLength) cost[r] = cost[r + 1] + 1;
+        else cost[r] = 0;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = upload_lap(c, c->sstore, lap, x, u, cost.data(), T); if (rc) return rc;
+    c->s_len.push_back(T); c->s_laptime.push_back(T); c->s_qlast.push_back(cost[T - 1]); c->s_q0.push_back(cost[0]);
+    return LMPC_OK;
+}
+
+__global__ void lmpc_store_row_kernel(double *base, int stride, int row, double v0, double v1, double v2, double v3, double v4, double v5, double v6, double v7, double v8) {
+    const double v[9] = {v0, v1, v2, v3, v4, v5, v6, v7, v8};
+    if (threadIdx.x < LMPC_COLS) base[(size_t)threadIdx.x * stride + row] = v[threadIdx.x];
+}
+
+int lmpc_ss_add_point(lmpc_ctx *c, const double *x, const double *u) {
+    ARGCHK(c && x && u);
+    if (c->s_len.empty()) return set_err(LMPC_E_STATE, "addPoint before any addTrajectory", "");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int lap = (int)c->s_len.size() - 1, row = c->s_len[lap];
+    if (row >= c->cfg.max_lap_len) return set_err(LMPC_E_CAPACITY, "lap longer than max_lap_len", "");
+    const double q = c->s_qlast[lap] - 1.0;                        // :474
+    double *base = c->sstore + (size_t)lap * LMPC_COLS * c->cfg.max_lap_len;
+    hipLaunchKernelGGL(lmpc_store_row_kernel, dim3(1), dim3(64), 0, c->stream, base, c->cfg.max_lap_len, row,
+                       x[0], x[1], x[2], x[3], x[4] + c->cfg.trackLength, x[5], u[0], u[1], q);   // :472-473
+    HIPCHK(hipGetLastError());
+    c->s_len[lap] = row + 1; c->s_qlast[lap] = q;
+    return LMPC_OK;
+}
+int lmpc_ss_replace_lap(lmpc_ctx *c, int lap, const double *x, const double *u, const double *qfun, int T) {
+    ARGCHK(c && x && u && qfun && lap >= 0 && lap < (int)c->s_len.size() && T >= 1);
+    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = upload_lap(c, c->sstore, lap, x, u, qfun, T); if (rc) return rc;
+    c->s_len[lap] = T; c->s_qlast[lap] = qfun[T - 1]; c->s_q0[lap] = qfun[0];
+    return LMPC_OK;
+}
+int lmpc_ss_set_selected(lmpc_ctx *c, const int *laps, int n) {
+    ARGCHK(c && n >= 0 && n <= LMPC_MAX_USED_LAPS);
+    c->s_override.assign(laps, laps + n);
+    return LMPC_OK;
+}
+int lmpc_ss_num_laps(lmpc_ctx *c, int *n) { ARGCHK(c && n); *n = (int)c->s_len.size(); return LMPC_OK; }
+int lmpc_ss_get_qfun(lmpc_ctx *c, int lap, double *qfun, int *T) {
+    ARGCHK(c && T && lap >= 0 && lap < (int)c->s_len.size());
+    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    *T = c->s_len[lap];
+    if (qfun) HIPCHK(hipMemcpy(qfun, c->sstore + ((size_t)lap * LMPC_COLS + 8) * c->cfg.max_lap_len, sizeof(double) * c->s_len[lap], hipMemcpyDeviceToHost));
+    return LMPC_OK;
+}
+
+// refresh the per-launch part of the device parameter block
+static int refresh_params(lmpc_ctx *c, bool need_model, bool need_ss) {
+    lmpc_dev_params &p = c->dp;
+    if (need_model) {
+        if ((int)c->m_order.size() < c->cfg.trToUse || c->cfg.trToUse < 1) return set_err(LMPC_E_STATE, "regression needs trToUse stored laps", "");
+        for (int i = 0; i < c->cfg.trToUse; i++) { p.mslot[i] = c->m_order[i]; p.mlen[i] = c->m_len[c->m_order[i]]; }   // usedIt = range(trToUse), PredictiveModel.py:31
+    }
+    if (need_ss) {
+        const int L = c->cfg.numSS_it, nl = (int)c->s_len.size();
+        if (nl < L) return set_err(LMPC_E_STATE, "safe set holds fewer than numSS_it laps", "");
+        std::vector<int> sel;
+        if (!c->s_override.empty()) { sel = c->s_override; if ((int)sel.size() != L) return set_err(LMPC_E_ARG, "selection override must list numSS_it laps", ""); }
+        else {   // argsort(LapTime)[0:numSS_it] (:395,402), stable
+            std::vector<int> idx(nl); for (int i = 0; i < nl; i++) idx[i] = i;
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return c->s_laptime[a] < c->s_laptime[b]; });
+            sel.assign(idx.begin(), idx.begin() + L);
+        }
+        for (int i = 0; i < L; i++) { if (sel[i] < 0 || sel[i] >= nl) return set_err(LMPC_E_ARG, "selected lap out of range", ""); p.sslot[i] = sel[i]; p.sslapid[i] = sel[i]; p.sslen[i] = c->s_len[sel[i]]; }
+        p.cur_it = nl;
+    }
+    return LMPC_OK;
+}
+
+static void ev_begin(lmpc_ctx *c, int kind) {
+    if (!c->profiling) return;
+    evpair e; hipEventCreate(&e.a); hipEventCreate(&e.b); e.kind = kind; hipEventRecord(e.a, c->stream); c->events.push_back(e);
+}
+static void ev_end(lmpc_ctx *c) { if (c->profiling) hipEventRecord(c->events.back().b, c->stream); }
+
+static int launch_regress(lmpc_ctx *c, int B, const double *d_xLin, int xstride, const double *d_uLin, double *dA, double *dB, double *dC, int *dst) {
+    int rc = refresh_params(c, true, false); if (rc) return rc;
+    const int items = B * c->cfg.N;
+    ev_begin(c, 0);
+    hipLaunchKernelGGL(lmpc_regress_kernel, dim3(items), dim3(WAVE), 0, c->stream, c->dp, items, d_xLin, xstride, d_uLin, dA, dB, dC, dst);
+    ev_end(c);
+    HIPCHK(hipGetLastError());
+    c->stats.n_regress++;
+    return LMPC_OK;
+}
+static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
+    const bool term = c->cfg.numSS_it > 0;
+    int rc = refresh_params(c, false, term && (io.mode & 1)); if (rc) return rc;
+    ev_begin(c, 1);
+    hipLaunchKernelGGL(lmpc_solve_kernel, dim3(B), dim3(WAVE), c->lds_bytes, c->stream, c->dp, B, io);
+    ev_end(c);
+    HIPCHK(hipGetLastError());
+    c->stats.n_solve++; if (io.mode & 2) c->stats.qp_solved += B;
+    return LMPC_OK;
+}
+
+#define H2D(dst, src, n) HIPCHK(hipMemcpyAsync(dst, src, sizeof(*(dst)) * (size_t)(n), hipMemcpyHostToDevice, c->stream))
+#define D2H(dst, src, n) do { if (dst) HIPCHK(hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(n), hipMemcpyDeviceToHost, c->stream)); } while (0)
+
+int lmpc_regress_batch(lmpc_ctx *c, int B, const double *xLin, int xLinRowStride, const double *uLin, double *A, double *Bm, double *C, int *status) {
+    ARGCHK(c && xLin && uLin && A && Bm && C && B >= 1 && B <= c->cfg.max_batch);
+    const int N = c->cfg.N;
+    ARGCHK(xLinRowStride == N * 6 || xLinRowStride == (N + 1) * 6);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    H2D(c->w_xLin, xLin, (size_t)B * xLinRowStride); H2D(c->w_uLin, uLin, (size_t)B * N * 2);
+    int rc = launch_regress(c, B, c->w_xLin, xLinRowStride, c->w_uLin, c->w_A, c->w_B, c->w_C, c->w_rstatus); if (rc) return rc;
+    D2H(A, c->w_A, (size_t)B * N * 36); D2H(Bm, c->w_B, (size_t)B * N * 12); D2H(C, c->w_C, (size_t)B * N * 6); D2H(status, c->w_rstatus, (size_t)B * N);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LMPC_OK;
+}
+
+int lmpc_select_batch(lmpc_ctx *c, int B, const double *x0, const double *zt, const double *xPredPrev, const int *hasPred, const int *timeStep,
+                      double *ssSel, double *qSel, double *succ, double *succU, double *ztUsed, int *status) {
+    ARGCHK(c && x0 && zt && B >= 1 && B <= c->cfg.max_batch && c->cfg.numSS_it > 0);
+    const int N = c->cfg.N, S = c->cfg.numSS_points;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    H2D(c->w_x0, x0, (size_t)B * 6); H2D(c->w_zt, zt, (size_t)B * 6);
+    if (xPredPrev) H2D(c->w_xPP, xPredPrev, (size_t)B * (N + 1) * 6);
+    if (hasPred) H2D(c->w_hasPred, hasPred, B); else HIPCHK(hipMemsetAsync(c->w_hasPred, 0, sizeof(int) * B, c->stream));
+    if (timeStep) H2D(c->w_tstep, timeStep, B); else HIPCHK(hipMemsetAsync(c->w_tstep, 0, sizeof(int) * B, c->stream));
+    lmpc_solve_io io; memset(&io, 0, sizeof(io));
+    io.mode = 1; io.x0 = c->w_x0; io.zt = c->w_zt; io.xPredPrev = c->w_xPP; io.hasPred = c->w_hasPred; io.timeStep = c->w_tstep;
+    io.ssSelOut = c->w_ssSel; io.qSelOut = c->w_qSel; io.succOut = c->w_succ; io.succUOut = c->w_succU; io.ztUsed = c->w_ztUsed; io.status = c->w_status; io.iters = c->w_iters;
+    int rc = launch_solve(c, B, io); if (rc) return rc;
+    D2H(ssSel, c->w_ssSel, (size_t)B * S * 6); D2H(qSel, c->w_qSel, (size_t)B * S); D2H(succ, c->w_succ, (size_t)B * S * 6); D2H(succU, c->w_succU, (size_t)B * S * 2);
+    D2H(ztUsed, c->w_ztUsed, (size_t)B * 6); D2H(status, c->w_status, B);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LMPC_OK;
+}
+
+int lmpc_qp_solve_batch(lmpc_ctx *c, int B, const double *A, const double *Bm, const double *C, const double *x0, const double *uOld,
+                        const double *ssSel, const double *qSel, double *xPred, double *uPred, double *slack, double *lambda, double *sTerm,
+                        double *mu, int *status, int *iters, double *resid) {
+    ARGCHK(c && A && Bm && C && x0 && uOld && xPred && uPred && B >= 1 && B <= c->cfg.max_batch);
+    const int N = c->cfg.N, S = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0, M = 8 * N + S;
+    if (S > 0) ARGCHK(ssSel && qSel);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    H2D(c->w_A, A, (size_t)B * N * 36); H2D(c->w_B, Bm, (size_t)B * N * 12); H2D(c->w_C, C, (size_t)B * N * 6);
+    H2D(c->w_x0, x0, (size_t)B * 6); H2D(c->w_uOld, uOld, (size_t)B * 2);
+    if (S > 0) { H2D(c->w_ssSel, ssSel, (size_t)B * S * 6); H2D(c->w_qSel, qSel, (size_t)B * S); }
+    lmpc_solve_io io; memset(&io, 0, sizeof(io));
+    io.mode = 2; io.A = c->w_A; io.Bm = c->w_B; io.C = c->w_C; io.x0 = c->w_x0; io.uOld = c->w_uOld; io.ssSelIn = c->w_ssSel; io.qSelIn = c->w_qSel;
+    io.xPred = c->w_xPred; io.uPred = c->w_uPred; io.slack = c->w_slack; io.lambda = c->w_lam; io.sTerm = c->w_sT; io.mu = c->w_mu; io.resid = c->w_resid;
+    io.status = c->w_status; io.iters = c->w_iters;
+    int rc = launch_solve(c, B, io); if (rc) return rc;
+    D2H(xPred, c->w_xPred, (size_t)B * (N + 1) * 6); D2H(uPred, c->w_uPred, (size_t)B * N * 2); D2H(slack, c->w_slack, (size_t)B * N * 2);
+    if (S > 0) { D2H(lambda, c->w_lam, (size_t)B * S); D2H(sTerm, c->w_sT, (size_t)B * 6); }
+    D2H(mu, c->w_mu, (size_t)B * M); D2H(status, c->w_status, B); D2H(iters, c->w_iters, B); D2H(resid, c->w_resid, (size_t)B * 3);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LMPC_OK;
+}
+
+int lmpc_step_batch_dev(lmpc_ctx *c, int B, const lmpc_step_dev_args *a) {
+    ARGCHK(c && a && B >= 1 && a->x0 && a->xLin && a->uLin && a->uOld && a->A && a->Bm && a->C && a->xPred && a->uPred && a->status && a->iters);
+    const int N = c->cfg.N; const bool term = c->cfg.numSS_it > 0;
+    if (term) ARGCHK(a->zt != nullptr);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    int rc = launch_regress(c, B, a->xLin, (N + 1) * 6, a->uLin, a->A, a->Bm, a->C, c->w_rstatus == nullptr ? nullptr : (B <= c->cfg.max_batch ? c->w_rstatus : nullptr));
+    if (rc) return rc;
+    lmpc_solve_io io; memset(&io, 0, sizeof(io));
+    io.mode = term ? 3 : 2; io.A = a->A; io.Bm = a->Bm; io.C = a->C; io.x0 = a->x0; io.uOld = a->uOld;
+    io.zt = a->zt; io.xPredPrev = a->xPredPrev; io.hasPred = a->hasPred; io.timeStep = a->timeStep;
+    io.xPred = a->xPred; io.uPred = a->uPred; io.slack = a->slack; io.lambda = a->lambda; io.sTerm = a->sTerm; io.mu = a->mu;
+    io.ztNext = a->ztNext; io.ztuNext = a->ztuNext; io.ssSelOut = a->ssSel; io.resid = a->resid; io.status = a->status; io.iters = a->iters;
+    return launch_solve(c, B, io);
+}
+
+int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, const double *uLin, const double *uOld, const double *zt,
+                    const double *xPredPrev, const int *hasPred, const int *timeStep, double *xPred, double *uPred, double *slack, double *lambda,
+                    double *sTerm, double *ztNext, double *ztuNext, double *ssSel, double *Aout, double *Bout, double *Cout, int *status, int *iters, double *resid) {
+    ARGCHK(c && x0 && xLin && uLin && uOld && xPred && uPred && B >= 1 && B <= c->cfg.max_batch);
+    const int N = c->cfg.N; const bool term = c->cfg.numSS_it > 0; const int S = term ? c->cfg.numSS_points : 0;
+    if (term) ARGCHK(zt != nullptr);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    H2D(c->w_x0, x0, (size_t)B * 6); H2D(c->w_xLin, xLin, (size_t)B * (N + 1) * 6); H2D(c->w_uLin, uLin, (size_t)B * N * 2); H2D(c->w_uOld, uOld, (size_t)B * 2);
+    if (term) {
+        H2D(c->w_zt, zt, (size_t)B * 6);
+        if (xPredPrev) H2D(c->w_xPP, xPredPrev, (size_t)B * (N + 1) * 6);
+        if (hasPred && xPredPrev) H2D(c->w_hasPred, hasPred, B); else HIPCHK(hipMemsetAsync(c->w_hasPred, 0, sizeof(int) * B, c->stream));
+        if (timeStep) H2D(c->w_tstep, timeStep, B); else HIPCHK(hipMemsetAsync(c->w_tstep, 0, sizeof(int) * B, c->stream));
+    }
+    lmpc_step_dev_args a; memset(&a, 0, sizeof(a));
+    a.x0 = c->w_x0; a.xLin = c->w_xLin; a.uLin = c->w_uLin; a.uOld = c->w_uOld; a.zt = c->w_zt; a.xPredPrev = c->w_xPP; a.hasPred = c->w_hasPred; a.timeStep = c->w_tstep;
+    a.xPred = c->w_xPred; a.uPred = c->w_uPred; a.slack = c->w_slack; a.lambda = c->w_lam; a.sTerm = c->w_sT; a.ztNext = c->w_ztN; a.ztuNext = c->w_ztuN;
+    a.ssSel = c->w_ssSel; a.A = c->w_A; a.Bm = c->w_B; a.C = c->w_C; a.mu = c->w_mu; a.resid = c->w_resid; a.status = c->w_status; a.iters = c->w_iters;
+    int rc = lmpc_step_batch_dev(c, B, &a); if (rc) return rc;
+    D2H(xPred, c->w_xPred, (size_t)B * (N + 1) * 6); D2H(uPred, c->w_uPred, (size_t)B * N * 2); D2H(slack, c->w_slack, (size_t)B * N * 2);
+    if (term) { D2H(lambda, c->w_lam, (size_t)B * S); D2H(sTerm, c->w_sT, (size_t)B * 6); D2H(ssSel, c->w_ssSel, (size_t)B * S * 6); }
+    D2H(ztNext, c->w_ztN, (size_t)B * 6); D2H(ztuNext, c->w_ztuN, (size_t)B * 2);
+    D2H(Aout, c->w_A, (size_t)B * N * 36); D2H(Bout, c->w_B, (size_t)B * N * 12); D2H(Cout, c->w_C, (size_t)B * N * 6);
+    D2H(status, c->w_status, B); D2H(iters, c->w_iters, B); D2H(resid, c->w_resid, (size_t)B * 3);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (status) {   // fold the regression status bits of the N horizon steps into the per-problem status
+        std::vector<int> rs((size_t)B * N);
+        HIPCHK(hipMemcpy(rs.data(), c->w_rstatus, sizeof(int) * (size_t)B * N, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; b++) for (int i = 0; i < N; i++) status[b] |= rs[(size_t)b * N + i];
+    }
+    return LMPC_OK;
+}
+
+int lmpc_qp_dims(lmpc_ctx *c, int *nz, int *m_ineq, int *m_eq) {
+    ARGCHK(c);
+    const int N = c->cfg.N, S = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0;
+    if (nz) *nz = 6 * (N + 1) + 4 * N + (S > 0 ? S + 6 : 0);
+    if (m_ineq) *m_ineq = 8 * N + S;
+    if (m_eq) *m_eq = 6 * (N + 1) + (S > 0 ? 7 : 0);
+    return LMPC_OK;
+}
+
+int lmpc_assemble_batch(lmpc_ctx *c, int B, const double *A, const double *Bm, const double *C, const double *x0, const double *uOld,
+                        const double *ssSel, const double *qSel, double *Pdense, double *q, double *Adense, double *l, double *u) {
+    ARGCHK(c && A && Bm && C && x0 && uOld && Pdense && q && Adense && l && u && B >= 1 && B <= c->cfg.max_batch);
+    int nz, mi, me; lmpc_qp_dims(c, &nz, &mi, &me); const int mm = mi + me;
+    const int N = c->cfg.N, S = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0;
+    if (S > 0) ARGCHK(ssSel && qSel);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    double *dP, *dq, *dA, *dl, *du;
+    HIPCHK(hipMalloc(&dP, sizeof(double) * (size_t)B * nz * nz)); HIPCHK(hipMalloc(&dq, sizeof(double) * (size_t)B * nz));
+    HIPCHK(hipMalloc(&dA, sizeof(double) * (size_t)B * mm * nz)); HIPCHK(hipMalloc(&dl, sizeof(double) * (size_t)B * mm)); HIPCHK(hipMalloc(&du, sizeof(double) * (size_t)B * mm));
+    H2D(c->w_A, A, (size_t)B * N * 36); H2D(c->w_B, Bm, (size_t)B * N * 12); H2D(c->w_C, C, (size_t)B * N * 6);
+    H2D(c->w_x0, x0, (size_t)B * 6); H2D(c->w_uOld, uOld, (size_t)B * 2);
+    if (S > 0) { H2D(c->w_ssSel, ssSel, (size_t)B * S * 6); H2D(c->w_qSel, qSel, (size_t)B * S); }
+    hipLaunchKernelGGL(lmpc_assemble_kernel, dim3(B), dim3(256), 0, c->stream, c->dp, B, c->w_A, c->w_B, c->w_C, c->w_x0, c->w_uOld, c->w_ssSel, c->w_qSel, dP, dq, dA, dl, du);
+    HIPCHK(hipGetLastError());
+    D2H(Pdense, dP, (size_t)B * nz * nz); D2H(q, dq, (size_t)B * nz); D2H(Adense, dA, (size_t)B * mm * nz); D2H(l, dl, (size_t)B * mm); D2H(u, du, (size_t)B * mm);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(dP); hipFree(dq); hipFree(dA); hipFree(dl); hipFree(du);
+    return LMPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- device buffers
+int lmpc_dev_alloc(lmpc_ctx *c, long long bytes, void **dptr) { ARGCHK(c && dptr && bytes > 0); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipMalloc(dptr, (size_t)bytes)); return LMPC_OK; }
+int lmpc_dev_free(lmpc_ctx *c, void *dptr) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipFree(dptr)); return LMPC_OK; }
+int lmpc_dev_upload(lmpc_ctx *c, void *dptr, const void *host, long long bytes) { ARGCHK(c && dptr && host); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipMemcpyAsync(dptr, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
+int lmpc_dev_download(lmpc_ctx *c, void *host, const void *dptr, long long bytes) { ARGCHK(c && dptr && host); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipMemcpyAsync(host, dptr, (size_t)bytes, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
+int lmpc_dev_sync(lmpc_ctx *c) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
+
+int lmpc_set_profiling(lmpc_ctx *c, int on) { ARGCHK(c); c->profiling = on ? 1 : 0; return LMPC_OK; }
+static int drain_events(lmpc_ctx *c) {
+    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &e : c->events) {
+        float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        if (e.kind == 0) c->stats.ms_regress += ms; else c->stats.ms_solve += ms;
+        hipEventDestroy(e.a); hipEventDestroy(e.b);
+    }
+    c->events.clear();
+    return LMPC_OK;
+}
+int lmpc_get_stats(lmpc_ctx *c, lmpc_stats *out) { ARGCHK(c && out); int rc = drain_events(c); if (rc) return rc; *out = c->stats; return LMPC_OK; }
+int lmpc_reset_stats(lmpc_ctx *c) { ARGCHK(c); int rc = drain_events(c); if (rc) return rc; memset(&c->stats, 0, sizeof(c->stats)); return LMPC_OK; }
+
+}  // extern "C"

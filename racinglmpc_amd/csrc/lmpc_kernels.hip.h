@@ -1,0 +1,872 @@
+// racinglmpc_amd/csrc/lmpc_kernels.hip.h -- gfx950 (MI355X) device code of the LMPC hot path.
+//
+//   lmpc_regress_kernel : K1  LTV model regression + linearisation
+//                         (reference PredictiveModel.py:48-197, Track.py:292-310)
+//   lmpc_solve_kernel   : K2+K3  safe-set selection (PredictiveControllers.py:386-412, 478-514),
+//                         structured QP data (never a dense/CSC matrix) and the QP solve
+//                         (replaces osqp_solve_qp, :259-283) + unpack (:364-384)
+//   lmpc_assemble_kernel: explicit reference-form QP matrices, parity checks only (:166-257, :340-362)
+//
+// Execution model: ONE 64-lane wavefront per work item (one (problem, horizon step) pair in K1, one QP
+// in K2+K3), one wave per work-group, all per-item state in LDS; cross-lane sums are wavefront
+// reductions; sequential recursions (Riccati sweeps) are lane-parallel inside a stage.
+// FP64 throughout (the reference is FP64 end to end; regression normal matrices have cond ~1e5..1e8).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "../../include/lmpc_hip.h"
+
+#define WAVE 64
+#define LMPC_COLS 9                 // lap-store columns: x0..x5, u0, u1, Qfun
+
+struct lmpc_dev_params {
+    int N, S, L, ppl;               // horizon, safe-set columns, laps per solve, points per lap (S/L)
+    int trToUse, maxNumPoint;
+    double h, lamb, dt, scaling[5];
+    double Q2[36], R2[4], Qf2[36], dR2[2], a_s, c_s, T2[6], xRef[6];   // 2Q, 2R, 2Qf, 2dR, 2Qslack[0], Qslack[1], 2 diag(QtermSlack)
+    double Fx[12], bx[2], Fu[8], bu[4];
+    double track[LMPC_MAX_TRACK_ROWS * 6]; int track_rows; double TL;
+    double tol_gap, tol_res, reg; int max_iter;
+    int lap_stride;                 // rows per column (max_lap_len)
+    const double *mstore; int mslot[LMPC_MAX_USED_LAPS]; int mlen[LMPC_MAX_USED_LAPS];
+    const double *sstore; int sslot[LMPC_MAX_USED_LAPS]; int sslen[LMPC_MAX_USED_LAPS]; int sslapid[LMPC_MAX_USED_LAPS];
+    int cur_it;                     // LMPC.it (number of laps in the safe set)
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+// lexicographic (value, index) minimum across the wave; all lanes receive the result
+__device__ __forceinline__ void wave_argmin(double &v, int &i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_xor(v, o, WAVE); int oi = __shfl_xor(i, o, WAVE);
+        bool take = (ov < v) || (ov == v && oi < i);
+        v = take ? ov : v; i = take ? oi : i;
+    }
+}
+
+// Map.curvature, Track.py:292-310.  Returns 0 and sets *bad when s lies on no segment (the reference raises).
+__device__ __forceinline__ double track_curvature(const lmpc_dev_params &p, double s, int *bad) {
+    const double TL = p.TL;
+    while (s > TL) s = s - TL;
+    for (int i = 0; i < p.track_rows; i++) {
+        const double c0 = p.track[i * 6 + 3], len = p.track[i * 6 + 4];
+        if (s >= c0 && s < c0 + len) return p.track[i * 6 + 5];
+    }
+    *bad = 1;
+    return 0.0;
+}
+
+// =====================================================================================================
+// K1: regression + linearisation.  One wave per (problem b, horizon step i).
+// =====================================================================================================
+#define K1_MAXPTS (LMPC_MAX_USED_LAPS * 8)
+
+__global__ __launch_bounds__(WAVE) void lmpc_regress_kernel(lmpc_dev_params p, int nitems, const double *__restrict__ xLin,
+                                                            int xstride, const double *__restrict__ uLin,
+                                                            double *__restrict__ Aout, double *__restrict__ Bout,
+                                                            double *__restrict__ Cout, int *__restrict__ status) {
+    const int item = blockIdx.x;
+    if (item >= nitems) return;
+    const int lane = threadIdx.x;
+    const int b = item / p.N, i = item % p.N;
+    const double *xq = xLin + (size_t)b * xstride + (size_t)i * 6;
+    const double *uq = uLin + ((size_t)b * p.N + i) * 2;
+
+    __shared__ double pts[K1_MAXPTS][9];     // vx vy wz delta a K y_vx y_vy y_wz   (PredictiveModel.py:141-168)
+    __shared__ double gram[45];              // Q_vx(15) b_vx(5) Q_lat(15) b_vy(5) b_wz(5)
+    __shared__ double theta[3][5];
+    __shared__ double outv[54];
+    __shared__ int st_sh;
+
+    const double xi[5] = {xq[0], xq[1], xq[2], uq[0], uq[1]};     // xuLin, PredictiveModel.py:54
+    const int MAXP = p.maxNumPoint > 8 ? 8 : p.maxNumPoint;
+    int npts = 0;
+    if (lane == 0) st_sh = 0;
+
+    // ---- computeIndices for every used lap (PredictiveModel.py:180-197) ------------------------------
+    for (int c = 0; c < p.trToUse; c++) {
+        const double *base = p.mstore + (size_t)p.mslot[c] * LMPC_COLS * p.lap_stride;
+        const int T = p.mlen[c];
+        double d[8]; int id[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { d[k] = INFINITY; id[k] = 0x7fffffff; }
+        int cnt = 0;
+        for (int t = lane; t < T - 1; t += WAVE) {
+            // la.norm(diff, 1, axis=1) of (Data - x) . scaling : |.| accumulated in feature order, no contraction
+            double nrm = fabs((base[0 * p.lap_stride + t] - xi[0]) * p.scaling[0]);
+            nrm = nrm + fabs((base[1 * p.lap_stride + t] - xi[1]) * p.scaling[1]);
+            nrm = nrm + fabs((base[2 * p.lap_stride + t] - xi[2]) * p.scaling[2]);
+            nrm = nrm + fabs((base[6 * p.lap_stride + t] - xi[3]) * p.scaling[3]);
+            nrm = nrm + fabs((base[7 * p.lap_stride + t] - xi[4]) * p.scaling[4]);
+            if (nrm < p.h) {
+                cnt++;
+                if (nrm < d[7]) {        // keep the 8 smallest of this lane, ascending, earlier row first on ties
+                    d[7] = nrm; id[7] = t;
+#pragma unroll
+                    for (int k = 7; k > 0; k--) {
+                        if (d[k] < d[k - 1]) { double td = d[k]; d[k] = d[k - 1]; d[k - 1] = td; int ti = id[k]; id[k] = id[k - 1]; id[k - 1] = ti; }
+                    }
+                }
+            }
+        }
+        const int total = (int)wave_sum((double)cnt);
+        const int nsel = total >= MAXP ? MAXP : total;       // >= MaxNumPoint -> argsort[:7], else all within h
+        double seld[8]; int seli[8];
+        for (int r = 0; r < nsel; r++) {
+            double v = d[0]; int vi = id[0];
+            wave_argmin(v, vi);
+            seld[r] = v; seli[r] = vi;
+            if (d[0] == v && id[0] == vi) {                   // winner pops its head
+#pragma unroll
+                for (int k = 0; k < 7; k++) { d[k] = d[k + 1]; id[k] = id[k + 1]; }
+                d[7] = INFINITY; id[7] = 0x7fffffff;
+            }
+        }
+        if (total < MAXP) {                                   // np.where order = ascending row index
+            for (int a = 1; a < nsel; a++)
+                for (int q = a; q > 0 && seli[q] < seli[q - 1]; q--) {
+                    int ti = seli[q]; seli[q] = seli[q - 1]; seli[q - 1] = ti; double td = seld[q]; seld[q] = seld[q - 1]; seld[q - 1] = td;
+                }
+        }
+        if (lane < nsel) {
+            int r = lane; double dd = seld[0]; int ii = seli[0];
+#pragma unroll
+            for (int k = 1; k < 8; k++) if (r == k) { dd = seld[k]; ii = seli[k]; }
+            double q = dd / p.h; q = q * q;
+            double K = (1.0 - q) * 3.0 / 4.0;                  // :193
+            double *pt = pts[npts + r];
+            pt[0] = base[0 * p.lap_stride + ii]; pt[1] = base[1 * p.lap_stride + ii]; pt[2] = base[2 * p.lap_stride + ii];
+            pt[3] = base[6 * p.lap_stride + ii]; pt[4] = base[7 * p.lap_stride + ii]; pt[5] = K;
+            pt[6] = base[0 * p.lap_stride + ii + 1]; pt[7] = base[1 * p.lap_stride + ii + 1]; pt[8] = base[2 * p.lap_stride + ii + 1];
+        }
+        npts += nsel;
+    }
+    __syncthreads();
+
+    // ---- compute_Q_M / compute_b (:141-168): Q = M' diag(K) M (+ lamb I), b = -M' diag(K) y --------------
+    if (lane < 45) {
+        int sys, e;                      // sys 0: vx system (input feature a), 1: lateral (input feature delta)
+        if (lane < 20) { sys = 0; e = lane; } else { sys = 1; e = lane - 20; }
+        const int fin = sys == 0 ? 4 : 3;        // column of pts holding the input feature
+        double acc = 0.0;
+        if (e < 15) {
+            int r = 0, cc = e; while (cc >= 5 - r) { cc -= 5 - r; r++; } cc += r;      // upper-triangular (r, cc)
+            for (int q = 0; q < npts; q++) {
+                const double *pt = pts[q];
+                double fr = r < 3 ? pt[r] : (r == 3 ? pt[fin] : 1.0);
+                double fc = cc < 3 ? pt[cc] : (cc == 3 ? pt[fin] : 1.0);
+                acc = fma(fr * pt[5], fc, acc);
+            }
+            if (r == cc) acc += p.lamb;
+        } else {
+            int r = (e - 15) % 5, tgt = sys == 0 ? 0 : 1 + (e - 15) / 5;
+            for (int q = 0; q < npts; q++) {
+                const double *pt = pts[q];
+                double fr = r < 3 ? pt[r] : (r == 3 ? pt[fin] : 1.0);
+                acc = fma(fr * pt[5], pt[6 + tgt], acc);
+            }
+            acc = -acc;
+        }
+        gram[lane] = acc;
+    }
+    __syncthreads();
+
+    // ---- LMPC_LocLinReg (:170-178): unconstrained qp(Q, b)  <=>  Q theta = -b ; Cholesky 5x5 --------------
+    if (lane < 3) {
+        const double *Qv = lane == 0 ? &gram[0] : &gram[20];
+        const double *bv = lane == 0 ? &gram[15] : (lane == 1 ? &gram[35] : &gram[40]);
+        double Lm[5][5]; int bad = 0;
+        { int e = 0; for (int r = 0; r < 5; r++) for (int c = r; c < 5; c++) { Lm[c][r] = Qv[e]; Lm[r][c] = Qv[e]; e++; } }
+        for (int j = 0; j < 5; j++) {
+            double dj = Lm[j][j];
+            for (int k = 0; k < j; k++) dj -= Lm[j][k] * Lm[j][k];
+            if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
+            dj = sqrt(dj); Lm[j][j] = dj;
+            for (int r = j + 1; r < 5; r++) {
+                double v = Lm[r][j];
+                for (int k = 0; k < j; k++) v -= Lm[r][k] * Lm[j][k];
+                Lm[r][j] = v / dj;
+            }
+        }
+        double y[5];
+        for (int r = 0; r < 5; r++) { double v = -bv[r]; for (int k = 0; k < r; k++) v -= Lm[r][k] * y[k]; y[r] = v / Lm[r][r]; }
+        for (int r = 4; r >= 0; r--) { double v = y[r]; for (int k = r + 1; k < 5; k++) v -= Lm[k][r] * y[k]; y[r] = v / Lm[r][r]; }
+        for (int r = 0; r < 5; r++) theta[lane][r] = bad ? 0.0 : y[r];
+        if (bad || npts < 5) atomicOr(&st_sh, LMPC_ST_REG_SINGULAR);
+    }
+    if (lane < 54) outv[lane] = 0.0;
+    __syncthreads();
+
+    // ---- assemble A_i, B_i, C_i (:70-135) -----------------------------------------------------------------
+    if (lane == 0) {
+        double *Ai = outv, *Bi = outv + 36, *Ci = outv + 48;
+        for (int r = 0; r < 3; r++) { Ai[r * 6 + 0] = theta[r][0]; Ai[r * 6 + 1] = theta[r][1]; Ai[r * 6 + 2] = theta[r][2]; Ci[r] = theta[r][4]; }
+        Bi[0 * 2 + 1] = theta[0][3]; Bi[1 * 2 + 0] = theta[1][3]; Bi[2 * 2 + 0] = theta[2][3];
+        const double vx = xq[0], vy = xq[1], wz = xq[2], epsi = xq[3], s = xq[4], ey = xq[5], dt = p.dt;
+        int bad = 0;
+        const double cur = track_curvature(p, s, &bad);
+        if (bad) atomicOr(&st_sh, LMPC_ST_NO_SEGMENT);
+        const double den = 1 - cur * ey, ce = cos(epsi), se = sin(epsi);
+        const double xv[6] = {vx, vy, wz, epsi, s, ey};
+        double row[6], dot;
+        row[0] = -dt * ce / den * cur; row[1] = dt * se / den * cur; row[2] = dt;
+        row[3] = 1 - dt * (-vx * se - vy * ce) / den * cur; row[4] = 0;
+        row[5] = dt * (vx * ce - vy * se) / (den * den) * cur * (-cur);
+        dot = 0; for (int j = 0; j < 6; j++) { Ai[18 + j] = row[j]; dot += row[j] * xv[j]; }
+        Ci[3] = epsi + dt * (wz - (vx * ce - vy * se) / (1 - cur * ey) * cur) - dot;
+        row[0] = dt * (ce / den); row[1] = -dt * (se / den); row[2] = 0; row[3] = dt * (-vx * se - vy * ce) / den; row[4] = 1;
+        row[5] = -dt * (vx * ce - vy * se) / (den * den) * (-cur);
+        dot = 0; for (int j = 0; j < 6; j++) { Ai[24 + j] = row[j]; dot += row[j] * xv[j]; }
+        Ci[4] = s + dt * ((vx * ce - vy * se) / (1 - cur * ey)) - dot;
+        row[0] = dt * se; row[1] = dt * ce; row[2] = 0; row[3] = dt * (vx * ce - vy * se); row[4] = 0; row[5] = 1;
+        dot = 0; for (int j = 0; j < 6; j++) { Ai[30 + j] = row[j]; dot += row[j] * xv[j]; }
+        Ci[5] = ey + dt * (vx * se + vy * ce) - dot;
+    }
+    __syncthreads();
+    if (lane < 36) Aout[(size_t)item * 36 + lane] = outv[lane];
+    else if (lane < 48) Bout[(size_t)item * 12 + (lane - 36)] = outv[lane];
+    else if (lane < 54) Cout[(size_t)item * 6 + (lane - 48)] = outv[lane];
+    if (lane == 0) status[item] = st_sh;
+}
+
+// =====================================================================================================
+// K2 + K3: safe-set selection + structured primal-dual interior-point QP solve.  One wave per QP.
+// =====================================================================================================
+struct lmpc_solve_io {
+    // mode bit 0: select the safe set on device (else read ssSel/qSel); bit 1: run the QP solve
+    int mode;
+    const double *A, *Bm, *C, *x0, *uOld, *ssSelIn, *qSelIn;
+    const double *zt, *xPredPrev; const int *hasPred, *timeStep;
+    double *xPred, *uPred, *slack, *lambda, *sTerm, *mu, *ztNext, *ztuNext;
+    double *ssSelOut, *qSelOut, *succOut, *succUOut, *ztUsed, *resid;
+    int *status, *iters;
+};
+
+struct lds_layout {
+    int A, B, C, x, u, s, lam, dx, du, ds, dl, nu, dnu, m, t, th, h, tp, dm, dtv, rx, ru, rs, rl, Phi, Mi, gam, gup, pst, phi, k0,
+        kap, Ds, eta, e, Pi, T1, T2, Mxx, Mxu, Muu, Qm, Ra, Rb, R, Ri, sqD, ct, SS, Qsel, Succ, SuccU, y7, w7, PiT, sT, tot;
+};
+__host__ __device__ inline lds_layout make_layout(int N, int S) {
+    lds_layout L; int o = 0; const int M = 8 * N + S;
+#define AL(name, n) L.name = o; o += (n);
+    AL(A, 36 * N) AL(B, 12 * N) AL(C, 6 * N)
+    AL(x, 6 * (N + 1)) AL(u, 2 * N) AL(s, 2 * N) AL(lam, S)
+    AL(dx, 6 * (N + 1)) AL(du, 2 * N) AL(ds, 2 * N) AL(dl, S)
+    AL(nu, 6 * N) AL(dnu, 6 * N)
+    AL(m, M) AL(t, M) AL(th, M) AL(h, M) AL(tp, M) AL(dm, M) AL(dtv, M)
+    AL(rx, 6 * (N + 1)) AL(ru, 2 * N) AL(rs, 2 * N) AL(rl, S)
+    AL(Phi, 64 * N) AL(Mi, 4 * N) AL(gam, 8 * N) AL(gup, 2 * N) AL(pst, 8 * (N + 1)) AL(phi, 8 * N) AL(k0, 2 * N)
+    AL(kap, 2 * N) AL(Ds, 2 * N) AL(eta, 2 * N) AL(e, 2 * N)
+    AL(Pi, 64) AL(T1, 36) AL(T2, 12) AL(Mxx, 36) AL(Mxu, 12) AL(Muu, 4)
+    AL(Qm, 7 * WAVE) AL(Ra, 49) AL(Rb, 49) AL(R, 49) AL(Ri, 49) AL(sqD, WAVE) AL(ct, WAVE)
+    AL(SS, 6 * S) AL(Qsel, S) AL(Succ, 6 * S) AL(SuccU, 2 * S) AL(y7, 8) AL(w7, 8) AL(PiT, 36) AL(sT, 8)
+#undef AL
+    L.tot = o;
+    return L;
+}
+
+#define FOR_LANES(idx, n) for (int idx = lane; idx < (n); idx += WAVE)
+
+__global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
+    extern __shared__ double sm[];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int lane = threadIdx.x;
+    const int N = p.N, S = p.S, M = 8 * N + S;
+    const bool term = S > 0;
+    const lds_layout L = make_layout(N, S);
+    double *A = sm + L.A, *Bm = sm + L.B, *C = sm + L.C, *x = sm + L.x, *u = sm + L.u, *s = sm + L.s, *lam = sm + L.lam;
+    double *dx = sm + L.dx, *du = sm + L.du, *ds = sm + L.ds, *dl = sm + L.dl, *nu = sm + L.nu, *dnu = sm + L.dnu;
+    double *m = sm + L.m, *t = sm + L.t, *th = sm + L.th, *h = sm + L.h, *tp = sm + L.tp, *dm = sm + L.dm, *dtv = sm + L.dtv;
+    double *rx = sm + L.rx, *ru = sm + L.ru, *rs = sm + L.rs, *rl = sm + L.rl;
+    double *Phi = sm + L.Phi, *Mi = sm + L.Mi, *gam = sm + L.gam, *gup = sm + L.gup, *pst = sm + L.pst, *phi = sm + L.phi, *k0 = sm + L.k0;
+    double *kap = sm + L.kap, *Dsl = sm + L.Ds, *eta = sm + L.eta, *ee = sm + L.e;
+    double *Pi = sm + L.Pi, *T1 = sm + L.T1, *T2 = sm + L.T2, *Mxx = sm + L.Mxx, *Mxu = sm + L.Mxu, *Muu = sm + L.Muu;
+    double *Qm = sm + L.Qm, *Ra = sm + L.Ra, *Rb = sm + L.Rb, *Rm = sm + L.R, *Ri = sm + L.Ri, *sqD = sm + L.sqD, *ct = sm + L.ct;
+    double *SS = sm + L.SS, *Qsel = sm + L.Qsel, *Succ = sm + L.Succ, *SuccU = sm + L.SuccU, *y7 = sm + L.y7, *w7 = sm + L.w7, *PiT = sm + L.PiT, *sT = sm + L.sT;
+    __shared__ int st_sh;
+    if (lane == 0) st_sh = 0;
+    __syncthreads();
+
+    // ------------------------------------------------------------------------------------------------
+    // K2: safe-set selection.  LMPC.addTerminalComponents :392-412 and selectPoints :478-514.
+    // ------------------------------------------------------------------------------------------------
+    if (term) {
+        if (io.mode & 1) {
+            double ztv[6];
+            for (int j = 0; j < 6; j++) ztv[j] = io.zt[(size_t)b * 6 + j];
+            const double x04 = io.x0[(size_t)b * 6 + 4];
+            if (ztv[4] - x04 > p.TL / 2) ztv[4] = fmax(ztv[4] - p.TL, 0.0);        // :392-393
+            if (io.ztUsed && lane < 6) io.ztUsed[(size_t)b * 6 + lane] = ztv[lane];
+            // prediction-crossing bookkeeping for the Q-function shift (:502-512)
+            const int hasPred = io.hasPred ? io.hasPred[b] : 0;
+            int crossed = 0;
+            if (hasPred) for (int k = 0; k <= N; k++) crossed += (io.xPredPrev[((size_t)b * (N + 1) + k) * 6 + 4] > p.TL) ? 1 : 0;
+            const int tstep = io.timeStep ? io.timeStep[b] : 0;
+            const int npw = p.ppl + 1;                                              // numSS_Points/numSS_it + 1 (=13)
+            for (int l = 0; l < p.L; l++) {
+                const double *base = p.sstore + (size_t)p.sslot[l] * LMPC_COLS * p.lap_stride;
+                const int T = p.sslen[l];
+                double best = INFINITY; int bi = 0x7fffffff;
+                for (int r = lane; r < T; r += WAVE) {
+                    double nrm = fabs(base[0 * p.lap_stride + r] - ztv[0]);         // la.norm(x - zt, 1, axis=1)
+                    nrm = nrm + fabs(base[1 * p.lap_stride + r] - ztv[1]);
+                    nrm = nrm + fabs(base[2 * p.lap_stride + r] - ztv[2]);
+                    nrm = nrm + fabs(base[3 * p.lap_stride + r] - ztv[3]);
+                    nrm = nrm + fabs(base[4 * p.lap_stride + r] - ztv[4]);
+                    nrm = nrm + fabs(base[5 * p.lap_stride + r] - ztv[5]);
+                    if (nrm < best) { best = nrm; bi = r; }
+                }
+                wave_argmin(best, bi);                                              // np.argmin: first minimum
+                const int MinNorm = bi;
+                const int start = ((double)MinNorm - (double)npw / 2.0 >= 0.0) ? MinNorm - npw / 2 : MinNorm;   // :492-495
+                if (start + npw > T && lane == 0) atomicOr(&st_sh, LMPC_ST_WINDOW);
+                double shift = 0.0;                                                 // :502-512
+                if (hasPred && crossed > 0) {
+                    if (p.sslapid[l] < p.cur_it - 1) shift = base[8 * p.lap_stride + 0];
+                    else shift = (double)tstep + (double)(N - crossed);
+                }
+                if (lane < p.ppl) {
+                    int r0 = start + lane; if (r0 > T - 1) r0 = T - 1; if (r0 < 0) r0 = 0;
+                    int r1 = start + lane + 1; if (r1 > T - 1) r1 = T - 1; if (r1 < 0) r1 = 0;
+                    const int col = l * p.ppl + lane;
+                    for (int j = 0; j < 6; j++) { SS[j * S + col] = base[j * p.lap_stride + r0]; Succ[j * S + col] = base[j * p.lap_stride + r1]; }
+                    SuccU[0 * S + col] = base[6 * p.lap_stride + r1]; SuccU[1 * S + col] = base[7 * p.lap_stride + r1];
+                    Qsel[col] = base[8 * p.lap_stride + r0] + shift;
+                }
+            }
+        } else {
+            FOR_LANES(c, S) {
+                for (int j = 0; j < 6; j++) { SS[j * S + c] = io.ssSelIn[((size_t)b * S + c) * 6 + j]; Succ[j * S + c] = 0.0; }
+                SuccU[c] = 0.0; SuccU[S + c] = 0.0;
+                Qsel[c] = io.qSelIn[(size_t)b * S + c];
+            }
+        }
+        __syncthreads();
+        FOR_LANES(c, S) {
+            if (io.ssSelOut) for (int j = 0; j < 6; j++) io.ssSelOut[((size_t)b * S + c) * 6 + j] = SS[j * S + c];
+            if (io.qSelOut) io.qSelOut[(size_t)b * S + c] = Qsel[c];
+            if (io.succOut) for (int j = 0; j < 6; j++) io.succOut[((size_t)b * S + c) * 6 + j] = Succ[j * S + c];
+            if (io.succUOut) { io.succUOut[((size_t)b * S + c) * 2 + 0] = SuccU[c]; io.succUOut[((size_t)b * S + c) * 2 + 1] = SuccU[S + c]; }
+        }
+    }
+    if (!(io.mode & 2)) { if (lane == 0) io.status[b] = st_sh; return; }
+
+    // ------------------------------------------------------------------------------------------------
+    // K3: QP solve.  Variables z = [x_0..x_N | u_0..u_{N-1} | s (2N) | lambda (S) | s_T (6)] exactly as
+    // LMPC.unpackSolution (:364-375); inequality rows in the reference's order (buildIneqConstr :166-198,
+    // addSafeSetIneqConstr :340-343).  s_T is eliminated (s_T = SS lambda - x_N).
+    // ------------------------------------------------------------------------------------------------
+    FOR_LANES(i, 36 * N) A[i] = io.A[(size_t)b * 36 * N + i];
+    FOR_LANES(i, 12 * N) Bm[i] = io.Bm[(size_t)b * 12 * N + i];
+    FOR_LANES(i, 6 * N) C[i] = io.C[(size_t)b * 6 * N + i];
+    if (lane < 6) x[lane] = io.x0[(size_t)b * 6 + lane];
+    FOR_LANES(i, 2 * N) u[i] = 0.0;
+    FOR_LANES(i, 6 * N) nu[i] = 0.0;
+    const double uOld0 = io.uOld[(size_t)b * 2 + 0], uOld1 = io.uOld[(size_t)b * 2 + 1];
+    __syncthreads();
+    for (int k = 0; k < N; k++) {                      // strictly interior start: u = 0, x by roll-out
+        if (lane < 6) {
+            double v = C[k * 6 + lane];
+            for (int j = 0; j < 6; j++) v = fma(A[k * 36 + lane * 6 + j], x[k * 6 + j], v);
+            x[(k + 1) * 6 + lane] = v;
+        }
+        __syncthreads();
+    }
+    FOR_LANES(i, 2 * N) {
+        const int k = i >> 1, j = i & 1; double f = 0.0;
+        for (int c = 0; c < 6; c++) f = fma(p.Fx[j * 6 + c], x[k * 6 + c], f);
+        s[i] = fmax(f - p.bx[j], 0.0) + 1.0;
+    }
+    double qmax = 0.0;
+    FOR_LANES(c, S) { lam[c] = 1.0 / (double)S; qmax = fmax(qmax, fabs(Qsel[c])); }
+    qmax = wave_max(qmax);
+    const double mu0 = fmax(1.0, 0.01 * (term ? qmax : 1.0));
+    if (lane < 4 && !(p.bu[lane] > 0.0)) atomicOr(&st_sh, LMPC_ST_NOT_INTERIOR);
+    double eta_m = 0.0;
+    __syncthreads();
+
+    // row helpers ------------------------------------------------------------------------------------
+    // F_r . (x,u,s,lam) for row r in the reference's ordering
+    auto rowF = [&](int r, const double *xx, const double *uu, const double *ss_, const double *ll) -> double {
+        if (r < 2 * N) { const int k = r >> 1, j = r & 1; double f = 0.0; for (int c = 0; c < 6; c++) f = fma(p.Fx[j * 6 + c], xx[k * 6 + c], f); return f - ss_[r]; }
+        if (r < 6 * N) { const int q = r - 2 * N, k = q >> 2, j = q & 3; return p.Fu[j * 2] * uu[k * 2] + p.Fu[j * 2 + 1] * uu[k * 2 + 1]; }
+        if (r < 8 * N) return -ss_[r - 6 * N];
+        return -ll[r - 8 * N];
+    };
+    auto rowb = [&](int r) -> double { if (r < 2 * N) return p.bx[r & 1]; if (r < 6 * N) return p.bu[(r - 2 * N) & 3]; return 0.0; };
+
+    FOR_LANES(r, M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t[r] = tt; m[r] = mu0 / tt; }
+    __syncthreads();
+
+    // one Newton-system solve for the right-hand side currently in (rx,ru,rs,rl,h); result in dx,du,ds,dl
+    auto kkt_solve = [&](double re_sum) {
+        FOR_LANES(i, 2 * N) {                                   // slack elimination, per lane row (k,j)
+            const double hl = h[i], hs = h[6 * N + i];
+            const double e_ = -(rs[i] + hl + hs);
+            ee[i] = e_; eta[i] = hl + th[i] * e_ / Dsl[i];
+        }
+        if (term) {
+            double c_ = 0.0;
+            if (lane < S) c_ = (rl[lane] + h[8 * N + lane]) / sqD[lane];
+            ct[lane] = c_;
+            double yy[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) yy[j] = wave_sum(Qm[j * WAVE + lane] * c_);
+            if (lane < 7) {
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < 7; j++) if (lane == j) v = yy[j];
+                y7[lane] = v;
+            }
+        }
+        __syncthreads();
+        if (term && lane < 7) {                                 // w7 = Ri (Ri' d0 + y7), d0 = (0,..,0,-re_sum)
+            double v = Ri[6 * 7 + lane] * (-re_sum) + y7[lane];     // (Ri' d0)[lane] = Ri[6][lane] * d0[6]
+            sT[lane] = v;                                        // scratch
+        }
+        __syncthreads();
+        if (lane < 8) {
+            double v = 0.0;
+            if (lane < 6) {
+                v = rx[N * 6 + lane];
+                if (term) for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], sT[j], v);
+            }
+            pst[N * 8 + lane] = v;
+        }
+        FOR_LANES(i, 2 * N) {                                   // gu' = ru - Fu' h_u
+            const int k = i >> 1, c = i & 1; double v = ru[i];
+            for (int j = 0; j < 4; j++) v -= p.Fu[j * 2 + c] * h[2 * N + 4 * k + j];
+            gup[i] = v;
+        }
+        __syncthreads();
+        FOR_LANES(i, 8 * N) {                                   // gamma_k = [gx' - Kx' gu' ; -Ku' gu'] = [gx';0] + Phi[6:8,:]' gu'
+            const int k = i >> 3, c = i & 7;
+            double v = 0.0;
+            if (c < 6) { v = rx[k * 6 + c]; v -= p.Fx[0 * 6 + c] * eta[2 * k] + p.Fx[1 * 6 + c] * eta[2 * k + 1]; }
+            v = fma(Phi[k * 64 + 6 * 8 + c], gup[2 * k], v);
+            v = fma(Phi[k * 64 + 7 * 8 + c], gup[2 * k + 1], v);
+            gam[i] = v;
+        }
+        __syncthreads();
+        for (int k = N - 1; k >= 0; k--) {                      // backward sweep: p_k = Phi_k' p_{k+1} + gamma_k
+            if (lane < 8) {
+                double v = gam[k * 8 + lane];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v = fma(Phi[k * 64 + j * 8 + lane], pst[(k + 1) * 8 + j], v);
+                pst[k * 8 + lane] = v;
+            }
+            __syncthreads();
+        }
+        FOR_LANES(i, 2 * N) {                                   // k0_k = Mi_k (gu' + B' p_x + p_u)
+            const int k = i >> 1;
+            double w0 = gup[2 * k] + pst[(k + 1) * 8 + 6], w1 = gup[2 * k + 1] + pst[(k + 1) * 8 + 7];
+            for (int j = 0; j < 6; j++) { w0 = fma(Bm[k * 12 + j * 2], pst[(k + 1) * 8 + j], w0); w1 = fma(Bm[k * 12 + j * 2 + 1], pst[(k + 1) * 8 + j], w1); }
+            const int c = i & 1;
+            k0[i] = Mi[k * 4 + c * 2] * w0 + Mi[k * 4 + c * 2 + 1] * w1;
+        }
+        __syncthreads();
+        FOR_LANES(i, 8 * N) {                                   // phi_k = [-B k0 ; -k0]
+            const int k = i >> 3, c = i & 7;
+            phi[i] = c < 6 ? -(Bm[k * 12 + c * 2] * k0[2 * k] + Bm[k * 12 + c * 2 + 1] * k0[2 * k + 1]) : -k0[2 * k + (c - 6)];
+        }
+        if (lane < 6) dx[lane] = 0.0;
+        __syncthreads();
+        for (int k = 0; k < N; k++) {                           // forward sweep: xi_{k+1} = Phi_k xi_k + phi_k
+            if (lane < 8) {
+                double v = phi[k * 8 + lane];
+#pragma unroll
+                for (int j = 0; j < 6; j++) v = fma(Phi[k * 64 + lane * 8 + j], dx[k * 6 + j], v);
+                if (k > 0) { v = fma(Phi[k * 64 + lane * 8 + 6], du[(k - 1) * 2], v); v = fma(Phi[k * 64 + lane * 8 + 7], du[(k - 1) * 2 + 1], v); }
+                if (lane < 6) dx[(k + 1) * 6 + lane] = v; else du[k * 2 + (lane - 6)] = v;
+            }
+            __syncthreads();
+        }
+        FOR_LANES(i, 2 * N) {
+            const int k = i >> 1, j = i & 1; double f = 0.0;
+            for (int c = 0; c < 6; c++) f = fma(p.Fx[j * 6 + c], dx[k * 6 + c], f);
+            ds[i] = (th[i] * f + ee[i]) / Dsl[i];
+        }
+        if (term) {
+            if (lane < 7) {                                     // z7 = Ri' d7, d7 = (dx_N ; -re_sum)
+                double v = 0.0;
+                for (int j = 0; j <= lane; j++) v = fma(Ri[j * 7 + lane], j < 6 ? dx[N * 6 + j] : -re_sum, v);
+                w7[lane] = v;
+            }
+            __syncthreads();
+            double v = -ct[lane];
+#pragma unroll
+            for (int j = 0; j < 7; j++) v = fma(Qm[j * WAVE + lane], y7[j] + w7[j], v);
+            if (lane < S) dl[lane] = v / sqD[lane];
+        }
+        __syncthreads();
+    };
+
+    int it = 0, converged = 0;
+    double gap = 0.0, rdn = 0.0, ren = 0.0;
+    for (it = 0; it <= p.max_iter; it++) {
+        // ---- slacks of the inequality rows, terminal slack, residuals --------------------------------
+        FOR_LANES(r, M) t[r] = rowb(r) - rowF(r, x, u, s, lam);
+        if (term && lane < 6) { double v = -x[N * 6 + lane]; for (int c = 0; c < S; c++) v = fma(SS[lane * S + c], lam[c], v); sT[lane] = v; }
+        __syncthreads();
+        double gsum = 0.0, rmax = 0.0, remax = 0.0;
+        FOR_LANES(r, M) gsum = fma(t[r], m[r], gsum);
+        FOR_LANES(i, 6 * (N + 1)) {
+            const int k = i / 6, c = i % 6; double v = 0.0;
+            if (k >= 1) {
+                const double *Qk = k < N ? p.Q2 : p.Qf2;
+                for (int j = 0; j < 6; j++) v = fma(Qk[c * 6 + j], x[k * 6 + j] - p.xRef[j], v);
+                v += nu[(k - 1) * 6 + c];
+                if (k < N) {
+                    v += p.Fx[0 * 6 + c] * m[2 * k] + p.Fx[1 * 6 + c] * m[2 * k + 1];
+                    for (int j = 0; j < 6; j++) v -= A[k * 36 + j * 6 + c] * nu[k * 6 + j];
+                } else if (term) v -= p.T2[c] * sT[c];
+                rmax = fmax(rmax, fabs(v));
+            }
+            rx[i] = v;
+        }
+        FOR_LANES(i, 2 * N) {
+            const int k = i >> 1, c = i & 1;
+            const double up = k > 0 ? u[(k - 1) * 2 + c] : (c == 0 ? uOld0 : uOld1);
+            double v = p.R2[c * 2] * u[k * 2] + p.R2[c * 2 + 1] * u[k * 2 + 1] + p.dR2[c] * (u[i] - up);
+            if (k < N - 1) v += p.dR2[c] * (u[i] - u[(k + 1) * 2 + c]);
+            for (int j = 0; j < 4; j++) v = fma(p.Fu[j * 2 + c], m[2 * N + 4 * k + j], v);
+            for (int j = 0; j < 6; j++) v -= Bm[k * 12 + j * 2 + c] * nu[k * 6 + j];
+            ru[i] = v; rmax = fmax(rmax, fabs(v));
+            const double vs = p.a_s * s[i] + p.c_s - m[i] - m[6 * N + i];
+            rs[i] = vs; rmax = fmax(rmax, fabs(vs));
+        }
+        double lsum = 0.0;
+        FOR_LANES(c, S) {
+            double v = Qsel[c] - m[8 * N + c] + eta_m;
+            for (int j = 0; j < 6; j++) v = fma(SS[j * S + c], p.T2[j] * sT[j], v);
+            rl[c] = v; rmax = fmax(rmax, fabs(v)); lsum += lam[c];
+        }
+        FOR_LANES(i, 6 * N) {                                    // dynamics residual (monitoring only)
+            const int k = i / 6, c = i % 6;
+            double v = x[(k + 1) * 6 + c] - C[i] - Bm[k * 12 + c * 2] * u[k * 2] - Bm[k * 12 + c * 2 + 1] * u[k * 2 + 1];
+            for (int j = 0; j < 6; j++) v -= A[k * 36 + c * 6 + j] * x[k * 6 + j];
+            remax = fmax(remax, fabs(v));
+        }
+        gap = wave_sum(gsum) / (double)M;
+        rdn = wave_max(rmax);
+        const double re_sum = term ? wave_sum(lsum) - 1.0 : 0.0;
+        ren = fmax(wave_max(remax), fabs(re_sum));
+        if (gap < p.tol_gap && rdn < p.tol_res && ren < p.tol_res) { converged = 1; break; }
+        if (it == p.max_iter) break;
+        if (!(gap == gap) || !(rdn == rdn)) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
+
+        // ---- factorisation of the Newton (block-banded KKT) matrix -------------------------------------
+        FOR_LANES(r, M) th[r] = m[r] / t[r];
+        __syncthreads();
+        FOR_LANES(i, 2 * N) {
+            const double d_ = p.a_s + th[i] + th[6 * N + i];
+            Dsl[i] = d_; kap[i] = th[i] * (p.a_s + th[6 * N + i]) / d_;
+        }
+        FOR_LANES(i, 64) Pi[i] = 0.0;
+        __syncthreads();
+        if (term) {
+            // terminal block: M = [E D^-1/2 | T7^-1/2] (7 x (S+6)), M' = Q R by twice-applied MGS, one column of M per lane
+            double q[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) q[j] = 0.0;
+            if (lane < S) {
+                const double sd = sqrt(th[8 * N + lane] + p.reg); sqD[lane] = sd;
+#pragma unroll
+                for (int j = 0; j < 6; j++) q[j] = SS[j * S + lane] / sd;
+                q[6] = 1.0 / sd;
+            } else if (lane < S + 6) {
+                sqD[lane] = 1.0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) if (lane - S == j) q[j] = 1.0 / sqrt(p.T2[j]);
+            } else sqD[lane] = 1.0;
+            for (int pass = 0; pass < 2; pass++) {
+                double *Rp = pass == 0 ? Ra : Rb;
+#pragma unroll
+                for (int i = 0; i < 7; i++) {
+                    const double nrm = sqrt(wave_sum(q[i] * q[i]));
+                    q[i] = q[i] / nrm;
+                    if (lane == 0) Rp[i * 7 + i] = nrm;
+#pragma unroll
+                    for (int j = 0; j < 7; j++) if (j > i) {
+                        const double rij = wave_sum(q[i] * q[j]);
+                        q[j] = fma(-rij, q[i], q[j]);
+                        if (lane == 0) { Rp[i * 7 + j] = rij; Rp[j * 7 + i] = 0.0; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 7; j++) Qm[j * WAVE + lane] = q[j];
+            __syncthreads();
+            if (lane < 49) {                                     // R = Rb Ra (upper triangular)
+                const int i = lane / 7, j = lane % 7; double v = 0.0;
+                for (int k = i; k <= j; k++) v = fma(Rb[i * 7 + k], Ra[k * 7 + j], v);
+                Rm[lane] = v;
+            }
+            __syncthreads();
+            if (lane < 7) {                                      // Ri = R^-1, column `lane` by back substitution
+                const int j = lane;
+                double col[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) col[i] = 0.0;
+                for (int i = 6; i >= 0; i--) {
+                    if (i > j) continue;
+                    double v = (i == j) ? 1.0 : 0.0;
+                    for (int k = i + 1; k <= j; k++) v -= Rm[i * 7 + k] * col[k];
+                    col[i] = v / Rm[i * 7 + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 7; i++) Ri[i * 7 + j] = col[i];
+            }
+            __syncthreads();
+            if (lane < 36) {                                     // Pi_term = (Ri Ri')[0:6,0:6]
+                const int i = lane / 6, j = lane % 6; double v = 0.0;
+                for (int k = (i > j ? i : j); k < 7; k++) v = fma(Ri[i * 7 + k], Ri[j * 7 + k], v);
+                PiT[lane] = v;
+            }
+            __syncthreads();
+        }
+        if (lane < 36) { const int i = lane / 6, j = lane % 6; Pi[i * 8 + j] = p.Qf2[lane] + (term ? PiT[lane] : 0.0); }
+        __syncthreads();
+        int numeric_bad = 0;
+        for (int k = N - 1; k >= 0; k--) {
+            const double *Ak = A + k * 36, *Bk = Bm + k * 12;
+            if (lane < 36) {                                     // T1 = Pxx A
+                const int i = lane / 6, j = lane % 6; double v = 0.0;
+#pragma unroll
+                for (int l = 0; l < 6; l++) v = fma(Pi[i * 8 + l], Ak[l * 6 + j], v);
+                T1[lane] = v;
+            } else if (lane < 48) {                              // T2 = Pxx B + Pxu
+                const int q = lane - 36, i = q >> 1, c = q & 1; double v = Pi[i * 8 + 6 + c];
+#pragma unroll
+                for (int l = 0; l < 6; l++) v = fma(Pi[i * 8 + l], Bk[l * 2 + c], v);
+                T2[q] = v;
+            }
+            __syncthreads();
+            if (lane < 36) {                                     // Mxx = Hx + A' T1
+                const int i = lane / 6, j = lane % 6;
+                double v = p.Q2[lane] + kap[2 * k] * p.Fx[i] * p.Fx[j] + kap[2 * k + 1] * p.Fx[6 + i] * p.Fx[6 + j];
+#pragma unroll
+                for (int l = 0; l < 6; l++) v = fma(Ak[l * 6 + i], T1[l * 6 + j], v);
+                Mxx[lane] = v;
+            } else if (lane < 48) {                              // Mxu = A' T2
+                const int q = lane - 36, i = q >> 1, c = q & 1; double v = 0.0;
+#pragma unroll
+                for (int l = 0; l < 6; l++) v = fma(Ak[l * 6 + i], T2[l * 2 + c], v);
+                Mxu[q] = v;
+            } else if (lane < 52) {                              // Muu = Hu + 2dR + B'T2 + Pxu'B + Puu
+                const int q = lane - 48, c = q >> 1, d = q & 1;
+                double v = p.R2[q] + (c == d ? p.dR2[c] : 0.0) + Pi[(6 + c) * 8 + 6 + d];
+                for (int j = 0; j < 4; j++) v = fma(th[2 * N + 4 * k + j] * p.Fu[j * 2 + c], p.Fu[j * 2 + d], v);
+#pragma unroll
+                for (int l = 0; l < 6; l++) { v = fma(Bk[l * 2 + c], T2[l * 2 + d], v); v = fma(Pi[l * 8 + 6 + c], Bk[l * 2 + d], v); }
+                Muu[q] = v;
+            }
+            __syncthreads();
+            const double det = Muu[0] * Muu[3] - Muu[1] * Muu[2];
+            if (!(det > 0.0) || !(Muu[0] > 0.0)) numeric_bad = 1;
+            const double i00 = Muu[3] / det, i01 = -Muu[1] / det, i10 = -Muu[2] / det, i11 = Muu[0] / det;
+            if (lane < 12) {                                     // Phi[6:8, 0:6] = -Kx = -Mi Mxu'
+                const int c = lane / 6, j = lane % 6;
+                const double kx = (c == 0 ? i00 : i10) * Mxu[j * 2] + (c == 0 ? i01 : i11) * Mxu[j * 2 + 1];
+                Phi[k * 64 + (6 + c) * 8 + j] = -kx;
+            } else if (lane < 16) {                              // Phi[6:8, 6:8] = -Ku = Mi 2dR
+                const int q = lane - 12, c = q >> 1, d = q & 1;
+                const double mi = c == 0 ? (d == 0 ? i00 : i01) : (d == 0 ? i10 : i11);
+                Phi[k * 64 + (6 + c) * 8 + 6 + d] = mi * p.dR2[d];
+                Mi[k * 4 + q] = mi;
+            }
+            __syncthreads();
+            const double *F6 = Phi + k * 64 + 48, *F7 = Phi + k * 64 + 56;      // rows -K (2 x 8)
+            if (lane < 36) {                                     // Pxx_new = Mxx - Mxu Kx ; Acl = A - B Kx
+                const int i = lane / 6, j = lane % 6;
+                Pi[i * 8 + j] = Mxx[lane] + Mxu[i * 2] * F6[j] + Mxu[i * 2 + 1] * F7[j];
+                Phi[k * 64 + i * 8 + j] = Ak[lane] + Bk[i * 2] * F6[j] + Bk[i * 2 + 1] * F7[j];
+            } else if (lane < 48) {                              // Pxu_new = -Mxu Ku ; Bcl = -B Ku
+                const int q = lane - 36, i = q >> 1, d = q & 1;
+                const double v = Mxu[i * 2] * F6[6 + d] + Mxu[i * 2 + 1] * F7[6 + d];
+                Pi[i * 8 + 6 + d] = v; Pi[(6 + d) * 8 + i] = v;
+                Phi[k * 64 + i * 8 + 6 + d] = Bk[i * 2] * F6[6 + d] + Bk[i * 2 + 1] * F7[6 + d];
+            } else if (lane < 52) {                              // Puu_new = 2dR + 2dR Ku
+                const int q = lane - 48, c = q >> 1, d = q & 1;
+                Pi[(6 + c) * 8 + 6 + d] = (c == d ? p.dR2[c] : 0.0) - p.dR2[c] * (c == 0 ? F6[6 + d] : F7[6 + d]);
+            }
+            __syncthreads();
+        }
+        if (numeric_bad) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
+
+        // ---- predictor (affine scaling) direction: h = mu -------------------------------------------------
+        FOR_LANES(r, M) h[r] = m[r];
+        __syncthreads();
+        kkt_solve(re_sum);
+        double amax = 1.0;
+        FOR_LANES(r, M) {
+            const double dta = -rowF(r, dx, du, ds, dl);
+            const double dma = -m[r] - th[r] * dta;
+            dtv[r] = dta; dm[r] = dma;
+            if (dta < 0.0) amax = fmin(amax, -t[r] / dta);
+            if (dma < 0.0) amax = fmin(amax, -m[r] / dma);
+        }
+        amax = wave_min(amax);
+        double gaff = 0.0;
+        FOR_LANES(r, M) { gaff = fma(t[r] + amax * dtv[r], m[r] + amax * dm[r], gaff); tp[r] = dtv[r] * dm[r]; }
+        gaff = wave_sum(gaff) / (double)M;
+        double sig = gaff / gap; sig = sig * sig * sig;
+        // ---- corrector: h = (t mu - sigma gap + dt_aff dmu_aff) / t ----------------------------------------
+        __syncthreads();
+        FOR_LANES(r, M) h[r] = (t[r] * m[r] - sig * gap + tp[r]) / t[r];
+        __syncthreads();
+        kkt_solve(re_sum);
+        double amx = INFINITY;
+        FOR_LANES(r, M) {
+            const double dtt = -rowF(r, dx, du, ds, dl);
+            const double dmm = -h[r] - th[r] * dtt;
+            dtv[r] = dtt; dm[r] = dmm;
+            if (dtt < 0.0) amx = fmin(amx, -t[r] / dtt);
+            if (dmm < 0.0) amx = fmin(amx, -m[r] / dmm);
+        }
+        amx = wave_min(amx);
+        const double al = fmin(1.0, 0.995 * amx);
+        __syncthreads();
+        // ---- multipliers of the equality rows (costates), backwards ----------------------------------------
+        if (term && lane < 6) { double v = -dx[N * 6 + lane]; for (int c = 0; c < S; c++) v = fma(SS[lane * S + c], dl[c], v); w7[lane] = v; }   // d s_T
+        __syncthreads();
+        if (lane < 6) {
+            double g = rx[N * 6 + lane];
+            for (int j = 0; j < 6; j++) g = fma(p.Qf2[lane * 6 + j], dx[N * 6 + j], g);
+            if (term) g -= p.T2[lane] * w7[lane];
+            dnu[(N - 1) * 6 + lane] = -g;
+        }
+        __syncthreads();
+        for (int k = N - 1; k >= 1; k--) {
+            if (lane < 6) {
+                double g = rx[k * 6 + lane] + p.Fx[lane] * dm[2 * k] + p.Fx[6 + lane] * dm[2 * k + 1];
+                for (int j = 0; j < 6; j++) { g = fma(p.Q2[lane * 6 + j], dx[k * 6 + j], g); g -= A[k * 36 + j * 6 + lane] * dnu[k * 6 + j]; }
+                dnu[(k - 1) * 6 + lane] = -g;
+            }
+            __syncthreads();
+        }
+        double deta = 0.0;
+        if (term) {
+            double v = 0.0;
+            if (lane < S) { v = -rl[lane] + dm[8 * N + lane]; for (int j = 0; j < 6; j++) v -= SS[j * S + lane] * p.T2[j] * w7[j]; }
+            deta = wave_sum(v) / (double)S;
+        }
+        // ---- step ------------------------------------------------------------------------------------------
+        FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
+        FOR_LANES(i, 2 * N) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
+        FOR_LANES(c, S) lam[c] = fma(al, dl[c], lam[c]);
+        FOR_LANES(r, M) m[r] = fma(al, dm[r], m[r]);
+        FOR_LANES(i, 6 * N) nu[i] = fma(al, dnu[i], nu[i]);
+        eta_m = fma(al, deta, eta_m);
+        __syncthreads();
+    }
+    if (!converged && lane == 0 && !(st_sh & LMPC_ST_NUMERIC)) atomicOr(&st_sh, LMPC_ST_MAXITER);
+    __syncthreads();
+
+    // ---- unpackSolution (:364-379) and feasibleStateInput (:382-384) -------------------------------------
+    FOR_LANES(i, 6 * (N + 1)) io.xPred[(size_t)b * 6 * (N + 1) + i] = x[i];
+    FOR_LANES(i, 2 * N) { io.uPred[(size_t)b * 2 * N + i] = u[i]; if (io.slack) io.slack[(size_t)b * 2 * N + i] = s[i]; }
+    if (io.mu) FOR_LANES(r, M) io.mu[(size_t)b * M + r] = m[r];
+    if (term) {
+        if (io.lambda) FOR_LANES(c, S) io.lambda[(size_t)b * S + c] = lam[c];
+        if (lane < 6) {
+            double v = -x[N * 6 + lane], z = 0.0;
+            for (int c = 0; c < S; c++) { v = fma(SS[lane * S + c], lam[c], v); z = fma(Succ[lane * S + c], lam[c], z); }
+            if (io.sTerm) io.sTerm[(size_t)b * 6 + lane] = v;
+            if (io.ztNext) io.ztNext[(size_t)b * 6 + lane] = z;
+        } else if (lane < 8 && io.ztuNext) {
+            double z = 0.0; const int c2 = lane - 6;
+            for (int c = 0; c < S; c++) z = fma(SuccU[c2 * S + c], lam[c], z);
+            io.ztuNext[(size_t)b * 2 + c2] = z;
+        }
+    } else {
+        if (lane < 6 && io.ztNext) io.ztNext[(size_t)b * 6 + lane] = x[N * 6 + lane];          // MPC.feasibleStateInput :157-159
+        if (lane < 2 && io.ztuNext) io.ztuNext[(size_t)b * 2 + lane] = u[(N - 1) * 2 + lane];
+    }
+    if (lane == 0) {
+        io.status[b] = st_sh; io.iters[b] = it;
+        if (io.resid) { io.resid[(size_t)b * 3] = gap; io.resid[(size_t)b * 3 + 1] = rdn; io.resid[(size_t)b * 3 + 2] = ren; }
+    }
+}
+
+// =====================================================================================================
+// Explicit reference-form QP (parity checks only): P (nz x nz), q, A_osqp = [F; G] (m x nz), l, u, dense
+// row-major.  Follows buildIneqConstr :166-198, buildCost :228-257, buildEqConstr :200-226,
+// addSafeSetIneqConstr :340-343, addSafeSetEqConstr :345-357, addSafeSetCost :359-362, osqp_solve_qp :269-273.
+// One work-group per problem; every thread fills a strided share of the entries.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void lmpc_assemble_kernel(lmpc_dev_params p, int B, const double *__restrict__ A, const double *__restrict__ Bm,
+                                                            const double *__restrict__ C, const double *__restrict__ x0, const double *__restrict__ uOld,
+                                                            const double *__restrict__ ssSel, const double *__restrict__ qSel,
+                                                            double *__restrict__ Pd, double *__restrict__ q, double *__restrict__ Ad,
+                                                            double *__restrict__ l, double *__restrict__ u) {
+    const int b = blockIdx.x; if (b >= B) return;
+    const int N = p.N, S = p.S, n = 6, d = 2;
+    const int ox = 0, ou = n * (N + 1), os = ou + d * N, ol = os + 2 * N, ot = ol + S, nz = S > 0 ? ot + n : ol;
+    const int mi = 8 * N + S, me = n * (N + 1) + (S > 0 ? n + 1 : 0), mm = mi + me;
+    double *Pb = Pd + (size_t)b * nz * nz, *Ab = Ad + (size_t)b * mm * nz, *qb = q + (size_t)b * nz, *lb = l + (size_t)b * mm, *ub = u + (size_t)b * mm;
+    const double *Ab_ = A + (size_t)b * 36 * N, *Bb_ = Bm + (size_t)b * 12 * N, *Cb_ = C + (size_t)b * 6 * N;
+    for (size_t i = threadIdx.x; i < (size_t)nz * nz; i += blockDim.x) Pb[i] = 0.0;
+    for (size_t i = threadIdx.x; i < (size_t)mm * nz; i += blockDim.x) Ab[i] = 0.0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nz; i += blockDim.x) {
+        double v = 0.0;
+        if (i < ou) { const int k = i / n, c = i % n; const double *Qk = k < N ? p.Q2 : p.Qf2; for (int j = 0; j < n; j++) v -= p.xRef[j] * Qk[j * 6 + c]; }
+        else if (i < os) { const int k = (i - ou) / d, c = (i - ou) % d; v = k == 0 ? -p.dR2[c] * uOld[(size_t)b * 2 + c] : 0.0; }
+        else if (i < ol) v = p.c_s;
+        else if (i < ot) v = qSel[(size_t)b * S + (i - ol)];
+        qb[i] = v;
+    }
+    // P
+    for (int i = threadIdx.x; i < (N + 1) * 36; i += blockDim.x) { const int k = i / 36, r = (i % 36) / 6, c = i % 6; Pb[(size_t)(k * 6 + r) * nz + k * 6 + c] = k < N ? p.Q2[r * 6 + c] : p.Qf2[r * 6 + c]; }
+    for (int i = threadIdx.x; i < N * 4; i += blockDim.x) {
+        const int k = i / 4, r = (i % 4) / 2, c = i % 2;
+        double v = p.R2[r * 2 + c]; if (r == c) v += (k < N - 1 ? 2.0 : 1.0) * p.dR2[r];
+        Pb[(size_t)(ou + k * 2 + r) * nz + ou + k * 2 + c] = v;
+        if (r == c && k < N - 1) { Pb[(size_t)(ou + k * 2 + r) * nz + ou + (k + 1) * 2 + r] = -p.dR2[r]; Pb[(size_t)(ou + (k + 1) * 2 + r) * nz + ou + k * 2 + r] = -p.dR2[r]; }
+    }
+    for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) Pb[(size_t)(os + i) * nz + os + i] = p.a_s;
+    if (S > 0) for (int i = threadIdx.x; i < 6; i += blockDim.x) Pb[(size_t)(ot + i) * nz + ot + i] = p.T2[i];
+    // inequality rows
+    for (int r = threadIdx.x; r < mi; r += blockDim.x) {
+        double *row = Ab + (size_t)r * nz; double bb = 0.0;
+        if (r < 2 * N) { const int k = r >> 1, j = r & 1; for (int c = 0; c < 6; c++) row[ox + k * 6 + c] = p.Fx[j * 6 + c]; row[os + r] = -1.0; bb = p.bx[j]; }
+        else if (r < 6 * N) { const int qd = r - 2 * N, k = qd >> 2, j = qd & 3; row[ou + k * 2] = p.Fu[j * 2]; row[ou + k * 2 + 1] = p.Fu[j * 2 + 1]; bb = p.bu[j]; }
+        else if (r < 8 * N) row[os + (r - 6 * N)] = -1.0;
+        else row[ol + (r - 8 * N)] = -1.0;
+        lb[r] = -INFINITY; ub[r] = bb;
+    }
+    // equality rows
+    for (int r = threadIdx.x; r < me; r += blockDim.x) {
+        double *row = Ab + (size_t)(mi + r) * nz; double be = 0.0;
+        if (r < 6) { row[r] = 1.0; be = x0[(size_t)b * 6 + r]; }
+        else if (r < 6 * (N + 1)) {
+            const int k = r / 6 - 1, c = r % 6;
+            row[(k + 1) * 6 + c] = 1.0;
+            for (int j = 0; j < 6; j++) row[k * 6 + j] += -Ab_[k * 36 + c * 6 + j];
+            row[ou + k * 2] = -Bb_[k * 12 + c * 2]; row[ou + k * 2 + 1] = -Bb_[k * 12 + c * 2 + 1];
+            be = Cb_[k * 6 + c];
+        } else if (r < 6 * (N + 1) + 6) {
+            const int c = r - 6 * (N + 1);
+            row[N * 6 + c] = 1.0;
+            for (int j = 0; j < S; j++) row[ol + j] = -ssSel[((size_t)b * S + j) * 6 + c];
+            row[ot + c] = 1.0;
+        } else { for (int j = 0; j < S; j++) row[ol + j] = 1.0; be = 1.0; }
+        lb[mi + r] = be; ub[mi + r] = be;
+    }
+}

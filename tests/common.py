@@ -1,0 +1,141 @@
+"""Shared helpers for the parity tests (and __graft_entry__.smoke)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# Stated parity tolerances (see DESIGN.md "Parity").
+TOL_ABC = 1e-9        # |A,B,C(gpu) - A,B,C(reference)| <= TOL_ABC * (1 + |ref|): regression normal matrices have cond 1e5..1e8
+TOL_XU = 1e-6         # |xPred,uPred(gpu) - certified optimum| (absolute); reference OSQP runs at eps_abs = eps_rel = 1e-3
+TOL_ZT = 1e-6         # |zt, zt_u|
+TOL_KKT = 1e-7        # solver-independent certificate of the GPU solution
+
+
+def load_lmpc_golden():
+    return np.load(os.path.join(GOLDEN, "lmpc_n12.npz"))
+
+
+def load_ltv_golden():
+    return np.load(os.path.join(GOLDEN, "ltvmpc_n12.npz"))
+
+
+def lmpc_config(g, N=12, max_batch=64, **kw):
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    par = orc.QPParams.lmpc_default(N)
+    cfg = _capi.config_from(N, par.Q, par.R, par.Qf, par.dR, par.Qslack, par.Fx, par.bx, par.Fu, par.bu, par.xRef,
+                            QterminalSlack=par.QterminalSlack, numSS_Points=48, numSS_it=4, trToUse=4,
+                            track=g["track"], trackLength=float(g["trackLength"]), max_batch=max_batch, **kw)
+    return cfg, par
+
+
+def mpc_config(g, N=12, max_batch=64, **kw):
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    par = orc.QPParams.mpc_default(N, 0.8)
+    cfg = _capi.config_from(N, par.Q, par.R, par.Qf, par.dR, par.Qslack, par.Fx, par.bx, par.Fu, par.bu, par.xRef,
+                            numSS_it=0, trToUse=1, track=g["track"], trackLength=float(g["trackLength"]), max_batch=max_batch, **kw)
+    return cfg, par
+
+
+def dense_from_csc(g, r, prefix="rec_"):
+    from scipy import sparse
+    Pp, Pi, Px = g[prefix + "Pp"][r], g[prefix + "Pi"][r], g[prefix + "Px"][r]
+    Ap, Ai, Ax = g[prefix + "Ap"][r], g[prefix + "Ai"][r], g[prefix + "Ax"][r]
+    n = len(Pp) - 1
+    m = g[prefix + "l"][r].shape[0]
+    P = sparse.csc_matrix((Px[:Pp[-1]], Pi[:Pp[-1]], Pp), shape=(n, n)).toarray()
+    A = sparse.csc_matrix((Ax[:Ap[-1]], Ai[:Ap[-1]], Ap), shape=(m, n)).toarray()
+    return P, g[prefix + "q"][r], A, g[prefix + "l"][r], g[prefix + "u"][r]
+
+
+def stores_at_lap(g, lap):
+    """Lap stores as they were when LMPC lap `lap` (4 or 5 in the fixture) started.
+
+    Returns (model laps in the reference's addTrajectory call order, safe-set laps [(x, u, qfun-or-None)]).
+    The stored PID lap carries reference quirk E-2 (PredictiveControllers.py:394 runs on a VIEW of the stored lap at
+    the first LMPC solve: ey of row 5 is decremented by TrackLength in place, before the safe-set selection of that
+    same solve); the fixture's SS0 holds that array.  During lap `lap`, addPoint extends safe-set lap `lap - 1`;
+    the caller replays those calls."""
+    xPID, uPID = g["xPID"], g["uPID"]
+    model = [(xPID, uPID)] * 4
+    ss = [(g["SS0"], g["uSS0"], None)] * 3
+    if lap == 4:
+        ss = ss + [(g["SS3"][:1000], g["uSS3"][:1000], None)]
+    else:
+        model = model + [(g["lapx0"], g["lapu0"])]
+        ss = ss + [(g["SS3"], g["uSS3"], g["Qfun3"]), (g["lapx0"], g["lapu0"], None)]
+    return model, ss
+
+
+def make_lmpc_ctx(g, lap, max_batch=64, **kw):
+    from racinglmpc_amd import _capi
+    cfg, par = lmpc_config(g, 12, max_batch=max_batch, **kw)
+    ctx = _capi.Context(cfg)
+    model, ss = stores_at_lap(g, lap)
+    for x, u in model:
+        ctx.model_add_trajectory(x, u)
+    for i, (x, u, qf) in enumerate(ss):
+        if qf is None:
+            ctx.ss_add_trajectory(x, u)
+        else:   # lap already extended by addPoint: add at its addTrajectory-time length, then install the extended rows
+            ctx.ss_add_trajectory(x[:1000], u[:1000])
+            ctx.ss_replace_lap(i, x, u, qf)
+    return ctx, par
+
+
+def certificate(P, q, A, l, u, w, mu, mi):
+    """KKT certificate of a primal solution w with inequality duals mu (equality duals by least squares)."""
+    from oracle import lmpc_oracle as orc
+    F, G = A[:mi], A[mi:]
+    nu = np.linalg.lstsq(G.T, -(P @ w + q + F.T @ mu), rcond=None)[0]
+    return orc.kkt_certificate(P, q, A, l, u, w, np.concatenate([mu, nu]))
+
+
+def replay_lap(g, lap, ctx, on_record, max_records=None):
+    """Walk through the recorded closed-loop steps of LMPC lap `lap`, calling on_record(r) at every recorded step
+    (store state identical to the reference's at that step) and lmpc_ss_add_point after each step (SysModel.py:38)."""
+    rec_lap, rec_t = g["rec_lap"], g["rec_t"]
+    all_lap, all_x0, all_u0 = g["all_lap"], g["all_x0"], g["all_u0"]
+    steps = np.where(all_lap == lap)[0]
+    recs = {int(rec_t[r]): r for r in range(len(rec_lap)) if rec_lap[r] == lap}
+    n = 0
+    for t, gi in enumerate(steps):
+        if t in recs and (max_records is None or n < max_records):
+            on_record(recs[t]); n += 1
+        ctx.ss_add_point(all_x0[gi], all_u0[gi])
+    return n
+
+
+def run_golden_step_check(max_records=None):
+    """Replay the recorded reference laps through the HIP path (lmpc_step_batch, B = 1 per recorded step, addPoint
+    in between) and compare with the certified optimum of the reference-assembled QP.  Used by smoke() and tests."""
+    g = load_lmpc_golden()
+    errs, stats, iters, zerr = [], [], [], []
+    left = max_records
+    for lap in (4, 5):
+        if left is not None and left <= 0:
+            break
+        ctx, par = make_lmpc_ctx(g, lap, max_batch=4)
+
+        def on_record(r):
+            out = ctx.step_batch(g["rec_x0"][r][None], g["rec_xLin"][r][None], g["rec_uLin"][r][None], g["rec_OldInput"][r][None],
+                                 zt=g["rec_zt"][r][None], xPredPrev=g["rec_xPredPrev"][r][None],
+                                 hasPred=np.array([g["rec_hasPred"][r]]), timeStep=np.array([g["rec_t"][r]]))
+            opt = g["rec_sol_opt"][r]
+            ex = np.abs(out["xPred"][0].ravel() - opt[:78]).max()
+            eu = np.abs(out["uPred"][0].ravel() - opt[78:102]).max()
+            errs.append(max(ex, eu)); stats.append(int(out["status"][0])); iters.append(int(out["iters"][0]))
+            zerr.append(np.abs(out["ssSel"][0] - g["rec_SSsel"][r].T).max())
+
+        n = replay_lap(g, lap, ctx, on_record, left)
+        if left is not None:
+            left -= n
+        ctx.close()
+    return dict(max_err_xu=float(np.max(errs)), max_err_sssel=float(np.max(zerr)), n=len(errs), status=np.array(stats),
+                iters_mean=float(np.mean(iters)), iters_max=int(np.max(iters)))

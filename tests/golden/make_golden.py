@@ -10,6 +10,8 @@ What is reference code and what is not:
     /root/reference/src and run UNMODIFIED, except for the one-line NumPy>=2 fix of
     PredictiveControllers.py:502 (`self.xPred == []` raises on NumPy 2; intended meaning
     "no prediction yet") which is applied to the module source in memory before exec.
+  * `sol_opt` / `y_opt` / `cert_opt`: the certified optimum of the recorded QP (oracle.osqp_solve_exact) and its
+    solver-independent KKT certificate -- the value GPU results are compared with.
   * `cvxopt` and `osqp` are third-party packages that are not installed here.  In-memory stand-ins
     are registered in sys.modules: cvxopt.solvers.qp(Q, b) -> numpy.linalg.solve(Q, -b) (what an
     unconstrained qp is), osqp.OSQP -> oracle.lmpc_oracle.osqp_solve (the restated OSQP algorithm).
@@ -153,6 +155,8 @@ def main():
                    status=status, xPred=mpc.xPred.copy(), uPred=mpc.uPred.copy())
         rec["Pp"], rec["Pi"], rec["Px"] = csc_parts(P)
         rec["Ap"], rec["Ai"], rec["Ax"] = csc_parts(A)
+        ex, cert = orc.osqp_solve_exact(P, q, A, l, u)
+        rec["sol_opt"], rec["y_opt"], rec["cert_opt"] = ex.x, ex.y, cert
         recs.append(rec)
         xc, xg = simulator.dynModel(xc, xg, mpc.uPred[0, :].copy())
     keys = recs[0].keys()
@@ -196,6 +200,9 @@ def main():
         rec["Pp"], rec["Pi"], rec["Px"] = csc_parts(P)
         rec["Ap"], rec["Ai"], rec["Ax"] = csc_parts(A)
         rec["keep"] = 1 if (lmpc.timeStep - 1 < 3 or (lmpc.timeStep - 1) % 8 == 0) else 0
+        if rec["keep"]:
+            ex, cert = orc.osqp_solve_exact(P, q, A, l, u)
+            rec["sol_opt"], rec["y_opt"], rec["cert_opt"] = ex.x, ex.y, cert
         records.append(rec)
         step_counter[0] = t + 1
 

@@ -1,0 +1,93 @@
+"""CPU: the oracle restatement reproduces what the reference's own classes produced (golden fixtures made by
+tests/golden/make_golden.py), and the restated OSQP returns certified optima."""
+import numpy as np
+
+from oracle import lmpc_oracle as orc
+from tests import common
+
+
+def test_track_table_matches_reference():
+    g = common.load_lmpc_golden()
+    pt, TL = orc.make_track()
+    assert np.array_equal(pt, g["track"]) and TL == float(g["trackLength"])
+    for s, k in ((0.0, 0), (0.5, 0), (1.0, 1), (5.6, 2), (7.9, 3), (12.3, 4), (15.2, 5), (18.0, 6), (19.3, 0), (40.0, 1)):
+        assert orc.curvature(pt, s) == pt[k, 5]
+
+
+def test_pid_lap_restatement_is_bit_exact():
+    """oracle plant + PID == reference Simulator.sim + PID (np.random.seed(0)), 1000 steps."""
+    g = common.load_lmpc_golden()
+    pt, _ = orc.make_track()
+    x, u, xg = orc.pid_lap(pt, 0.8, 0, maxSimTime=15)          # first 150 steps are enough (same RNG stream)
+    assert np.array_equal(x, g["xPID"][:150]) and np.array_equal(u, g["uPID"][:150]) and np.array_equal(xg, g["xPID_glob"][:150])
+
+
+def test_regression_restatement_matches_reference():
+    g = common.load_lmpc_golden()
+    pt = g["track"]
+    for r in (0, 1, 7, 30, 31, 45, 59):
+        lap = int(g["rec_lap"][r])
+        xs = [g["xStored%d" % i] for i in range(6)]; us = [g["uStored%d" % i] for i in range(6)]
+        if lap == 4:
+            xS, uS = xs[2:6], us[2:6]
+        else:
+            xS, uS = xs[1:6], us[1:6]
+        A, B, C = orc.compute_ltv_dynamics(xS, uS, [0, 1, 2, 3], pt, g["rec_xLin"][r], g["rec_uLin"][r], 12)
+        for got, ref in ((A, g["rec_A"][r]), (B, g["rec_B"][r]), (C, g["rec_C"][r])):
+            assert (np.abs(got - ref) / (1 + np.abs(ref))).max() < 1e-10
+
+
+def test_selection_and_assembly_restatement_bit_exact():
+    g = common.load_lmpc_golden()
+    par = orc.QPParams.lmpc_default(12)
+    TL = float(g["trackLength"])
+    for r in (0, 2, 9, 29, 30, 33, 44, 59):
+        lap = int(g["rec_lap"][r]); nl = lap
+        SS = [g["SS%d" % i][:g["rec_ssLen"][r][i]] for i in range(nl)]
+        uSS = [g["uSS%d" % i][:g["rec_ssLen"][r][i]] for i in range(nl)]
+        Qf = [g["Qfun%d" % i][:g["rec_ssLen"][r][i]] for i in range(nl)]
+        zt = g["rec_zt"][r].copy()
+        if zt[4] - g["rec_x0"][r][4] > TL / 2:
+            zt[4] = np.max([zt[4] - TL, 0])
+        xpp = g["rec_xPredPrev"][r] if g["rec_hasPred"][r] else None
+        SSsel, Qsel, Succ, SuccU = orc.terminal_components(SS, uSS, Qf, list(g["rec_LapTime"][r][:nl]), zt, 48, 4, xpp, lap,
+                                                           int(g["rec_t"][r]), 12, TL)
+        assert np.array_equal(SSsel, g["rec_SSsel"][r]) and np.array_equal(Qsel, g["rec_Qsel"][r])
+        assert np.array_equal(Succ, g["rec_Succ"][r]) and np.array_equal(SuccU, g["rec_SuccU"][r])
+        P, q, A, l, u = orc.assemble_lmpc_qp(par, g["rec_A"][r], g["rec_B"][r], g["rec_C"][r], g["rec_x0"][r], g["rec_OldInput"][r], SSsel, Qsel)
+        Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r)
+        assert np.array_equal(P, Pr) and np.array_equal(q, qr) and np.array_equal(A, Ar) and np.array_equal(l, lr) and np.array_equal(u, ur)
+
+
+def test_compute_cost_restatement():
+    g = common.load_lmpc_golden()
+    TL = float(g["trackLength"])
+    assert np.array_equal(orc.compute_cost(g["SS0"], TL)[:1000], g["Qfun0"])
+    assert np.array_equal(orc.compute_cost(g["lapx1"], TL), g["Qfun5"])
+
+
+def test_restated_osqp_certificates():
+    """Default-settings run is within OSQP's own tolerance of the certified optimum; the exact mode is certified."""
+    g = common.load_lmpc_golden()
+    for r in (0, 6, 12, 36):
+        P, q, A, l, u = common.dense_from_csc(g, r)
+        res = orc.osqp_solve(P, q, A, l, u, polish=True)
+        assert res.status == 1
+        assert np.allclose(res.x, g["rec_sol"][r], atol=1e-12)            # deterministic
+        ex, cert = orc.osqp_solve_exact(P, q, A, l, u)
+        assert cert < 1e-8
+        assert np.abs(ex.x[:102] - g["rec_sol_opt"][r][:102]).max() < 1e-8
+        assert np.abs(res.x[78:102] - ex.x[78:102]).max() < 5e-2            # eps = 1e-3 ADMM iterate vs optimum
+
+
+def test_ipm_model_matches_certified_optimum():
+    """The NumPy model of the HIP solve kernel (tests/ipm_model.py) reaches the certified optimum."""
+    from tests import ipm_model as im
+    g = common.load_lmpc_golden()
+    par = orc.QPParams.lmpc_default(12)
+    for r in (0, 5, 13, 29, 41, 50):
+        qp = im.StructQP(par, g["rec_A"][r], g["rec_B"][r], g["rec_C"][r], g["rec_x0"][r], g["rec_OldInput"][r], g["rec_SSsel"][r], g["rec_Qsel"][r])
+        o = im.ipm_solve(qp, reg_l=1e-6)
+        assert o["iters"] < 25
+        w = np.concatenate([o["x"].ravel(), o["u"].ravel()])
+        assert np.abs(w - g["rec_sol_opt"][r][:102]).max() < 1e-6
