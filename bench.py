@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py -- QP solves/sec of the LMPC hot path on MI355X (driver contract: see task statement).
+
+One "step" = one pass of the full hot path (LTV regression for N horizon points, safe-set selection,
+QP assembly-in-structure + solve to the certified optimum, unpack) over one batch of synthetic QPs whose
+inputs are already resident in HBM.  Workload at N_gpus=1: BASELINE.json configs[1]
+("batch=256 LMPC QPs, N=12, fixed safe-set, 1xMI355X"), generated as SURVEY.md section 8(d) prescribes.
+With --gpus G (launched by torch.distributed.run, one rank per GPU) every rank runs the same batch size on
+its own GPU (weak scaling, no data-path collective: the QPs are independent); value = all ranks' solves /
+max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak (MI355X_MICROARCH.md)
+FP64_VEC_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (spec)
+
+
+def synth_batch(g, B, N, seed=1234):
+    """SURVEY 8(d) 'cfg batch=256, fixed safe-set': problem b starts at row t_b = 37 b mod 900 of the PID seed lap."""
+    xPID, uPID = g["xPID"], g["uPID"]
+    rng = np.random.default_rng(seed)
+    tb = (37 * np.arange(B)) % 900
+    eps = rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02])
+    x0 = xPID[tb] + eps
+    xLin = np.stack([xPID[t + 1:t + N + 2] for t in tb])
+    uLin = np.stack([uPID[t + 1:t + N + 1] for t in tb])
+    uOld = uPID[tb].copy()
+    zt = xPID[tb + N + 1].copy()
+    tstep = (tb % 300).astype(np.int32)
+    return dict(x0=x0, xLin=xLin, uLin=uLin, uOld=uOld, zt=zt, timeStep=tstep, hasPred=np.zeros(B, np.int32),
+                xPredPrev=np.zeros((B, N + 1, 6)))
+
+
+def make_ctx(g, N, B, device):
+    from racinglmpc_amd import _capi
+    from tests import common
+    cfg, par = common.lmpc_config(g, N, max_batch=max(B, 1), device=device)
+    ctx = _capi.Context(cfg)
+    for _ in range(4):                                  # main.py:102-110: model store = safe set = 4 x PID lap
+        ctx.model_add_trajectory(g["xPID"], g["uPID"])
+        ctx.ss_add_trajectory(g["xPID"], g["uPID"])
+    return ctx, par
+
+
+def device_args(ctx, inp, B, N, S):
+    from racinglmpc_amd import _capi
+    a = _capi.StepDevArgs()
+    keep = []
+
+    def up(arr):
+        p = ctx.dev_array(arr); keep.append(p); return p
+
+    def alloc(nbytes):
+        p = ctx.dev_alloc(max(nbytes, 8)); keep.append(p); return p
+    a.x0, a.xLin, a.uLin, a.uOld, a.zt = up(inp["x0"]), up(inp["xLin"]), up(inp["uLin"]), up(inp["uOld"]), up(inp["zt"])
+    a.xPredPrev, a.hasPred, a.timeStep = up(inp["xPredPrev"]), up(inp["hasPred"]), up(inp["timeStep"])
+    M = 8 * N + S
+    a.xPred, a.uPred, a.slack = alloc(B * (N + 1) * 6 * 8), alloc(B * N * 2 * 8), alloc(B * N * 2 * 8)
+    a.lambda_, a.sTerm, a.ztNext, a.ztuNext = alloc(B * S * 8), alloc(B * 6 * 8), alloc(B * 6 * 8), alloc(B * 2 * 8)
+    a.ssSel, a.A, a.Bm, a.C = alloc(B * S * 6 * 8), alloc(B * N * 36 * 8), alloc(B * N * 12 * 8), alloc(B * N * 6 * 8)
+    a.mu, a.resid, a.status, a.iters = alloc(B * M * 8), alloc(B * 3 * 8), alloc(B * 4), alloc(B * 4)
+    return a, keep
+
+
+def cpu_baseline(g, inp, N, nsample, budget_s=25.0):
+    """Reference-algorithm port (oracle/: NumPy regression/selection/assembly + restated OSQP, default settings with
+    polish -- what main.py does per step), single core, on the first `nsample` problems of the same batch."""
+    from oracle import lmpc_oracle as orc
+    par = orc.QPParams.lmpc_default(N)
+    pt, TL = g["track"], float(g["trackLength"])
+    xS = [g["xPID"]] * 4; uS = [g["uPID"]] * 4
+    Qf = [orc.compute_cost(g["xPID"], TL)] * 4
+    done = 0
+    t0 = time.perf_counter()
+    for b in range(nsample):
+        A, Bm, C = orc.compute_ltv_dynamics(xS, uS, [0, 1, 2, 3], pt, inp["xLin"][b], inp["uLin"][b], N)
+        zt = inp["zt"][b].copy()
+        if zt[4] - inp["x0"][b][4] > TL / 2:
+            zt[4] = np.max([zt[4] - TL, 0])
+        SSsel, Qsel, Succ, SuccU = orc.terminal_components(xS, uS, Qf, [1000] * 4, zt, 48, 4, None, 4, int(inp["timeStep"][b]), N, TL)
+        P, q, Ao, l, u = orc.assemble_lmpc_qp(par, A, Bm, C, inp["x0"][b], inp["uOld"][b], SSsel, Qsel)
+        orc.osqp_solve(P, q, Ao, l, u, polish=True)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="solves/s", cores=1, kind="port",
+                sample="first %d problems of the bench batch, full step (NumPy regression+selection+assembly, restated OSQP eps=1e-3+polish), %.1f s" % (done, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="QPs per GPU per step (BASELINE configs[1]: 256)")
+    ap.add_argument("--horizon", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--sweep", action="store_true", help="also report solves/s for batch 1..8192 (extra key 'sweep')")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+
+    from tests import common
+    g = common.load_lmpc_golden()
+    N, B = args.horizon, args.batch
+    ctx, par = make_ctx(g, N, B, local)
+    S = ctx.S
+    inp = synth_batch(g, B, N, seed=1234 + rank)
+    a, keep = device_args(ctx, inp, B, N, S)
+
+    def sync_all():
+        ctx.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.step_batch_dev(B, a)
+    sync_all()
+    ctx.reset_stats(); ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.step_batch_dev(B, a)
+    sync_all()
+    dt = time.perf_counter() - t0
+    st = ctx.stats(); ctx.set_profiling(False)
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); resid = np.zeros((B, 3))
+    ctx.dev_download(a.status, status); ctx.dev_download(a.iters, iters); ctx.dev_download(a.resid, resid)
+    n_ok = int(np.sum(status == 0))
+
+    out = None
+    if rank == 0:
+        ms_solve = st.ms_solve / max(st.n_solve, 1); ms_reg = st.ms_regress / max(st.n_regress, 1)
+        bytes_per_solve = 8 * (18 * N + 92)                     # SURVEY 8(d) B_solve: compulsory in+out per full step
+        achieved = B * bytes_per_solve / (ms_solve * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("lmpc_solve_kernel_bytes_per_launch_B%d_N%d" % (B, N))
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "QP solves/sec (N=%d, nx=6, nu=2)" % N, "value": world * B * args.steps / dt, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "batch=%d LMPC QPs per GPU, N=%d, fixed safe-set (4x PID seed lap, 48 points from 4 laps), full step a3-a19" % (B, N),
+                       "batch_per_gpu": B, "N": N, "numSS_points": S, "laps_scanned": 4, "rows_per_lap": 1000,
+                       "solver": "Riccati-structured primal-dual interior point to certified optimum (gap<1e-11, res<1e-9)"},
+            "solved_ok": n_ok, "ipm_iters_mean": float(iters.mean()), "ipm_iters_max": int(iters.max()),
+            "kernel_ms": {"lmpc_solve_kernel": ms_solve, "lmpc_regress_kernel": ms_reg},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "lmpc_solve_kernel", "algorithmic_bytes_per_launch": B * bytes_per_solve,
+                         "note": "latency/FP64-issue bound path: compulsory HBM traffic is 2.46 KB per solve (SURVEY 8(d)); see DESIGN.md"},
+        }
+        if args.sweep:
+            sweep = {}
+            for bb in (1, 8, 64, 256, 1024, 4096, 8192):
+                c2, _ = make_ctx(g, N, bb, local)
+                i2 = synth_batch(g, bb, N)
+                a2, k2 = device_args(c2, i2, bb, N, S)
+                for _ in range(2):
+                    c2.step_batch_dev(bb, a2)
+                c2.sync(); t1 = time.perf_counter(); reps = 20 if bb <= 1024 else 5
+                for _ in range(reps):
+                    c2.step_batch_dev(bb, a2)
+                c2.sync(); sweep[str(bb)] = bb * reps / (time.perf_counter() - t1)
+                for p in k2:
+                    c2.dev_free(p)
+                c2.close()
+            out["sweep_solves_per_s"] = sweep
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(g, inp, N, min(args.cpu_sample, B))
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+    for p in keep:
+        ctx.dev_free(p)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

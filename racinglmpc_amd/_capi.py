@@ -81,6 +81,11 @@ def _d(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _p(p):
+    """device pointer -> c_void_p (ctypes hands Structure c_void_p fields back as plain ints)."""
+    return p if isinstance(p, C.c_void_p) else C.c_void_p(p)
+
+
 def _f64(a, shape=None):
     a = np.ascontiguousarray(a, dtype=np.float64)
     if shape is not None:
@@ -230,15 +235,15 @@ class Context:
         return p
 
     def dev_free(self, p):
-        _chk(self.lib.lmpc_dev_free(self._h, p))
+        _chk(self.lib.lmpc_dev_free(self._h, _p(p)))
 
     def dev_upload(self, p, arr):
         arr = np.ascontiguousarray(arr)
-        _chk(self.lib.lmpc_dev_upload(self._h, p, _d(arr), C.c_longlong(arr.nbytes)))
+        _chk(self.lib.lmpc_dev_upload(self._h, _p(p), _d(arr), C.c_longlong(arr.nbytes)))
 
     def dev_download(self, p, arr):
         assert arr.flags["C_CONTIGUOUS"]
-        _chk(self.lib.lmpc_dev_download(self._h, _d(arr), p, C.c_longlong(arr.nbytes)))
+        _chk(self.lib.lmpc_dev_download(self._h, _d(arr), _p(p), C.c_longlong(arr.nbytes)))
         return arr
 
     def dev_array(self, arr):
