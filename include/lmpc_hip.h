@@ -142,6 +142,7 @@ typedef struct {          /* all device pointers, layouts as in lmpc_step_batch 
 } lmpc_step_dev_args;
 int lmpc_step_batch_dev(lmpc_ctx *, int B, const lmpc_step_dev_args *args);   /* async on the ctx stream */
 
+int lmpc_selftest(lmpc_ctx *);                   /* device self test of the cross-lane reduction primitives */
 int lmpc_set_profiling(lmpc_ctx *, int on);       /* HIP events around each kernel launch */
 int lmpc_get_stats(lmpc_ctx *, lmpc_stats *out);  /* drains pending events */
 int lmpc_reset_stats(lmpc_ctx *);

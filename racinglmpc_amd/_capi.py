@@ -47,7 +47,7 @@ EXPORTS = [
     "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun",
     "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
-    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats",
+    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest",
 ]
 
 _lib = None
@@ -259,6 +259,9 @@ class Context:
 
     def step_batch_dev(self, B, args):
         _chk(self.lib.lmpc_step_batch_dev(self._h, C.c_int(B), C.byref(args)))
+
+    def selftest(self):
+        _chk(self.lib.lmpc_selftest(self._h))
 
     def set_profiling(self, on):
         _chk(self.lib.lmpc_set_profiling(self._h, C.c_int(1 if on else 0)))

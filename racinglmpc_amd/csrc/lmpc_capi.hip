@@ -30,8 +30,26 @@ struct lmpc_ctx {
     double *w_xPred, *w_uPred, *w_slack, *w_lam, *w_sT, *w_mu, *w_ztN, *w_ztuN, *w_resid;
     int *w_hasPred, *w_tstep, *w_status, *w_iters, *w_rstatus;
     size_t lds_bytes;
+    int (*solve_launch)(lmpc_ctx *, int, const lmpc_solve_io &);
     int profiling; std::vector<evpair> events; lmpc_stats stats;
 };
+
+template <int N, int S> static int solve_launch_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
+    hipLaunchKernelGGL((lmpc_solve_kernel<N, S>), dim3(B), dim3(WAVE), c->lds_bytes, c->stream, c->dp, B, io);
+    return LMPC_OK;
+}
+template <int N, int S> static bool try_pick(lmpc_ctx *c, int n, int s) {
+    if (n != N || s != S) return false;
+    c->lds_bytes = (size_t)solve_lds<N, S>::tot * sizeof(double);
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
+    c->solve_launch = &solve_launch_t<N, S>;
+    return true;
+}
+static bool pick_solver(lmpc_ctx *c) {
+    const int n = c->cfg.N, s = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0;
+    return try_pick<8, 0>(c, n, s) || try_pick<12, 0>(c, n, s) || try_pick<14, 0>(c, n, s) || try_pick<20, 0>(c, n, s) || try_pick<40, 0>(c, n, s) ||
+           try_pick<8, 48>(c, n, s) || try_pick<12, 48>(c, n, s) || try_pick<14, 48>(c, n, s) || try_pick<20, 48>(c, n, s) || try_pick<40, 48>(c, n, s);
+}
 
 extern "C" {
 
@@ -102,9 +120,7 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     DALLOC(w_mu, B * M); DALLOC(w_ztN, B * 6); DALLOC(w_ztuN, B * 2); DALLOC(w_resid, B * 3);
     DALLOC(w_hasPred, B); DALLOC(w_tstep, B); DALLOC(w_status, B); DALLOC(w_iters, B); DALLOC(w_rstatus, B * N);
 #undef DALLOC
-    c->lds_bytes = (size_t)make_layout((int)N, (int)S).tot * sizeof(double);
-    if (c->lds_bytes > 160 * 1024 - 64) { delete c; return set_err(LMPC_E_ARG, "horizon too long for the LDS-resident solver", ""); }
-    HIPCHK(hipFuncSetAttribute((const void *)lmpc_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    if (!pick_solver(c)) { delete c; return set_err(LMPC_E_ARG, "unsupported (N, numSS_points): built variants are N in {8,12,14,20,40} x numSS_points in {0,48}", ""); }
     fill_params(c);
     *out = c;
     return LMPC_OK;
@@ -260,8 +276,9 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
     const bool term = c->cfg.numSS_it > 0;
     int rc = refresh_params(c, false, term && (io.mode & 1)); if (rc) return rc;
     ev_begin(c, 1);
-    hipLaunchKernelGGL(lmpc_solve_kernel, dim3(B), dim3(WAVE), c->lds_bytes, c->stream, c->dp, B, io);
+    rc = c->solve_launch(c, B, io);
     ev_end(c);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     c->stats.n_solve++; if (io.mode & 2) c->stats.qp_solved += B;
     return LMPC_OK;
@@ -407,6 +424,40 @@ int lmpc_dev_free(lmpc_ctx *c, void *dptr) { ARGCHK(c); HIPCHK(hipSetDevice(c->c
 int lmpc_dev_upload(lmpc_ctx *c, void *dptr, const void *host, long long bytes) { ARGCHK(c && dptr && host); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipMemcpyAsync(dptr, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
 int lmpc_dev_download(lmpc_ctx *c, void *host, const void *dptr, long long bytes) { ARGCHK(c && dptr && host); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipMemcpyAsync(host, dptr, (size_t)bytes, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
 int lmpc_dev_sync(lmpc_ctx *c) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
+
+// timing build only: one solve of problem 0 of a host batch with cycle stamps (tools/phase_timing.py)
+int lmpc_debug_timing(lmpc_ctx *c, const double *A, const double *Bm, const double *C, const double *x0, const double *uOld,
+                      const double *ssSel, const double *qSel, long long *tbuf_host, int nt) {
+    ARGCHK(c && tbuf_host && nt >= 2);
+    const int N = c->cfg.N, S = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    H2D(c->w_A, A, (size_t)N * 36); H2D(c->w_B, Bm, (size_t)N * 12); H2D(c->w_C, C, (size_t)N * 6); H2D(c->w_x0, x0, 6); H2D(c->w_uOld, uOld, 2);
+    if (S > 0) { H2D(c->w_ssSel, ssSel, (size_t)S * 6); H2D(c->w_qSel, qSel, S); }
+    long long *dt; HIPCHK(hipMalloc(&dt, sizeof(long long) * nt)); HIPCHK(hipMemsetAsync(dt, 0, sizeof(long long) * nt, c->stream));
+    lmpc_solve_io io; memset(&io, 0, sizeof(io));
+    io.mode = 2; io.A = c->w_A; io.Bm = c->w_B; io.C = c->w_C; io.x0 = c->w_x0; io.uOld = c->w_uOld; io.ssSelIn = c->w_ssSel; io.qSelIn = c->w_qSel;
+    io.xPred = c->w_xPred; io.uPred = c->w_uPred; io.slack = c->w_slack; io.lambda = c->w_lam; io.sTerm = c->w_sT; io.mu = c->w_mu; io.resid = c->w_resid;
+    io.status = c->w_status; io.iters = c->w_iters; io.tbuf = dt;
+    int rc = launch_solve(c, 1, io); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(tbuf_host, dt, sizeof(long long) * nt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream)); hipFree(dt);
+    return LMPC_OK;
+}
+
+int lmpc_selftest(lmpc_ctx *c) {
+    // cross-lane primitives (DPP + v_permlane16/32_swap reductions) against closed-form values
+    ARGCHK(c);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    double *d; HIPCHK(hipMalloc(&d, sizeof(double) * 192));
+    hipLaunchKernelGGL(lmpc_selftest_kernel, dim3(1), dim3(WAVE), 0, c->stream, d);
+    double hbuf[192]; HIPCHK(hipMemcpyAsync(hbuf, d, sizeof(hbuf), hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); hipFree(d);
+    double s = 0, mx = -1e300, mn = 1e300;
+    for (int l = 0; l < 64; l++) { const double v = 1.0 + 0.25 * l + ((l * 37) % 11) * 1e-3; s += v; mx = v > mx ? v : mx; mn = v < mn ? v : mn; }
+    for (int l = 0; l < 64; l++) {
+        if (fabs(hbuf[l] - s) > 1e-9 * s || hbuf[64 + l] != mx || hbuf[128 + l] != mn) return set_err(LMPC_E_HIP, "wave reduction self test failed", "");
+    }
+    return LMPC_OK;
+}
 
 int lmpc_set_profiling(lmpc_ctx *c, int on) { ARGCHK(c); c->profiling = on ? 1 : 0; return LMPC_OK; }
 static int drain_events(lmpc_ctx *c) {

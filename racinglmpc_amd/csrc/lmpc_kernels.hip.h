@@ -245,6 +245,8 @@ __global__ __launch_bounds__(WAVE) void lmpc_regress_kernel(lmpc_dev_params p, i
 
 // =====================================================================================================
 // K2 + K3: safe-set selection + structured primal-dual interior-point QP solve.  One wave per QP.
+// Templated on the horizon N and the number of safe-set columns S (0 = plain MPC, no terminal set) so that
+// every LDS offset and trip count is a compile-time constant.
 // =====================================================================================================
 struct lmpc_solve_io {
     // mode bit 0: select the safe set on device (else read ssSel/qSel); bit 1: run the QP solve
@@ -254,116 +256,189 @@ struct lmpc_solve_io {
     double *xPred, *uPred, *slack, *lambda, *sTerm, *mu, *ztNext, *ztuNext;
     double *ssSelOut, *qSelOut, *succOut, *succUOut, *ztUsed, *resid;
     int *status, *iters;
+    long long *tbuf;          // optional cycle stamps of problem 0 (builds with -DLMPC_TIMING only)
 };
 
-struct lds_layout {
-    int A, B, C, x, u, s, lam, dx, du, ds, dl, nu, dnu, m, t, th, h, tp, dm, dtv, rx, ru, rs, rl, Phi, Mi, gam, gup, pst, phi, k0,
-        kap, Ds, eta, e, Pi, T1, T2, Mxx, Mxu, Muu, Qm, Ra, Rb, R, Ri, sqD, ct, SS, Qsel, Succ, SuccU, y7, w7, PiT, sT, tot;
-};
-__host__ __device__ inline lds_layout make_layout(int N, int S) {
-    lds_layout L; int o = 0; const int M = 8 * N + S;
-#define AL(name, n) L.name = o; o += (n);
-    AL(A, 36 * N) AL(B, 12 * N) AL(C, 6 * N)
-    AL(x, 6 * (N + 1)) AL(u, 2 * N) AL(s, 2 * N) AL(lam, S)
-    AL(dx, 6 * (N + 1)) AL(du, 2 * N) AL(ds, 2 * N) AL(dl, S)
-    AL(nu, 6 * N) AL(dnu, 6 * N)
-    AL(m, M) AL(t, M) AL(th, M) AL(h, M) AL(tp, M) AL(dm, M) AL(dtv, M)
-    AL(rx, 6 * (N + 1)) AL(ru, 2 * N) AL(rs, 2 * N) AL(rl, S)
-    AL(Phi, 64 * N) AL(Mi, 4 * N) AL(gam, 8 * N) AL(gup, 2 * N) AL(pst, 8 * (N + 1)) AL(phi, 8 * N) AL(k0, 2 * N)
-    AL(kap, 2 * N) AL(Ds, 2 * N) AL(eta, 2 * N) AL(e, 2 * N)
-    AL(Pi, 64) AL(T1, 36) AL(T2, 12) AL(Mxx, 36) AL(Mxu, 12) AL(Muu, 4)
-    AL(Qm, 7 * WAVE) AL(Ra, 49) AL(Rb, 49) AL(R, 49) AL(Ri, 49) AL(sqD, WAVE) AL(ct, WAVE)
-    AL(SS, 6 * S) AL(Qsel, S) AL(Succ, 6 * S) AL(SuccU, 2 * S) AL(y7, 8) AL(w7, 8) AL(PiT, 36) AL(sT, 8)
-#undef AL
-    L.tot = o;
-    return L;
+#ifdef LMPC_TIMING
+#define TSTAMP(id) do { if (io.tbuf && b == 0 && lane == 0 && tcnt < 4000) { io.tbuf[2 * tcnt] = (id); io.tbuf[2 * tcnt + 1] = (long long)__builtin_readcyclecounter(); tcnt++; } } while (0)
+#else
+#define TSTAMP(id) do { } while (0)
+#endif
+
+// ---- cross-lane primitives (gfx950): DPP inside a row of 16 lanes, v_permlane16/32_swap across rows ----
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
+// returns (a, b): a = v with odd rows replaced by the partner's even rows, b = the complementary half
+__device__ __forceinline__ void swap16(double v, double &a, double &b) {
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]); b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void swap32(double v, double &a, double &b) {
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]); b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+#define DPP_QP_X1 0xB1          // quad_perm [1,0,3,2]
+#define DPP_QP_X2 0x4E          // quad_perm [2,3,0,1]
+#define DPP_HALF_MIRROR 0x141
+#define DPP_MIRROR 0x140
+struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+struct OpMax { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
+struct OpMin { __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); } };
+template <class Op> __device__ __forceinline__ double wave_allreduce(double v, Op op) {
+    v = op(v, dpp_mov<DPP_QP_X1>(v));
+    v = op(v, dpp_mov<DPP_QP_X2>(v));
+    v = op(v, dpp_mov<DPP_HALF_MIRROR>(v));
+    v = op(v, dpp_mov<DPP_MIRROR>(v));
+    double a, b;
+    swap16(v, a, b); v = op(a, b);
+    swap32(v, a, b); v = op(a, b);
+    return v;
+}
+__device__ __forceinline__ double wsum(double v) { return wave_allreduce(v, OpSum()); }
+__device__ __forceinline__ double wmax(double v) { return wave_allreduce(v, OpMax()); }
+__device__ __forceinline__ double wmin(double v) { return wave_allreduce(v, OpMin()); }
+
+// parameter block staged in LDS (lane-dependent indexing of kernel arguments would go through global memory)
+enum { PAR_FX = 0, PAR_FU = 12, PAR_BX = 20, PAR_BU = 22, PAR_Q2 = 26, PAR_QF2 = 62, PAR_R2 = 98, PAR_DR2 = 102, PAR_T2 = 104,
+       PAR_XREF = 110, PAR_AS = 116, PAR_CS = 117, PAR_TOT = 118 };
+
+template <int N, int S> struct solve_lds {
+    static constexpr int M = 8 * N + S;
+    static constexpr int oA = 0, oB = oA + 36 * N, oC = oB + 12 * N;
+    static constexpr int ox = oC + 6 * N, ou = ox + 6 * (N + 1), os = ou + 2 * N, olam = os + 2 * N;
+    static constexpr int odx = olam + S, odu = odx + 6 * (N + 1), ods = odu + 2 * N, odl = ods + 2 * N;
+    static constexpr int onu = odl + S, odnu = onu + 6 * N;
+    static constexpr int om = odnu + 6 * N, oth = om + M, oh = oth + M, odm = oh + M;
+    static constexpr int orx = odm + M, oru = orx + 6 * (N + 1), ors = oru + 2 * N, orl = ors + 2 * N;
+    static constexpr int oPhi = orl + S, oMi = oPhi + 64 * N, ogam = oMi + 4 * N, ogup = ogam + 8 * N, opst = ogup + 2 * N, ok0 = opst + 8 * (N + 1);
+    static constexpr int okap = ok0 + 2 * N, orDs = okap + 2 * N, oeta = orDs + 2 * N, oe = oeta + 2 * N;
+    static constexpr int oPi = oe + 2 * N, oT1 = oPi + 64, oT2 = oT1 + 36, oMxx = oT2 + 12, oMxu = oMxx + 36, oMuu = oMxu + 12;
+    static constexpr int oQm = oMuu + 4, oRa = oQm + (S > 0 ? 7 * WAVE : 0), oRb = oRa + 49, oR = oRb + 49, oRi = oR + 49, orsq = oRi + 49, oct = orsq + WAVE;
+    static constexpr int oSS = oct + WAVE, oQsel = oSS + 6 * S, oy7 = oQsel + S, ow7 = oy7 + 8, oz7 = ow7 + 8, oPiT = oz7 + 8, osT = oPiT + 36;
+    static constexpr int opar = osT + 8, tot = opar + PAR_TOT;
+};
 
 #define FOR_LANES(idx, n) for (int idx = lane; idx < (n); idx += WAVE)
 
+template <int N, int S>
 __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
     extern __shared__ double sm[];
+    using LL = solve_lds<N, S>;
+    constexpr int M = LL::M;
+    constexpr bool term = S > 0;
+    constexpr int RPL = (M + WAVE - 1) / WAVE;              // inequality rows per lane
     const int b = blockIdx.x;
     if (b >= B) return;
     const int lane = threadIdx.x;
-    const int N = p.N, S = p.S, M = 8 * N + S;
-    const bool term = S > 0;
-    const lds_layout L = make_layout(N, S);
-    double *A = sm + L.A, *Bm = sm + L.B, *C = sm + L.C, *x = sm + L.x, *u = sm + L.u, *s = sm + L.s, *lam = sm + L.lam;
-    double *dx = sm + L.dx, *du = sm + L.du, *ds = sm + L.ds, *dl = sm + L.dl, *nu = sm + L.nu, *dnu = sm + L.dnu;
-    double *m = sm + L.m, *t = sm + L.t, *th = sm + L.th, *h = sm + L.h, *tp = sm + L.tp, *dm = sm + L.dm, *dtv = sm + L.dtv;
-    double *rx = sm + L.rx, *ru = sm + L.ru, *rs = sm + L.rs, *rl = sm + L.rl;
-    double *Phi = sm + L.Phi, *Mi = sm + L.Mi, *gam = sm + L.gam, *gup = sm + L.gup, *pst = sm + L.pst, *phi = sm + L.phi, *k0 = sm + L.k0;
-    double *kap = sm + L.kap, *Dsl = sm + L.Ds, *eta = sm + L.eta, *ee = sm + L.e;
-    double *Pi = sm + L.Pi, *T1 = sm + L.T1, *T2 = sm + L.T2, *Mxx = sm + L.Mxx, *Mxu = sm + L.Mxu, *Muu = sm + L.Muu;
-    double *Qm = sm + L.Qm, *Ra = sm + L.Ra, *Rb = sm + L.Rb, *Rm = sm + L.R, *Ri = sm + L.Ri, *sqD = sm + L.sqD, *ct = sm + L.ct;
-    double *SS = sm + L.SS, *Qsel = sm + L.Qsel, *Succ = sm + L.Succ, *SuccU = sm + L.SuccU, *y7 = sm + L.y7, *w7 = sm + L.w7, *PiT = sm + L.PiT, *sT = sm + L.sT;
+    double *A = sm + LL::oA, *Bm = sm + LL::oB, *C = sm + LL::oC, *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
+    double *dx = sm + LL::odx, *du = sm + LL::odu, *ds = sm + LL::ods, *dl = sm + LL::odl, *nu = sm + LL::onu, *dnu = sm + LL::odnu;
+    double *m = sm + LL::om, *th = sm + LL::oth, *h = sm + LL::oh, *dm = sm + LL::odm;
+    double *rx = sm + LL::orx, *ru = sm + LL::oru, *rs = sm + LL::ors, *rl = sm + LL::orl;
+    double *Phi = sm + LL::oPhi, *Mi = sm + LL::oMi, *gam = sm + LL::ogam, *gup = sm + LL::ogup, *pst = sm + LL::opst, *k0 = sm + LL::ok0;
+    double *phi = gam;                                     // gamma is dead once the backward sweep is done
+    double *kap = sm + LL::okap, *rDs = sm + LL::orDs, *eta = sm + LL::oeta, *ee = sm + LL::oe;
+    double *Pi = sm + LL::oPi, *T1 = sm + LL::oT1, *T2 = sm + LL::oT2, *Mxx = sm + LL::oMxx, *Mxu = sm + LL::oMxu, *Muu = sm + LL::oMuu;
+    double *Qm = sm + LL::oQm, *Ra = sm + LL::oRa, *Rb = sm + LL::oRb, *Rm = sm + LL::oR, *Ri = sm + LL::oRi, *rsq = sm + LL::orsq, *ct = sm + LL::oct;
+    double *SS = sm + LL::oSS, *Qsel = sm + LL::oQsel, *y7 = sm + LL::oy7, *w7 = sm + LL::ow7, *z7 = sm + LL::oz7, *PiT = sm + LL::oPiT, *sT = sm + LL::osT;
+    double *par = sm + LL::opar;
+    const double *Fx = par + PAR_FX, *Fu = par + PAR_FU, *bx = par + PAR_BX, *bu = par + PAR_BU, *Q2 = par + PAR_Q2, *Qf2 = par + PAR_QF2,
+                 *R2 = par + PAR_R2, *dR2 = par + PAR_DR2, *T2p = par + PAR_T2, *xRef = par + PAR_XREF;
     __shared__ int st_sh;
+    __shared__ int sel_start[LMPC_MAX_USED_LAPS];
+    int tcnt = 0; (void)tcnt;
+    TSTAMP(0);
     if (lane == 0) st_sh = 0;
+    // stage the parameter block
+    if (lane < 12) par[PAR_FX + lane] = p.Fx[lane];
+    if (lane < 8) par[PAR_FU + lane] = p.Fu[lane];
+    if (lane < 2) { par[PAR_BX + lane] = p.bx[lane]; par[PAR_DR2 + lane] = p.dR2[lane]; }
+    if (lane < 4) { par[PAR_BU + lane] = p.bu[lane]; par[PAR_R2 + lane] = p.R2[lane]; }
+    if (lane < 36) { par[PAR_Q2 + lane] = p.Q2[lane]; par[PAR_QF2 + lane] = p.Qf2[lane]; }
+    if (lane < 6) { par[PAR_T2 + lane] = p.T2[lane]; par[PAR_XREF + lane] = p.xRef[lane]; }
+    if (lane == 0) { par[PAR_AS] = p.a_s; par[PAR_CS] = p.c_s; }
     __syncthreads();
+    const double a_s = par[PAR_AS], c_s = par[PAR_CS];
 
     // ------------------------------------------------------------------------------------------------
     // K2: safe-set selection.  LMPC.addTerminalComponents :392-412 and selectPoints :478-514.
     // ------------------------------------------------------------------------------------------------
-    if (term) {
+    if constexpr (term) {
         if (io.mode & 1) {
             double ztv[6];
+#pragma unroll
             for (int j = 0; j < 6; j++) ztv[j] = io.zt[(size_t)b * 6 + j];
             const double x04 = io.x0[(size_t)b * 6 + 4];
             if (ztv[4] - x04 > p.TL / 2) ztv[4] = fmax(ztv[4] - p.TL, 0.0);        // :392-393
-            if (io.ztUsed && lane < 6) io.ztUsed[(size_t)b * 6 + lane] = ztv[lane];
-            // prediction-crossing bookkeeping for the Q-function shift (:502-512)
-            const int hasPred = io.hasPred ? io.hasPred[b] : 0;
+            if (io.ztUsed && lane < 6) { double v = ztv[0];
+#pragma unroll
+                for (int j = 1; j < 6; j++) if (lane == j) v = ztv[j];
+                io.ztUsed[(size_t)b * 6 + lane] = v; }
+            const int hasPred = io.hasPred ? io.hasPred[b] : 0;                     // Q-function shift bookkeeping (:502-512)
             int crossed = 0;
-            if (hasPred) for (int k = 0; k <= N; k++) crossed += (io.xPredPrev[((size_t)b * (N + 1) + k) * 6 + 4] > p.TL) ? 1 : 0;
+            if (hasPred) {
+                int c_ = 0;
+                if (lane <= N) c_ = (io.xPredPrev[((size_t)b * (N + 1) + lane) * 6 + 4] > p.TL) ? 1 : 0;
+                crossed = (int)__popcll(__ballot(c_));
+            }
             const int tstep = io.timeStep ? io.timeStep[b] : 0;
-            const int npw = p.ppl + 1;                                              // numSS_Points/numSS_it + 1 (=13)
+            const int ppl = p.ppl, npw = ppl + 1;                                   // numSS_Points/numSS_it + 1 (=13)
             for (int l = 0; l < p.L; l++) {
                 const double *base = p.sstore + (size_t)p.sslot[l] * LMPC_COLS * p.lap_stride;
-                const int T = p.sslen[l];
+                const int T = p.sslen[l], ls = p.lap_stride;
                 double best = INFINITY; int bi = 0x7fffffff;
                 for (int r = lane; r < T; r += WAVE) {
-                    double nrm = fabs(base[0 * p.lap_stride + r] - ztv[0]);         // la.norm(x - zt, 1, axis=1)
-                    nrm = nrm + fabs(base[1 * p.lap_stride + r] - ztv[1]);
-                    nrm = nrm + fabs(base[2 * p.lap_stride + r] - ztv[2]);
-                    nrm = nrm + fabs(base[3 * p.lap_stride + r] - ztv[3]);
-                    nrm = nrm + fabs(base[4 * p.lap_stride + r] - ztv[4]);
-                    nrm = nrm + fabs(base[5 * p.lap_stride + r] - ztv[5]);
+                    double nrm = fabs(base[r] - ztv[0]);                            // la.norm(x - zt, 1, axis=1)
+                    nrm = nrm + fabs(base[ls + r] - ztv[1]);
+                    nrm = nrm + fabs(base[2 * ls + r] - ztv[2]);
+                    nrm = nrm + fabs(base[3 * ls + r] - ztv[3]);
+                    nrm = nrm + fabs(base[4 * ls + r] - ztv[4]);
+                    nrm = nrm + fabs(base[5 * ls + r] - ztv[5]);
                     if (nrm < best) { best = nrm; bi = r; }
                 }
                 wave_argmin(best, bi);                                              // np.argmin: first minimum
                 const int MinNorm = bi;
                 const int start = ((double)MinNorm - (double)npw / 2.0 >= 0.0) ? MinNorm - npw / 2 : MinNorm;   // :492-495
-                if (start + npw > T && lane == 0) atomicOr(&st_sh, LMPC_ST_WINDOW);
+                if (lane == 0) { sel_start[l] = start; if (start + npw > T) atomicOr(&st_sh, LMPC_ST_WINDOW); }
                 double shift = 0.0;                                                 // :502-512
                 if (hasPred && crossed > 0) {
-                    if (p.sslapid[l] < p.cur_it - 1) shift = base[8 * p.lap_stride + 0];
+                    if (p.sslapid[l] < p.cur_it - 1) shift = base[8 * ls];
                     else shift = (double)tstep + (double)(N - crossed);
                 }
-                if (lane < p.ppl) {
-                    int r0 = start + lane; if (r0 > T - 1) r0 = T - 1; if (r0 < 0) r0 = 0;
-                    int r1 = start + lane + 1; if (r1 > T - 1) r1 = T - 1; if (r1 < 0) r1 = 0;
-                    const int col = l * p.ppl + lane;
-                    for (int j = 0; j < 6; j++) { SS[j * S + col] = base[j * p.lap_stride + r0]; Succ[j * S + col] = base[j * p.lap_stride + r1]; }
-                    SuccU[0 * S + col] = base[6 * p.lap_stride + r1]; SuccU[1 * S + col] = base[7 * p.lap_stride + r1];
-                    Qsel[col] = base[8 * p.lap_stride + r0] + shift;
+                if (lane < ppl) {
+                    int r0 = start + lane; r0 = r0 > T - 1 ? T - 1 : r0;
+                    int r1 = start + lane + 1; r1 = r1 > T - 1 ? T - 1 : r1;
+                    const int col = l * ppl + lane;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        const double v = base[j * ls + r0];
+                        SS[j * S + col] = v;
+                        if (io.ssSelOut) io.ssSelOut[((size_t)b * S + col) * 6 + j] = v;
+                        if (io.succOut) io.succOut[((size_t)b * S + col) * 6 + j] = base[j * ls + r1];
+                    }
+                    if (io.succUOut) { io.succUOut[((size_t)b * S + col) * 2] = base[6 * ls + r1]; io.succUOut[((size_t)b * S + col) * 2 + 1] = base[7 * ls + r1]; }
+                    const double qv = base[8 * ls + r0] + shift;
+                    Qsel[col] = qv;
+                    if (io.qSelOut) io.qSelOut[(size_t)b * S + col] = qv;
                 }
             }
         } else {
             FOR_LANES(c, S) {
-                for (int j = 0; j < 6; j++) { SS[j * S + c] = io.ssSelIn[((size_t)b * S + c) * 6 + j]; Succ[j * S + c] = 0.0; }
-                SuccU[c] = 0.0; SuccU[S + c] = 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) SS[j * S + c] = io.ssSelIn[((size_t)b * S + c) * 6 + j];
                 Qsel[c] = io.qSelIn[(size_t)b * S + c];
             }
         }
         __syncthreads();
-        FOR_LANES(c, S) {
-            if (io.ssSelOut) for (int j = 0; j < 6; j++) io.ssSelOut[((size_t)b * S + c) * 6 + j] = SS[j * S + c];
-            if (io.qSelOut) io.qSelOut[(size_t)b * S + c] = Qsel[c];
-            if (io.succOut) for (int j = 0; j < 6; j++) io.succOut[((size_t)b * S + c) * 6 + j] = Succ[j * S + c];
-            if (io.succUOut) { io.succUOut[((size_t)b * S + c) * 2 + 0] = SuccU[c]; io.succUOut[((size_t)b * S + c) * 2 + 1] = SuccU[S + c]; }
-        }
     }
+    TSTAMP(1);
     if (!(io.mode & 2)) { if (lane == 0) io.status[b] = st_sh; return; }
 
     // ------------------------------------------------------------------------------------------------
@@ -373,15 +448,15 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     // ------------------------------------------------------------------------------------------------
     FOR_LANES(i, 36 * N) A[i] = io.A[(size_t)b * 36 * N + i];
     FOR_LANES(i, 12 * N) Bm[i] = io.Bm[(size_t)b * 12 * N + i];
-    FOR_LANES(i, 6 * N) C[i] = io.C[(size_t)b * 6 * N + i];
+    FOR_LANES(i, 6 * N) { C[i] = io.C[(size_t)b * 6 * N + i]; nu[i] = 0.0; }
     if (lane < 6) x[lane] = io.x0[(size_t)b * 6 + lane];
     FOR_LANES(i, 2 * N) u[i] = 0.0;
-    FOR_LANES(i, 6 * N) nu[i] = 0.0;
     const double uOld0 = io.uOld[(size_t)b * 2 + 0], uOld1 = io.uOld[(size_t)b * 2 + 1];
     __syncthreads();
-    for (int k = 0; k < N; k++) {                      // strictly interior start: u = 0, x by roll-out
+    for (int k = 0; k < N; k++) {                          // strictly interior start: u = 0, x by roll-out
         if (lane < 6) {
             double v = C[k * 6 + lane];
+#pragma unroll
             for (int j = 0; j < 6; j++) v = fma(A[k * 36 + lane * 6 + j], x[k * 6 + j], v);
             x[(k + 1) * 6 + lane] = v;
         }
@@ -389,28 +464,36 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     }
     FOR_LANES(i, 2 * N) {
         const int k = i >> 1, j = i & 1; double f = 0.0;
-        for (int c = 0; c < 6; c++) f = fma(p.Fx[j * 6 + c], x[k * 6 + c], f);
-        s[i] = fmax(f - p.bx[j], 0.0) + 1.0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) f = fma(Fx[j * 6 + c], x[k * 6 + c], f);
+        s[i] = fmax(f - bx[j], 0.0) + 1.0;
     }
     double qmax = 0.0;
-    FOR_LANES(c, S) { lam[c] = 1.0 / (double)S; qmax = fmax(qmax, fabs(Qsel[c])); }
-    qmax = wave_max(qmax);
+    if constexpr (term) { FOR_LANES(c, S) { lam[c] = 1.0 / (double)S; qmax = fmax(qmax, fabs(Qsel[c])); } qmax = wmax(qmax); }
     const double mu0 = fmax(1.0, 0.01 * (term ? qmax : 1.0));
-    if (lane < 4 && !(p.bu[lane] > 0.0)) atomicOr(&st_sh, LMPC_ST_NOT_INTERIOR);
+    if (lane < 4 && !(bu[lane] > 0.0)) atomicOr(&st_sh, LMPC_ST_NOT_INTERIOR);
     double eta_m = 0.0;
     __syncthreads();
 
-    // row helpers ------------------------------------------------------------------------------------
-    // F_r . (x,u,s,lam) for row r in the reference's ordering
+    // F_r . (x,u,s,lam) and b_r for inequality row r in the reference's ordering
     auto rowF = [&](int r, const double *xx, const double *uu, const double *ss_, const double *ll) -> double {
-        if (r < 2 * N) { const int k = r >> 1, j = r & 1; double f = 0.0; for (int c = 0; c < 6; c++) f = fma(p.Fx[j * 6 + c], xx[k * 6 + c], f); return f - ss_[r]; }
-        if (r < 6 * N) { const int q = r - 2 * N, k = q >> 2, j = q & 3; return p.Fu[j * 2] * uu[k * 2] + p.Fu[j * 2 + 1] * uu[k * 2 + 1]; }
+        if (r < 2 * N) { const int k = r >> 1, j = r & 1; double f = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) f = fma(Fx[j * 6 + c], xx[k * 6 + c], f);
+            return f - ss_[r]; }
+        if (r < 6 * N) { const int q = r - 2 * N, k = q >> 2, j = q & 3; return Fu[j * 2] * uu[k * 2] + Fu[j * 2 + 1] * uu[k * 2 + 1]; }
         if (r < 8 * N) return -ss_[r - 6 * N];
         return -ll[r - 8 * N];
     };
-    auto rowb = [&](int r) -> double { if (r < 2 * N) return p.bx[r & 1]; if (r < 6 * N) return p.bu[(r - 2 * N) & 3]; return 0.0; };
+    auto rowb = [&](int r) -> double { if (r < 2 * N) return bx[r & 1]; if (r < 6 * N) return bu[(r - 2 * N) & 3]; return 0.0; };
 
-    FOR_LANES(r, M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t[r] = tt; m[r] = mu0 / tt; }
+    double t_r[RPL], rt_r[RPL], tp_r[RPL], dt_r[RPL];      // per-lane row state (row = lane + 64 j)
+#pragma unroll
+    for (int j = 0; j < RPL; j++) {
+        const int r = lane + WAVE * j;
+        t_r[j] = 1.0; rt_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
+        if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; m[r] = mu0 / tt; }
+    }
     __syncthreads();
 
     // one Newton-system solve for the right-hand side currently in (rx,ru,rs,rl,h); result in dx,du,ds,dl
@@ -418,51 +501,49 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         FOR_LANES(i, 2 * N) {                                   // slack elimination, per lane row (k,j)
             const double hl = h[i], hs = h[6 * N + i];
             const double e_ = -(rs[i] + hl + hs);
-            ee[i] = e_; eta[i] = hl + th[i] * e_ / Dsl[i];
-        }
-        if (term) {
-            double c_ = 0.0;
-            if (lane < S) c_ = (rl[lane] + h[8 * N + lane]) / sqD[lane];
-            ct[lane] = c_;
-            double yy[7];
-#pragma unroll
-            for (int j = 0; j < 7; j++) yy[j] = wave_sum(Qm[j * WAVE + lane] * c_);
-            if (lane < 7) {
-                double v = 0.0;
-#pragma unroll
-                for (int j = 0; j < 7; j++) if (lane == j) v = yy[j];
-                y7[lane] = v;
-            }
-        }
-        __syncthreads();
-        if (term && lane < 7) {                                 // w7 = Ri (Ri' d0 + y7), d0 = (0,..,0,-re_sum)
-            double v = Ri[6 * 7 + lane] * (-re_sum) + y7[lane];     // (Ri' d0)[lane] = Ri[6][lane] * d0[6]
-            sT[lane] = v;                                        // scratch
-        }
-        __syncthreads();
-        if (lane < 8) {
-            double v = 0.0;
-            if (lane < 6) {
-                v = rx[N * 6 + lane];
-                if (term) for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], sT[j], v);
-            }
-            pst[N * 8 + lane] = v;
+            ee[i] = e_; eta[i] = hl + th[i] * e_ * rDs[i];
         }
         FOR_LANES(i, 2 * N) {                                   // gu' = ru - Fu' h_u
             const int k = i >> 1, c = i & 1; double v = ru[i];
-            for (int j = 0; j < 4; j++) v -= p.Fu[j * 2 + c] * h[2 * N + 4 * k + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v -= Fu[j * 2 + c] * h[2 * N + 4 * k + j];
             gup[i] = v;
         }
+        if constexpr (term) {
+            double c_ = 0.0;
+            if (lane < S) c_ = (rl[lane] + h[8 * N + lane]) * rsq[lane];
+            ct[lane] = c_;
+            double yy[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) yy[j] = wsum(Qm[j * WAVE + lane] * c_);
+            if (lane < 7) {
+                double v = yy[0];
+#pragma unroll
+                for (int j = 1; j < 7; j++) if (lane == j) v = yy[j];
+                y7[lane] = v;
+                sT[lane] = Ri[6 * 7 + lane] * (-re_sum) + v;        // (Ri' d0 + y7), d0 = (0,..,0,-re_sum); sT is scratch here
+            }
+        }
         __syncthreads();
+        if (lane < 8) {                                         // terminal costate p_N = (rx_N + [Ri (Ri' d0 + y7)]_{0:6}, 0)
+            double v = 0.0;
+            if (lane < 6) {
+                v = rx[N * 6 + lane];
+                if constexpr (term) { for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], sT[j], v); }
+            }
+            pst[N * 8 + lane] = v;
+        }
         FOR_LANES(i, 8 * N) {                                   // gamma_k = [gx' - Kx' gu' ; -Ku' gu'] = [gx';0] + Phi[6:8,:]' gu'
             const int k = i >> 3, c = i & 7;
             double v = 0.0;
-            if (c < 6) { v = rx[k * 6 + c]; v -= p.Fx[0 * 6 + c] * eta[2 * k] + p.Fx[1 * 6 + c] * eta[2 * k + 1]; }
-            v = fma(Phi[k * 64 + 6 * 8 + c], gup[2 * k], v);
-            v = fma(Phi[k * 64 + 7 * 8 + c], gup[2 * k + 1], v);
+            if (c < 6) { v = rx[k * 6 + c]; v -= Fx[c] * eta[2 * k] + Fx[6 + c] * eta[2 * k + 1]; }
+            v = fma(Phi[k * 64 + 48 + c], gup[2 * k], v);
+            v = fma(Phi[k * 64 + 56 + c], gup[2 * k + 1], v);
             gam[i] = v;
         }
         __syncthreads();
+        TSTAMP(30);
+#pragma unroll 1
         for (int k = N - 1; k >= 0; k--) {                      // backward sweep: p_k = Phi_k' p_{k+1} + gamma_k
             if (lane < 8) {
                 double v = gam[k * 8 + lane];
@@ -472,11 +553,12 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             }
             __syncthreads();
         }
+        TSTAMP(31);
         FOR_LANES(i, 2 * N) {                                   // k0_k = Mi_k (gu' + B' p_x + p_u)
-            const int k = i >> 1;
+            const int k = i >> 1, c = i & 1;
             double w0 = gup[2 * k] + pst[(k + 1) * 8 + 6], w1 = gup[2 * k + 1] + pst[(k + 1) * 8 + 7];
+#pragma unroll
             for (int j = 0; j < 6; j++) { w0 = fma(Bm[k * 12 + j * 2], pst[(k + 1) * 8 + j], w0); w1 = fma(Bm[k * 12 + j * 2 + 1], pst[(k + 1) * 8 + j], w1); }
-            const int c = i & 1;
             k0[i] = Mi[k * 4 + c * 2] * w0 + Mi[k * 4 + c * 2 + 1] * w1;
         }
         __syncthreads();
@@ -486,6 +568,8 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         }
         if (lane < 6) dx[lane] = 0.0;
         __syncthreads();
+        TSTAMP(32);
+#pragma unroll 1
         for (int k = 0; k < N; k++) {                           // forward sweep: xi_{k+1} = Phi_k xi_k + phi_k
             if (lane < 8) {
                 double v = phi[k * 8 + lane];
@@ -496,45 +580,56 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             }
             __syncthreads();
         }
+        TSTAMP(33);
         FOR_LANES(i, 2 * N) {
             const int k = i >> 1, j = i & 1; double f = 0.0;
-            for (int c = 0; c < 6; c++) f = fma(p.Fx[j * 6 + c], dx[k * 6 + c], f);
-            ds[i] = (th[i] * f + ee[i]) / Dsl[i];
+#pragma unroll
+            for (int c = 0; c < 6; c++) f = fma(Fx[j * 6 + c], dx[k * 6 + c], f);
+            ds[i] = (th[i] * f + ee[i]) * rDs[i];
         }
-        if (term) {
+        if constexpr (term) {
             if (lane < 7) {                                     // z7 = Ri' d7, d7 = (dx_N ; -re_sum)
                 double v = 0.0;
                 for (int j = 0; j <= lane; j++) v = fma(Ri[j * 7 + lane], j < 6 ? dx[N * 6 + j] : -re_sum, v);
-                w7[lane] = v;
+                z7[lane] = v + y7[lane];
             }
             __syncthreads();
             double v = -ct[lane];
 #pragma unroll
-            for (int j = 0; j < 7; j++) v = fma(Qm[j * WAVE + lane], y7[j] + w7[j], v);
-            if (lane < S) dl[lane] = v / sqD[lane];
+            for (int j = 0; j < 7; j++) v = fma(Qm[j * WAVE + lane], z7[j], v);
+            if (lane < S) dl[lane] = v * rsq[lane];
         }
         __syncthreads();
     };
 
     int it = 0, converged = 0;
     double gap = 0.0, rdn = 0.0, ren = 0.0;
+#pragma unroll 1
     for (it = 0; it <= p.max_iter; it++) {
+        TSTAMP(10);
         // ---- slacks of the inequality rows, terminal slack, residuals --------------------------------
-        FOR_LANES(r, M) t[r] = rowb(r) - rowF(r, x, u, s, lam);
-        if (term && lane < 6) { double v = -x[N * 6 + lane]; for (int c = 0; c < S; c++) v = fma(SS[lane * S + c], lam[c], v); sT[lane] = v; }
-        __syncthreads();
         double gsum = 0.0, rmax = 0.0, remax = 0.0;
-        FOR_LANES(r, M) gsum = fma(t[r], m[r], gsum);
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            const int r = lane + WAVE * j;
+            if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; rt_r[j] = 1.0 / tt; gsum = fma(tt, m[r], gsum); }
+        }
+        if constexpr (term) {
+            if (lane < 6) { double v = -x[N * 6 + lane]; for (int c = 0; c < S; c++) v = fma(SS[lane * S + c], lam[c], v); sT[lane] = v; }
+            __syncthreads();
+        }
         FOR_LANES(i, 6 * (N + 1)) {
             const int k = i / 6, c = i % 6; double v = 0.0;
             if (k >= 1) {
-                const double *Qk = k < N ? p.Q2 : p.Qf2;
-                for (int j = 0; j < 6; j++) v = fma(Qk[c * 6 + j], x[k * 6 + j] - p.xRef[j], v);
+                const double *Qk = k < N ? Q2 : Qf2;
+#pragma unroll
+                for (int j = 0; j < 6; j++) v = fma(Qk[c * 6 + j], x[k * 6 + j] - xRef[j], v);
                 v += nu[(k - 1) * 6 + c];
                 if (k < N) {
-                    v += p.Fx[0 * 6 + c] * m[2 * k] + p.Fx[1 * 6 + c] * m[2 * k + 1];
+                    v += Fx[c] * m[2 * k] + Fx[6 + c] * m[2 * k + 1];
+#pragma unroll
                     for (int j = 0; j < 6; j++) v -= A[k * 36 + j * 6 + c] * nu[k * 6 + j];
-                } else if (term) v -= p.T2[c] * sT[c];
+                } else if (term) v -= T2p[c] * sT[c];
                 rmax = fmax(rmax, fabs(v));
             }
             rx[i] = v;
@@ -542,68 +637,77 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         FOR_LANES(i, 2 * N) {
             const int k = i >> 1, c = i & 1;
             const double up = k > 0 ? u[(k - 1) * 2 + c] : (c == 0 ? uOld0 : uOld1);
-            double v = p.R2[c * 2] * u[k * 2] + p.R2[c * 2 + 1] * u[k * 2 + 1] + p.dR2[c] * (u[i] - up);
-            if (k < N - 1) v += p.dR2[c] * (u[i] - u[(k + 1) * 2 + c]);
-            for (int j = 0; j < 4; j++) v = fma(p.Fu[j * 2 + c], m[2 * N + 4 * k + j], v);
+            double v = R2[c * 2] * u[k * 2] + R2[c * 2 + 1] * u[k * 2 + 1] + dR2[c] * (u[i] - up);
+            if (k < N - 1) v += dR2[c] * (u[i] - u[(k + 1) * 2 + c]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) v = fma(Fu[j * 2 + c], m[2 * N + 4 * k + j], v);
+#pragma unroll
             for (int j = 0; j < 6; j++) v -= Bm[k * 12 + j * 2 + c] * nu[k * 6 + j];
             ru[i] = v; rmax = fmax(rmax, fabs(v));
-            const double vs = p.a_s * s[i] + p.c_s - m[i] - m[6 * N + i];
+            const double vs = a_s * s[i] + c_s - m[i] - m[6 * N + i];
             rs[i] = vs; rmax = fmax(rmax, fabs(vs));
         }
         double lsum = 0.0;
-        FOR_LANES(c, S) {
-            double v = Qsel[c] - m[8 * N + c] + eta_m;
-            for (int j = 0; j < 6; j++) v = fma(SS[j * S + c], p.T2[j] * sT[j], v);
-            rl[c] = v; rmax = fmax(rmax, fabs(v)); lsum += lam[c];
+        if constexpr (term) {
+            FOR_LANES(c, S) {
+                double v = Qsel[c] - m[8 * N + c] + eta_m;
+#pragma unroll
+                for (int j = 0; j < 6; j++) v = fma(SS[j * S + c], T2p[j] * sT[j], v);
+                rl[c] = v; rmax = fmax(rmax, fabs(v)); lsum += lam[c];
+            }
         }
         FOR_LANES(i, 6 * N) {                                    // dynamics residual (monitoring only)
             const int k = i / 6, c = i % 6;
             double v = x[(k + 1) * 6 + c] - C[i] - Bm[k * 12 + c * 2] * u[k * 2] - Bm[k * 12 + c * 2 + 1] * u[k * 2 + 1];
+#pragma unroll
             for (int j = 0; j < 6; j++) v -= A[k * 36 + c * 6 + j] * x[k * 6 + j];
             remax = fmax(remax, fabs(v));
         }
-        gap = wave_sum(gsum) / (double)M;
-        rdn = wave_max(rmax);
-        const double re_sum = term ? wave_sum(lsum) - 1.0 : 0.0;
-        ren = fmax(wave_max(remax), fabs(re_sum));
+        gap = wsum(gsum) / (double)M;
+        rdn = wmax(rmax);
+        const double re_sum = term ? wsum(lsum) - 1.0 : 0.0;
+        ren = fmax(wmax(remax), fabs(re_sum));
         if (gap < p.tol_gap && rdn < p.tol_res && ren < p.tol_res) { converged = 1; break; }
         if (it == p.max_iter) break;
         if (!(gap == gap) || !(rdn == rdn)) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
 
+        TSTAMP(11);
         // ---- factorisation of the Newton (block-banded KKT) matrix -------------------------------------
-        FOR_LANES(r, M) th[r] = m[r] / t[r];
-        __syncthreads();
-        FOR_LANES(i, 2 * N) {
-            const double d_ = p.a_s + th[i] + th[6 * N + i];
-            Dsl[i] = d_; kap[i] = th[i] * (p.a_s + th[6 * N + i]) / d_;
-        }
+#pragma unroll
+        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) th[r] = m[r] * rt_r[j]; }
         FOR_LANES(i, 64) Pi[i] = 0.0;
         __syncthreads();
-        if (term) {
+        FOR_LANES(i, 2 * N) {
+            const double d_ = 1.0 / (a_s + th[i] + th[6 * N + i]);
+            rDs[i] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
+        }
+        if constexpr (term) {
             // terminal block: M = [E D^-1/2 | T7^-1/2] (7 x (S+6)), M' = Q R by twice-applied MGS, one column of M per lane
             double q[7];
 #pragma unroll
             for (int j = 0; j < 7; j++) q[j] = 0.0;
             if (lane < S) {
-                const double sd = sqrt(th[8 * N + lane] + p.reg); sqD[lane] = sd;
+                const double rs_ = 1.0 / sqrt(th[8 * N + lane] + p.reg); rsq[lane] = rs_;
 #pragma unroll
-                for (int j = 0; j < 6; j++) q[j] = SS[j * S + lane] / sd;
-                q[6] = 1.0 / sd;
-            } else if (lane < S + 6) {
-                sqD[lane] = 1.0;
+                for (int j = 0; j < 6; j++) q[j] = SS[j * S + lane] * rs_;
+                q[6] = rs_;
+            } else {
+                rsq[lane] = 1.0;
 #pragma unroll
-                for (int j = 0; j < 6; j++) if (lane - S == j) q[j] = 1.0 / sqrt(p.T2[j]);
-            } else sqD[lane] = 1.0;
+                for (int j = 0; j < 6; j++) if (lane - S == j) q[j] = 1.0 / sqrt(T2p[j]);
+            }
+#pragma unroll
             for (int pass = 0; pass < 2; pass++) {
                 double *Rp = pass == 0 ? Ra : Rb;
 #pragma unroll
                 for (int i = 0; i < 7; i++) {
-                    const double nrm = sqrt(wave_sum(q[i] * q[i]));
-                    q[i] = q[i] / nrm;
+                    const double n2 = wsum(q[i] * q[i]);
+                    const double nrm = sqrt(n2), rn = 1.0 / nrm;
+                    q[i] = q[i] * rn;
                     if (lane == 0) Rp[i * 7 + i] = nrm;
 #pragma unroll
                     for (int j = 0; j < 7; j++) if (j > i) {
-                        const double rij = wave_sum(q[i] * q[j]);
+                        const double rij = wsum(q[i] * q[j]);
                         q[j] = fma(-rij, q[i], q[j]);
                         if (lane == 0) { Rp[i * 7 + j] = rij; Rp[j * 7 + i] = 0.0; }
                     }
@@ -618,19 +722,17 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
                 Rm[lane] = v;
             }
             __syncthreads();
-            if (lane < 7) {                                      // Ri = R^-1, column `lane` by back substitution
+            if (lane < 7) {                                      // Ri = R^-1, column `lane` by back substitution (through LDS)
                 const int j = lane;
-                double col[7];
-#pragma unroll
-                for (int i = 0; i < 7; i++) col[i] = 0.0;
                 for (int i = 6; i >= 0; i--) {
-                    if (i > j) continue;
-                    double v = (i == j) ? 1.0 : 0.0;
-                    for (int k = i + 1; k <= j; k++) v -= Rm[i * 7 + k] * col[k];
-                    col[i] = v / Rm[i * 7 + i];
+                    double v = 0.0;
+                    if (i <= j) {
+                        v = (i == j) ? 1.0 : 0.0;
+                        for (int k = i + 1; k <= j; k++) v -= Rm[i * 7 + k] * Ri[k * 7 + j];
+                        v = v / Rm[i * 7 + i];
+                    }
+                    Ri[i * 7 + j] = v;
                 }
-#pragma unroll
-                for (int i = 0; i < 7; i++) Ri[i * 7 + j] = col[i];
             }
             __syncthreads();
             if (lane < 36) {                                     // Pi_term = (Ri Ri')[0:6,0:6]
@@ -640,9 +742,11 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             }
             __syncthreads();
         }
-        if (lane < 36) { const int i = lane / 6, j = lane % 6; Pi[i * 8 + j] = p.Qf2[lane] + (term ? PiT[lane] : 0.0); }
+        TSTAMP(12);
+        if (lane < 36) { const int i = lane / 6, j = lane % 6; Pi[i * 8 + j] = Qf2[lane] + (term ? PiT[lane] : 0.0); }
         __syncthreads();
         int numeric_bad = 0;
+#pragma unroll 1
         for (int k = N - 1; k >= 0; k--) {
             const double *Ak = A + k * 36, *Bk = Bm + k * 12;
             if (lane < 36) {                                     // T1 = Pxx A
@@ -659,7 +763,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             __syncthreads();
             if (lane < 36) {                                     // Mxx = Hx + A' T1
                 const int i = lane / 6, j = lane % 6;
-                double v = p.Q2[lane] + kap[2 * k] * p.Fx[i] * p.Fx[j] + kap[2 * k + 1] * p.Fx[6 + i] * p.Fx[6 + j];
+                double v = Q2[lane] + kap[2 * k] * Fx[i] * Fx[j] + kap[2 * k + 1] * Fx[6 + i] * Fx[6 + j];
 #pragma unroll
                 for (int l = 0; l < 6; l++) v = fma(Ak[l * 6 + i], T1[l * 6 + j], v);
                 Mxx[lane] = v;
@@ -670,111 +774,140 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
                 Mxu[q] = v;
             } else if (lane < 52) {                              // Muu = Hu + 2dR + B'T2 + Pxu'B + Puu
                 const int q = lane - 48, c = q >> 1, d = q & 1;
-                double v = p.R2[q] + (c == d ? p.dR2[c] : 0.0) + Pi[(6 + c) * 8 + 6 + d];
-                for (int j = 0; j < 4; j++) v = fma(th[2 * N + 4 * k + j] * p.Fu[j * 2 + c], p.Fu[j * 2 + d], v);
+                double v = R2[q] + (c == d ? dR2[c] : 0.0) + Pi[(6 + c) * 8 + 6 + d];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v = fma(th[2 * N + 4 * k + j] * Fu[j * 2 + c], Fu[j * 2 + d], v);
 #pragma unroll
                 for (int l = 0; l < 6; l++) { v = fma(Bk[l * 2 + c], T2[l * 2 + d], v); v = fma(Pi[l * 8 + 6 + c], Bk[l * 2 + d], v); }
                 Muu[q] = v;
             }
             __syncthreads();
-            const double det = Muu[0] * Muu[3] - Muu[1] * Muu[2];
-            if (!(det > 0.0) || !(Muu[0] > 0.0)) numeric_bad = 1;
-            const double i00 = Muu[3] / det, i01 = -Muu[1] / det, i10 = -Muu[2] / det, i11 = Muu[0] / det;
-            if (lane < 12) {                                     // Phi[6:8, 0:6] = -Kx = -Mi Mxu'
-                const int c = lane / 6, j = lane % 6;
-                const double kx = (c == 0 ? i00 : i10) * Mxu[j * 2] + (c == 0 ? i01 : i11) * Mxu[j * 2 + 1];
-                Phi[k * 64 + (6 + c) * 8 + j] = -kx;
-            } else if (lane < 16) {                              // Phi[6:8, 6:8] = -Ku = Mi 2dR
-                const int q = lane - 12, c = q >> 1, d = q & 1;
-                const double mi = c == 0 ? (d == 0 ? i00 : i01) : (d == 0 ? i10 : i11);
-                Phi[k * 64 + (6 + c) * 8 + 6 + d] = mi * p.dR2[d];
-                Mi[k * 4 + q] = mi;
-            }
-            __syncthreads();
-            const double *F6 = Phi + k * 64 + 48, *F7 = Phi + k * 64 + 56;      // rows -K (2 x 8)
+            // every lane inverts the 2x2 pivot and forms the rows of -K it needs (saves one LDS round trip per stage)
+            const double m00 = Muu[0], m01 = Muu[1], m10 = Muu[2], m11 = Muu[3];
+            const double det = m00 * m11 - m01 * m10;
+            if (!(det > 0.0) || !(m00 > 0.0)) numeric_bad = 1;
+            const double rdet = 1.0 / det;
+            const double i00 = m11 * rdet, i01 = -m01 * rdet, i10 = -m10 * rdet, i11 = m00 * rdet;
+            // F6[c] = -K[0][c], F7[c] = -K[1][c] for c = 0..7 (c < 6: -Kx, c >= 6: -Ku = Mi 2dR)
+            auto negK = [&](int row, int c) -> double {
+                const double a0 = row == 0 ? i00 : i10, a1 = row == 0 ? i01 : i11;
+                if (c < 6) return -(a0 * Mxu[c * 2] + a1 * Mxu[c * 2 + 1]);
+                return (c == 6 ? a0 : a1) * dR2[c - 6];
+            };
             if (lane < 36) {                                     // Pxx_new = Mxx - Mxu Kx ; Acl = A - B Kx
                 const int i = lane / 6, j = lane % 6;
-                Pi[i * 8 + j] = Mxx[lane] + Mxu[i * 2] * F6[j] + Mxu[i * 2 + 1] * F7[j];
-                Phi[k * 64 + i * 8 + j] = Ak[lane] + Bk[i * 2] * F6[j] + Bk[i * 2 + 1] * F7[j];
+                const double f6 = negK(0, j), f7 = negK(1, j);
+                Pi[i * 8 + j] = Mxx[lane] + Mxu[i * 2] * f6 + Mxu[i * 2 + 1] * f7;
+                Phi[k * 64 + i * 8 + j] = Ak[lane] + Bk[i * 2] * f6 + Bk[i * 2 + 1] * f7;
             } else if (lane < 48) {                              // Pxu_new = -Mxu Ku ; Bcl = -B Ku
                 const int q = lane - 36, i = q >> 1, d = q & 1;
-                const double v = Mxu[i * 2] * F6[6 + d] + Mxu[i * 2 + 1] * F7[6 + d];
+                const double f6 = negK(0, 6 + d), f7 = negK(1, 6 + d);
+                const double v = Mxu[i * 2] * f6 + Mxu[i * 2 + 1] * f7;
                 Pi[i * 8 + 6 + d] = v; Pi[(6 + d) * 8 + i] = v;
-                Phi[k * 64 + i * 8 + 6 + d] = Bk[i * 2] * F6[6 + d] + Bk[i * 2 + 1] * F7[6 + d];
-            } else if (lane < 52) {                              // Puu_new = 2dR + 2dR Ku
+                Phi[k * 64 + i * 8 + 6 + d] = Bk[i * 2] * f6 + Bk[i * 2 + 1] * f7;
+            } else if (lane < 52) {                              // Puu_new = 2dR + 2dR Ku ; Mi
                 const int q = lane - 48, c = q >> 1, d = q & 1;
-                Pi[(6 + c) * 8 + 6 + d] = (c == d ? p.dR2[c] : 0.0) - p.dR2[c] * (c == 0 ? F6[6 + d] : F7[6 + d]);
+                Pi[(6 + c) * 8 + 6 + d] = (c == d ? dR2[c] : 0.0) - dR2[c] * negK(c, 6 + d);
+                Mi[k * 4 + q] = c == 0 ? (d == 0 ? i00 : i01) : (d == 0 ? i10 : i11);
+            } else {                                             // Phi rows 6,7 = -K (lanes 52..63 write 16 entries)
+                for (int e = lane - 52; e < 16; e += 12) { const int row = e >> 3, c = e & 7; Phi[k * 64 + (6 + row) * 8 + c] = negK(row, c); }
             }
             __syncthreads();
         }
         if (numeric_bad) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
 
+        TSTAMP(13);
         // ---- predictor (affine scaling) direction: h = mu -------------------------------------------------
         FOR_LANES(r, M) h[r] = m[r];
         __syncthreads();
         kkt_solve(re_sum);
-        double amax = 1.0;
-        FOR_LANES(r, M) {
-            const double dta = -rowF(r, dx, du, ds, dl);
-            const double dma = -m[r] - th[r] * dta;
-            dtv[r] = dta; dm[r] = dma;
-            if (dta < 0.0) amax = fmin(amax, -t[r] / dta);
-            if (dma < 0.0) amax = fmin(amax, -m[r] / dma);
+        TSTAMP(14);
+        double amax = 1.0, dma_r[RPL];
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            const int r = lane + WAVE * j; dma_r[j] = 0.0;
+            if (r < M) {
+                const double dta = -rowF(r, dx, du, ds, dl), mr = m[r];
+                const double dma = -mr - th[r] * dta;
+                dt_r[j] = dta; dma_r[j] = dma;
+                if (dta < 0.0) amax = fmin(amax, -t_r[j] / dta);
+                if (dma < 0.0) amax = fmin(amax, -mr / dma);
+            }
         }
-        amax = wave_min(amax);
+        amax = wmin(amax);
         double gaff = 0.0;
-        FOR_LANES(r, M) { gaff = fma(t[r] + amax * dtv[r], m[r] + amax * dm[r], gaff); tp[r] = dtv[r] * dm[r]; }
-        gaff = wave_sum(gaff) / (double)M;
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            const int r = lane + WAVE * j;
+            if (r < M) { gaff = fma(t_r[j] + amax * dt_r[j], m[r] + amax * dma_r[j], gaff); tp_r[j] = dt_r[j] * dma_r[j]; }
+        }
+        gaff = wsum(gaff) / (double)M;
         double sig = gaff / gap; sig = sig * sig * sig;
         // ---- corrector: h = (t mu - sigma gap + dt_aff dmu_aff) / t ----------------------------------------
         __syncthreads();
-        FOR_LANES(r, M) h[r] = (t[r] * m[r] - sig * gap + tp[r]) / t[r];
+#pragma unroll
+        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) h[r] = m[r] + (tp_r[j] - sig * gap) * rt_r[j]; }
         __syncthreads();
+        TSTAMP(15);
         kkt_solve(re_sum);
+        TSTAMP(16);
         double amx = INFINITY;
-        FOR_LANES(r, M) {
-            const double dtt = -rowF(r, dx, du, ds, dl);
-            const double dmm = -h[r] - th[r] * dtt;
-            dtv[r] = dtt; dm[r] = dmm;
-            if (dtt < 0.0) amx = fmin(amx, -t[r] / dtt);
-            if (dmm < 0.0) amx = fmin(amx, -m[r] / dmm);
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            const int r = lane + WAVE * j;
+            if (r < M) {
+                const double dtt = -rowF(r, dx, du, ds, dl), mr = m[r];
+                const double dmm = -h[r] - th[r] * dtt;
+                dm[r] = dmm;
+                if (dtt < 0.0) amx = fmin(amx, -t_r[j] / dtt);
+                if (dmm < 0.0) amx = fmin(amx, -mr / dmm);
+            }
         }
-        amx = wave_min(amx);
+        amx = wmin(amx);
         const double al = fmin(1.0, 0.995 * amx);
-        __syncthreads();
+        TSTAMP(17);
         // ---- multipliers of the equality rows (costates), backwards ----------------------------------------
-        if (term && lane < 6) { double v = -dx[N * 6 + lane]; for (int c = 0; c < S; c++) v = fma(SS[lane * S + c], dl[c], v); w7[lane] = v; }   // d s_T
+        if constexpr (term) {
+            if (lane < 6) { double v = -dx[N * 6 + lane]; for (int c = 0; c < S; c++) v = fma(SS[lane * S + c], dl[c], v); w7[lane] = v; }   // d s_T
+        }
         __syncthreads();
         if (lane < 6) {
             double g = rx[N * 6 + lane];
-            for (int j = 0; j < 6; j++) g = fma(p.Qf2[lane * 6 + j], dx[N * 6 + j], g);
-            if (term) g -= p.T2[lane] * w7[lane];
+#pragma unroll
+            for (int j = 0; j < 6; j++) g = fma(Qf2[lane * 6 + j], dx[N * 6 + j], g);
+            if constexpr (term) g -= T2p[lane] * w7[lane];
             dnu[(N - 1) * 6 + lane] = -g;
         }
         __syncthreads();
+#pragma unroll 1
         for (int k = N - 1; k >= 1; k--) {
             if (lane < 6) {
-                double g = rx[k * 6 + lane] + p.Fx[lane] * dm[2 * k] + p.Fx[6 + lane] * dm[2 * k + 1];
-                for (int j = 0; j < 6; j++) { g = fma(p.Q2[lane * 6 + j], dx[k * 6 + j], g); g -= A[k * 36 + j * 6 + lane] * dnu[k * 6 + j]; }
+                double g = rx[k * 6 + lane] + Fx[lane] * dm[2 * k] + Fx[6 + lane] * dm[2 * k + 1];
+#pragma unroll
+                for (int j = 0; j < 6; j++) { g = fma(Q2[lane * 6 + j], dx[k * 6 + j], g); g -= A[k * 36 + j * 6 + lane] * dnu[k * 6 + j]; }
                 dnu[(k - 1) * 6 + lane] = -g;
             }
             __syncthreads();
         }
         double deta = 0.0;
-        if (term) {
+        if constexpr (term) {
             double v = 0.0;
-            if (lane < S) { v = -rl[lane] + dm[8 * N + lane]; for (int j = 0; j < 6; j++) v -= SS[j * S + lane] * p.T2[j] * w7[j]; }
-            deta = wave_sum(v) / (double)S;
+            if (lane < S) { v = -rl[lane] + dm[8 * N + lane];
+#pragma unroll
+                for (int j = 0; j < 6; j++) v -= SS[j * S + lane] * T2p[j] * w7[j]; }
+            deta = wsum(v) / (double)S;
         }
+        TSTAMP(18);
         // ---- step ------------------------------------------------------------------------------------------
         FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
         FOR_LANES(i, 2 * N) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
-        FOR_LANES(c, S) lam[c] = fma(al, dl[c], lam[c]);
+        if constexpr (term) { FOR_LANES(c, S) lam[c] = fma(al, dl[c], lam[c]); }
         FOR_LANES(r, M) m[r] = fma(al, dm[r], m[r]);
         FOR_LANES(i, 6 * N) nu[i] = fma(al, dnu[i], nu[i]);
         eta_m = fma(al, deta, eta_m);
         __syncthreads();
     }
+    TSTAMP(20);
     if (!converged && lane == 0 && !(st_sh & LMPC_ST_NUMERIC)) atomicOr(&st_sh, LMPC_ST_MAXITER);
     __syncthreads();
 
@@ -782,26 +915,52 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     FOR_LANES(i, 6 * (N + 1)) io.xPred[(size_t)b * 6 * (N + 1) + i] = x[i];
     FOR_LANES(i, 2 * N) { io.uPred[(size_t)b * 2 * N + i] = u[i]; if (io.slack) io.slack[(size_t)b * 2 * N + i] = s[i]; }
     if (io.mu) FOR_LANES(r, M) io.mu[(size_t)b * M + r] = m[r];
-    if (term) {
+    if constexpr (term) {
         if (io.lambda) FOR_LANES(c, S) io.lambda[(size_t)b * S + c] = lam[c];
-        if (lane < 6) {
-            double v = -x[N * 6 + lane], z = 0.0;
-            for (int c = 0; c < S; c++) { v = fma(SS[lane * S + c], lam[c], v); z = fma(Succ[lane * S + c], lam[c], z); }
-            if (io.sTerm) io.sTerm[(size_t)b * 6 + lane] = v;
-            if (io.ztNext) io.ztNext[(size_t)b * 6 + lane] = z;
-        } else if (lane < 8 && io.ztuNext) {
-            double z = 0.0; const int c2 = lane - 6;
-            for (int c = 0; c < S; c++) z = fma(SuccU[c2 * S + c], lam[c], z);
-            io.ztuNext[(size_t)b * 2 + c2] = z;
+        if (lane < 6 && io.sTerm) {
+            double v = -x[N * 6 + lane];
+            for (int c = 0; c < S; c++) v = fma(SS[lane * S + c], lam[c], v);
+            io.sTerm[(size_t)b * 6 + lane] = v;
+        }
+        if ((io.mode & 1) && (io.ztNext || io.ztuNext)) {
+            // zt = Succ_SS lambda, zt_u = Succ_uSS lambda: successor rows are read back from the store (window starts kept)
+            double acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = 0.0;
+            if (lane < S) {
+                const int l = lane / p.ppl, cc = lane % p.ppl;
+                const double *base = p.sstore + (size_t)p.sslot[l] * LMPC_COLS * p.lap_stride;
+                int r1 = sel_start[l] + cc + 1; r1 = r1 > p.sslen[l] - 1 ? p.sslen[l] - 1 : r1;
+                const double lv = lam[lane];
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] = base[j * p.lap_stride + r1] * lv;
+            }
+            // reference order of np.dot(Succ, lambd): sequential over columns; a tree sum differs by rounding only
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = wsum(acc[j]);
+            if (lane < 6 && io.ztNext) { double v = acc[0];
+#pragma unroll
+                for (int j = 1; j < 6; j++) if (lane == j) v = acc[j];
+                io.ztNext[(size_t)b * 6 + lane] = v; }
+            if (lane < 2 && io.ztuNext) io.ztuNext[(size_t)b * 2 + lane] = lane == 0 ? acc[6] : acc[7];
         }
     } else {
         if (lane < 6 && io.ztNext) io.ztNext[(size_t)b * 6 + lane] = x[N * 6 + lane];          // MPC.feasibleStateInput :157-159
         if (lane < 2 && io.ztuNext) io.ztuNext[(size_t)b * 2 + lane] = u[(N - 1) * 2 + lane];
     }
+    TSTAMP(21);
     if (lane == 0) {
         io.status[b] = st_sh; io.iters[b] = it;
         if (io.resid) { io.resid[(size_t)b * 3] = gap; io.resid[(size_t)b * 3 + 1] = rdn; io.resid[(size_t)b * 3 + 2] = ren; }
     }
+}
+
+// wave-reduction self test (exercised by lmpc_selftest): out[0..2] = sum, max, min of lane-dependent values
+__global__ void lmpc_selftest_kernel(double *out) {
+    const int lane = threadIdx.x;
+    const double v = 1.0 + 0.25 * lane + ((lane * 37) % 11) * 1e-3;
+    const double s = wsum(v), mx = wmax(v), mn = wmin(v);
+    out[lane] = s; out[64 + lane] = mx; out[128 + lane] = mn;
 }
 
 // =====================================================================================================

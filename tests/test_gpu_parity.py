@@ -135,3 +135,10 @@ def test_status_flags(g):
 def _flag(name):
     from racinglmpc_amd import _capi
     return getattr(_capi, name)
+
+
+def test_device_selftest(g):
+    """DPP / v_permlane16_swap / v_permlane32_swap based wave reductions return exact sums / extrema."""
+    ctx, par = common.make_lmpc_ctx(g, 4, max_batch=1)
+    ctx.selftest()
+    ctx.close()

@@ -1,0 +1,46 @@
+"""Developer tool: per-phase cycle breakdown of one QP solve (problem 0) inside lmpc_solve_kernel.
+Builds a separate timing variant (liblmpc_hip_timing.so, -DLMPC_TIMING) so the product .so carries no stamps.
+Run on the GPU box:  python tools/phase_timing.py [record]"""
+import ctypes as C
+import collections
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = os.path.join(ROOT, "racinglmpc_amd", "liblmpc_hip_timing.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLMPC_TIMING",
+                       "-o", so, os.path.join(ROOT, "racinglmpc_amd", "csrc", "lmpc_capi.hip")])
+from racinglmpc_amd import _capi
+_capi.LIB_PATH = so
+from tests import common
+g = common.load_lmpc_golden()
+r = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+cfg, par = common.lmpc_config(g, 12, max_batch=4)
+ctx = _capi.Context(cfg)
+NT = 8000
+tb = np.zeros(NT, np.int64)
+f = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data_as(C.c_void_p)
+for rep in range(2):
+    rc = ctx.lib.lmpc_debug_timing(ctx._h, f(g["rec_A"][r]), f(g["rec_B"][r]), f(g["rec_C"][r]), f(g["rec_x0"][r]), f(g["rec_OldInput"][r]),
+                                   f(np.ascontiguousarray(g["rec_SSsel"][r].T)), f(g["rec_Qsel"][r]), tb.ctypes.data_as(C.c_void_p), C.c_int(NT))
+    assert rc == 0, ctx.lib.lmpc_last_error()
+ids, cyc = tb[0::2], tb[1::2]
+n = int(np.argmax(ids == 21)) + 1
+ids, cyc = ids[:n], cyc[:n]
+names = {(0, 1): "prologue+select", (1, 10): "init (load, rollout)", (10, 11): "residuals", (11, 12): "factor: terminal (MGS2, Ri, PiT)",
+         (12, 13): "factor: stages", (13, 30): "solve A: pre", (30, 31): "solve: backward sweep", (31, 32): "solve: k0/phi", (32, 33): "solve: forward sweep",
+         (33, 14): "solve A: post", (14, 15): "predictor post (steps, sigma, h)", (15, 30): "solve B: pre", (33, 16): "solve B: post",
+         (16, 17): "corrector post (dm, alpha)", (17, 18): "costates", (18, 10): "update", (18, 20): "update(last)", (10, 20): "final residual check", (20, 21): "epilogue"}
+acc = collections.OrderedDict()
+for i in range(1, n):
+    key = (int(ids[i - 1]), int(ids[i]))
+    acc.setdefault(key, []).append(int(cyc[i] - cyc[i - 1]))
+tot = int(cyc[n - 1] - cyc[0])
+iters = int(np.sum(ids == 11))
+print("total cycles %d, IPM iterations %d (%.0f cycles / iteration)" % (tot, iters, tot / max(iters, 1)))
+for key, v in acc.items():
+    print("%-40s n=%3d mean %8.0f  total %9d  (%.1f%%)" % (names.get(key, str(key)), len(v), np.mean(v), np.sum(v), 100.0 * np.sum(v) / tot))
