@@ -312,21 +312,35 @@ enum { PAR_FX = 0, PAR_FU = 12, PAR_BX = 20, PAR_BU = 22, PAR_Q2 = 26, PAR_QF2 =
 
 template <int N, int S> struct solve_lds {
     static constexpr int M = 8 * N + S;
-    static constexpr int oA = 0, oB = oA + 36 * N, oC = oB + 12 * N;
+    static constexpr int oAB = 0, oC = oAB + 48 * N;                      // AB[k] = [A_k | B_k] (6 x 8), C_k
     static constexpr int ox = oC + 6 * N, ou = ox + 6 * (N + 1), os = ou + 2 * N, olam = os + 2 * N;
     static constexpr int odx = olam + S, odu = odx + 6 * (N + 1), ods = odu + 2 * N, odl = ods + 2 * N;
     static constexpr int onu = odl + S, odnu = onu + 6 * N;
     static constexpr int om = odnu + 6 * N, oth = om + M, oh = oth + M, odm = oh + M;
     static constexpr int orx = odm + M, oru = orx + 6 * (N + 1), ors = oru + 2 * N, orl = ors + 2 * N;
-    static constexpr int oPhi = orl + S, oMi = oPhi + 64 * N, ogam = oMi + 4 * N, ogup = ogam + 8 * N, opst = ogup + 2 * N, ok0 = opst + 8 * (N + 1);
+    static constexpr int oPhi = orl + S, oPiAll = oPhi + 64 * N, oMi = oPiAll + 64 * N, ogam = oMi + 4 * N, ogup = ogam + 8 * N,
+                         opst = ogup + 2 * N, ok0 = opst + 8 * (N + 1);
     static constexpr int okap = ok0 + 2 * N, orDs = okap + 2 * N, oeta = orDs + 2 * N, oe = oeta + 2 * N;
-    static constexpr int oPi = oe + 2 * N, oT1 = oPi + 64, oT2 = oT1 + 36, oMxx = oT2 + 12, oMxu = oMxx + 36, oMuu = oMxu + 12;
-    static constexpr int oQm = oMuu + 4, oRa = oQm + (S > 0 ? 7 * WAVE : 0), oRb = oRa + 49, oR = oRb + 49, oRi = oR + 49, orsq = oRi + 49, oct = orsq + WAVE;
-    static constexpr int oSS = oct + WAVE, oQsel = oSS + 6 * S, oy7 = oQsel + S, ow7 = oy7 + 8, oz7 = ow7 + 8, oPiT = oz7 + 8, osT = oPiT + 36;
+    static constexpr int oPi = oe + 2 * N, oT = oPi + 64, oMr = oT + 64;
+    static constexpr int oRi = oMr + 64, orsq = oRi + 56, oct = orsq + WAVE;
+    static constexpr int oSS = oct + WAVE, oQsel = oSS + 6 * S, oy7 = oQsel + S, oz7 = oy7 + 8, ow7 = oz7 + 8, oPiT = ow7 + 8, osT = oPiT + 36;
     static constexpr int opar = osT + 8, tot = opar + PAR_TOT;
 };
 
 #define FOR_LANES(idx, n) for (int idx = lane; idx < (n); idx += WAVE)
+
+// sum over the 8 lanes of a group (lane = 8 g + c, all lanes of the group receive it) / over the 8 groups (same c)
+__device__ __forceinline__ double sum_over_c(double v) {
+    v += dpp_mov<DPP_QP_X1>(v); v += dpp_mov<DPP_QP_X2>(v); v += dpp_mov<DPP_HALF_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ double sum_over_g(double v) {
+    v += dpp_mov<0x128>(v);                 // row_ror:8  (lane c <-> c+8 inside a row of 16)
+    double a, b;
+    swap16(v, a, b); v = a + b;
+    swap32(v, a, b); v = a + b;
+    return v;
+}
 
 template <int N, int S>
 __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
@@ -338,16 +352,17 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     const int b = blockIdx.x;
     if (b >= B) return;
     const int lane = threadIdx.x;
-    double *A = sm + LL::oA, *Bm = sm + LL::oB, *C = sm + LL::oC, *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
+    const int lg = lane >> 3, lc = lane & 7;                // lane = 8 g + c  (8 x 8 tile coordinates)
+    double *AB = sm + LL::oAB, *C = sm + LL::oC, *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
     double *dx = sm + LL::odx, *du = sm + LL::odu, *ds = sm + LL::ods, *dl = sm + LL::odl, *nu = sm + LL::onu, *dnu = sm + LL::odnu;
     double *m = sm + LL::om, *th = sm + LL::oth, *h = sm + LL::oh, *dm = sm + LL::odm;
     double *rx = sm + LL::orx, *ru = sm + LL::oru, *rs = sm + LL::ors, *rl = sm + LL::orl;
-    double *Phi = sm + LL::oPhi, *Mi = sm + LL::oMi, *gam = sm + LL::ogam, *gup = sm + LL::ogup, *pst = sm + LL::opst, *k0 = sm + LL::ok0;
-    double *phi = gam;                                     // gamma is dead once the backward sweep is done
+    double *Phi = sm + LL::oPhi, *PiAll = sm + LL::oPiAll, *Mi = sm + LL::oMi, *gam = sm + LL::ogam, *gup = sm + LL::ogup, *pst = sm + LL::opst, *k0 = sm + LL::ok0;
+    double *phi = gam;                                     // gamma is dead (kept in registers) once the backward sweep starts
     double *kap = sm + LL::okap, *rDs = sm + LL::orDs, *eta = sm + LL::oeta, *ee = sm + LL::oe;
-    double *Pi = sm + LL::oPi, *T1 = sm + LL::oT1, *T2 = sm + LL::oT2, *Mxx = sm + LL::oMxx, *Mxu = sm + LL::oMxu, *Muu = sm + LL::oMuu;
-    double *Qm = sm + LL::oQm, *Ra = sm + LL::oRa, *Rb = sm + LL::oRb, *Rm = sm + LL::oR, *Ri = sm + LL::oRi, *rsq = sm + LL::orsq, *ct = sm + LL::oct;
-    double *SS = sm + LL::oSS, *Qsel = sm + LL::oQsel, *y7 = sm + LL::oy7, *w7 = sm + LL::ow7, *z7 = sm + LL::oz7, *PiT = sm + LL::oPiT, *sT = sm + LL::osT;
+    double *Pi = sm + LL::oPi, *Tm = sm + LL::oT, *Mr = sm + LL::oMr;
+    double *Ri = sm + LL::oRi, *rsq = sm + LL::orsq, *ct = sm + LL::oct;
+    double *SS = sm + LL::oSS, *Qsel = sm + LL::oQsel, *y7 = sm + LL::oy7, *z7 = sm + LL::oz7, *w7 = sm + LL::ow7, *PiT = sm + LL::oPiT, *sT = sm + LL::osT;
     double *par = sm + LL::opar;
     const double *Fx = par + PAR_FX, *Fu = par + PAR_FU, *bx = par + PAR_BX, *bu = par + PAR_BU, *Q2 = par + PAR_Q2, *Qf2 = par + PAR_QF2,
                  *R2 = par + PAR_R2, *dR2 = par + PAR_DR2, *T2p = par + PAR_T2, *xRef = par + PAR_XREF;
@@ -446,18 +461,19 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     // LMPC.unpackSolution (:364-375); inequality rows in the reference's order (buildIneqConstr :166-198,
     // addSafeSetIneqConstr :340-343).  s_T is eliminated (s_T = SS lambda - x_N).
     // ------------------------------------------------------------------------------------------------
-    FOR_LANES(i, 36 * N) A[i] = io.A[(size_t)b * 36 * N + i];
-    FOR_LANES(i, 12 * N) Bm[i] = io.Bm[(size_t)b * 12 * N + i];
+    FOR_LANES(i, 36 * N) { const int k = i / 36, r = (i % 36) / 6, c = i % 6; AB[k * 48 + r * 8 + c] = io.A[(size_t)b * 36 * N + i]; }
+    FOR_LANES(i, 12 * N) { const int k = i / 12, r = (i % 12) >> 1, c = i & 1; AB[k * 48 + r * 8 + 6 + c] = io.Bm[(size_t)b * 12 * N + i]; }
     FOR_LANES(i, 6 * N) { C[i] = io.C[(size_t)b * 6 * N + i]; nu[i] = 0.0; }
     if (lane < 6) x[lane] = io.x0[(size_t)b * 6 + lane];
     FOR_LANES(i, 2 * N) u[i] = 0.0;
     const double uOld0 = io.uOld[(size_t)b * 2 + 0], uOld1 = io.uOld[(size_t)b * 2 + 1];
     __syncthreads();
+#pragma unroll 1
     for (int k = 0; k < N; k++) {                          // strictly interior start: u = 0, x by roll-out
         if (lane < 6) {
             double v = C[k * 6 + lane];
 #pragma unroll
-            for (int j = 0; j < 6; j++) v = fma(A[k * 36 + lane * 6 + j], x[k * 6 + j], v);
+            for (int j = 0; j < 6; j++) v = fma(AB[k * 48 + lane * 8 + j], x[k * 6 + j], v);
             x[(k + 1) * 6 + lane] = v;
         }
         __syncthreads();
@@ -494,6 +510,22 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         t_r[j] = 1.0; rt_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
         if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; m[r] = mu0 / tt; }
     }
+    // loop-invariant pieces of the stage Hessian W for this lane's (a, c) = (lg, lc) tile entry
+    const bool w_xx = lg < 6 && lc < 6, w_uu = lg >= 6 && lc >= 6;
+    const double wq2 = w_xx ? Q2[lg * 6 + lc] : 0.0;
+    const double wf0 = w_xx ? Fx[lg] * Fx[lc] : 0.0, wf1 = w_xx ? Fx[6 + lg] * Fx[6 + lc] : 0.0;
+    double wr2 = 0.0, wfu[4] = {0.0, 0.0, 0.0, 0.0};
+    if (w_uu) {
+        wr2 = R2[(lg - 6) * 2 + (lc - 6)] + (lg == lc ? dR2[lg - 6] : 0.0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) wfu[j] = Fu[j * 2 + (lg - 6)] * Fu[j * 2 + (lc - 6)];
+    }
+    double ph[N];                                          // Phi_k entry this lane multiplies with in the register sweeps
+    double mcol[7];                                        // this lane's column of M = [E D^-1/2 | T7^-1/2]
+#pragma unroll
+    for (int j = 0; j < 7; j++) mcol[j] = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; k++) ph[k] = 0.0;
     __syncthreads();
 
     // one Newton-system solve for the right-hand side currently in (rx,ru,rs,rl,h); result in dx,du,ds,dl
@@ -509,19 +541,18 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             for (int j = 0; j < 4; j++) v -= Fu[j * 2 + c] * h[2 * N + 4 * k + j];
             gup[i] = v;
         }
+        double c_t = 0.0;
         if constexpr (term) {
-            double c_ = 0.0;
-            if (lane < S) c_ = (rl[lane] + h[8 * N + lane]) * rsq[lane];
-            ct[lane] = c_;
+            if (lane < S) c_t = (rl[lane] + h[8 * N + lane]) * rsq[lane];
             double yy[7];
 #pragma unroll
-            for (int j = 0; j < 7; j++) yy[j] = wsum(Qm[j * WAVE + lane] * c_);
-            if (lane < 7) {
-                double v = yy[0];
+            for (int j = 0; j < 7; j++) yy[j] = wsum(mcol[j] * c_t);        // M c~
+            if (lane < 7) {                                                 // y7 = Ri' (M c~) ; sT <- Ri' d0 + y7 (scratch)
+                double v = 0.0;
 #pragma unroll
-                for (int j = 1; j < 7; j++) if (lane == j) v = yy[j];
+                for (int j = 0; j < 7; j++) if (j <= lane) v = fma(Ri[j * 7 + lane], yy[j], v);
                 y7[lane] = v;
-                sT[lane] = Ri[6 * 7 + lane] * (-re_sum) + v;        // (Ri' d0 + y7), d0 = (0,..,0,-re_sum); sT is scratch here
+                sT[lane] = Ri[6 * 7 + lane] * (-re_sum) + v;
             }
         }
         __syncthreads();
@@ -543,43 +574,55 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         }
         __syncthreads();
         TSTAMP(30);
-#pragma unroll 1
-        for (int k = N - 1; k >= 0; k--) {                      // backward sweep: p_k = Phi_k' p_{k+1} + gamma_k
-            if (lane < 8) {
-                double v = gam[k * 8 + lane];
+        {   // backward sweep p_k = Phi_k' p_{k+1} + gamma_k, entirely in registers:
+            // stage k odd : lanes hold p[c], multiply by Phi_k[c][g], sum over c -> p_k[g]
+            // stage k even: lanes hold p[g], multiply by Phi_k[g][c], sum over g -> p_k[c]
+            double gm[N];
 #pragma unroll
-                for (int j = 0; j < 8; j++) v = fma(Phi[k * 64 + j * 8 + lane], pst[(k + 1) * 8 + j], v);
-                pst[k * 8 + lane] = v;
+            for (int k = 0; k < N; k++) gm[k] = (k & 1) ? gam[k * 8 + lg] : gam[k * 8 + lc];
+            double pv = ((N - 1) & 1) ? pst[N * 8 + lc] : pst[N * 8 + lg];
+#pragma unroll
+            for (int k = N - 1; k >= 0; k--) {
+                double pr = ph[k] * pv;
+                if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; if (lc == 0) pst[k * 8 + lg] = pv; }
+                else { pr = sum_over_g(pr); pv = pr + gm[k]; if (lg == 0) pst[k * 8 + lc] = pv; }
             }
-            __syncthreads();
         }
+        __syncthreads();
         TSTAMP(31);
         FOR_LANES(i, 2 * N) {                                   // k0_k = Mi_k (gu' + B' p_x + p_u)
             const int k = i >> 1, c = i & 1;
             double w0 = gup[2 * k] + pst[(k + 1) * 8 + 6], w1 = gup[2 * k + 1] + pst[(k + 1) * 8 + 7];
 #pragma unroll
-            for (int j = 0; j < 6; j++) { w0 = fma(Bm[k * 12 + j * 2], pst[(k + 1) * 8 + j], w0); w1 = fma(Bm[k * 12 + j * 2 + 1], pst[(k + 1) * 8 + j], w1); }
+            for (int j = 0; j < 6; j++) { w0 = fma(AB[k * 48 + j * 8 + 6], pst[(k + 1) * 8 + j], w0); w1 = fma(AB[k * 48 + j * 8 + 7], pst[(k + 1) * 8 + j], w1); }
             k0[i] = Mi[k * 4 + c * 2] * w0 + Mi[k * 4 + c * 2 + 1] * w1;
         }
         __syncthreads();
         FOR_LANES(i, 8 * N) {                                   // phi_k = [-B k0 ; -k0]
             const int k = i >> 3, c = i & 7;
-            phi[i] = c < 6 ? -(Bm[k * 12 + c * 2] * k0[2 * k] + Bm[k * 12 + c * 2 + 1] * k0[2 * k + 1]) : -k0[2 * k + (c - 6)];
+            phi[i] = c < 6 ? -(AB[k * 48 + c * 8 + 6] * k0[2 * k] + AB[k * 48 + c * 8 + 7] * k0[2 * k + 1]) : -k0[2 * k + (c - 6)];
         }
         if (lane < 6) dx[lane] = 0.0;
         __syncthreads();
         TSTAMP(32);
-#pragma unroll 1
-        for (int k = 0; k < N; k++) {                           // forward sweep: xi_{k+1} = Phi_k xi_k + phi_k
-            if (lane < 8) {
-                double v = phi[k * 8 + lane];
+        {   // forward sweep xi_{k+1} = Phi_k xi_k + phi_k, xi_k = (dx_k, du_{k-1}), in registers:
+            // stage k even: lanes hold xi[c], multiply by Phi_k[g][c], sum over c -> xi'[g]
+            // stage k odd : lanes hold xi[g], multiply by Phi_k[c][g], sum over g -> xi'[c]
+            double fm[N];
 #pragma unroll
-                for (int j = 0; j < 6; j++) v = fma(Phi[k * 64 + lane * 8 + j], dx[k * 6 + j], v);
-                if (k > 0) { v = fma(Phi[k * 64 + lane * 8 + 6], du[(k - 1) * 2], v); v = fma(Phi[k * 64 + lane * 8 + 7], du[(k - 1) * 2 + 1], v); }
-                if (lane < 6) dx[(k + 1) * 6 + lane] = v; else du[k * 2 + (lane - 6)] = v;
+            for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
+            double xi = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                double pr = ph[k] * xi;
+                int idx;
+                if (k & 1) { pr = sum_over_g(pr); idx = lc; } else { pr = sum_over_c(pr); idx = lg; }
+                xi = pr + fm[k];
+                const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
+                if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
             }
-            __syncthreads();
         }
+        __syncthreads();
         TSTAMP(33);
         FOR_LANES(i, 2 * N) {
             const int k = i >> 1, j = i & 1; double f = 0.0;
@@ -588,15 +631,21 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             ds[i] = (th[i] * f + ee[i]) * rDs[i];
         }
         if constexpr (term) {
-            if (lane < 7) {                                     // z7 = Ri' d7, d7 = (dx_N ; -re_sum)
-                double v = 0.0;
+            if (lane < 7) {                                     // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum)
+                double v = y7[lane];
                 for (int j = 0; j <= lane; j++) v = fma(Ri[j * 7 + lane], j < 6 ? dx[N * 6 + j] : -re_sum, v);
-                z7[lane] = v + y7[lane];
+                z7[lane] = v;
             }
             __syncthreads();
-            double v = -ct[lane];
+            if (lane < 7) {                                     // omega' = Ri z7
+                double v = 0.0;
+                for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], z7[j], v);
+                w7[lane] = v;
+            }
+            __syncthreads();
+            double v = -c_t;                                    // v = -c~ + M' omega'
 #pragma unroll
-            for (int j = 0; j < 7; j++) v = fma(Qm[j * WAVE + lane], z7[j], v);
+            for (int j = 0; j < 7; j++) v = fma(mcol[j], w7[j], v);
             if (lane < S) dl[lane] = v * rsq[lane];
         }
         __syncthreads();
@@ -628,7 +677,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
                 if (k < N) {
                     v += Fx[c] * m[2 * k] + Fx[6 + c] * m[2 * k + 1];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) v -= A[k * 36 + j * 6 + c] * nu[k * 6 + j];
+                    for (int j = 0; j < 6; j++) v -= AB[k * 48 + j * 8 + c] * nu[k * 6 + j];
                 } else if (term) v -= T2p[c] * sT[c];
                 rmax = fmax(rmax, fabs(v));
             }
@@ -642,7 +691,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
 #pragma unroll
             for (int j = 0; j < 4; j++) v = fma(Fu[j * 2 + c], m[2 * N + 4 * k + j], v);
 #pragma unroll
-            for (int j = 0; j < 6; j++) v -= Bm[k * 12 + j * 2 + c] * nu[k * 6 + j];
+            for (int j = 0; j < 6; j++) v -= AB[k * 48 + j * 8 + 6 + c] * nu[k * 6 + j];
             ru[i] = v; rmax = fmax(rmax, fabs(v));
             const double vs = a_s * s[i] + c_s - m[i] - m[6 * N + i];
             rs[i] = vs; rmax = fmax(rmax, fabs(vs));
@@ -658,9 +707,9 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         }
         FOR_LANES(i, 6 * N) {                                    // dynamics residual (monitoring only)
             const int k = i / 6, c = i % 6;
-            double v = x[(k + 1) * 6 + c] - C[i] - Bm[k * 12 + c * 2] * u[k * 2] - Bm[k * 12 + c * 2 + 1] * u[k * 2 + 1];
+            double v = x[(k + 1) * 6 + c] - C[i] - AB[k * 48 + c * 8 + 6] * u[k * 2] - AB[k * 48 + c * 8 + 7] * u[k * 2 + 1];
 #pragma unroll
-            for (int j = 0; j < 6; j++) v -= A[k * 36 + c * 6 + j] * x[k * 6 + j];
+            for (int j = 0; j < 6; j++) v -= AB[k * 48 + c * 8 + j] * x[k * 6 + j];
             remax = fmax(remax, fabs(v));
         }
         gap = wsum(gsum) / (double)M;
@@ -675,146 +724,133 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         // ---- factorisation of the Newton (block-banded KKT) matrix -------------------------------------
 #pragma unroll
         for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) th[r] = m[r] * rt_r[j]; }
-        FOR_LANES(i, 64) Pi[i] = 0.0;
         __syncthreads();
         FOR_LANES(i, 2 * N) {
             const double d_ = 1.0 / (a_s + th[i] + th[6 * N + i]);
             rDs[i] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
         }
+        int numeric_bad = 0;
         if constexpr (term) {
-            // terminal block: M = [E D^-1/2 | T7^-1/2] (7 x (S+6)), M' = Q R by twice-applied MGS, one column of M per lane
-            double q[7];
+            // terminal block: M = [E D^-1/2 | T7^-1/2] (7 x (S+6)), one column per lane; W = M M' by wave reductions,
+            // R'R = W (Cholesky) and Ri = R^-1 in registers (uniform across lanes); all later uses apply Ri / Ri' in factored form
 #pragma unroll
-            for (int j = 0; j < 7; j++) q[j] = 0.0;
+            for (int j = 0; j < 7; j++) mcol[j] = 0.0;
             if (lane < S) {
                 const double rs_ = 1.0 / sqrt(th[8 * N + lane] + p.reg); rsq[lane] = rs_;
 #pragma unroll
-                for (int j = 0; j < 6; j++) q[j] = SS[j * S + lane] * rs_;
-                q[6] = rs_;
+                for (int j = 0; j < 6; j++) mcol[j] = SS[j * S + lane] * rs_;
+                mcol[6] = rs_;
             } else {
                 rsq[lane] = 1.0;
 #pragma unroll
-                for (int j = 0; j < 6; j++) if (lane - S == j) q[j] = 1.0 / sqrt(T2p[j]);
+                for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = 1.0 / sqrt(T2p[j]);
             }
+            double Rr[7][7], Rv[7][7], rinv[7];
 #pragma unroll
-            for (int pass = 0; pass < 2; pass++) {
-                double *Rp = pass == 0 ? Ra : Rb;
+            for (int i = 0; i < 7; i++)
 #pragma unroll
-                for (int i = 0; i < 7; i++) {
-                    const double n2 = wsum(q[i] * q[i]);
-                    const double nrm = sqrt(n2), rn = 1.0 / nrm;
-                    q[i] = q[i] * rn;
-                    if (lane == 0) Rp[i * 7 + i] = nrm;
+                for (int j = 0; j < 7; j++) { Rr[i][j] = 0.0; Rv[i][j] = 0.0; }
 #pragma unroll
-                    for (int j = 0; j < 7; j++) if (j > i) {
-                        const double rij = wsum(q[i] * q[j]);
-                        q[j] = fma(-rij, q[i], q[j]);
-                        if (lane == 0) { Rp[i * 7 + j] = rij; Rp[j * 7 + i] = 0.0; }
-                    }
+            for (int i = 0; i < 7; i++)
+#pragma unroll
+                for (int j = i; j < 7; j++) Rr[i][j] = wsum(mcol[i] * mcol[j]);          // W (upper)
+#pragma unroll
+            for (int i = 0; i < 7; i++) {                                                 // Cholesky, row by row
+                double d_ = Rr[i][i];
+#pragma unroll
+                for (int k = 0; k < i; k++) d_ = fma(-Rr[k][i], Rr[k][i], d_);
+                if (!(d_ > 0.0)) { numeric_bad = 1; d_ = 1.0; }
+                const double rii = sqrt(d_); rinv[i] = 1.0 / rii; Rr[i][i] = rii;
+#pragma unroll
+                for (int j = i + 1; j < 7; j++) {
+                    double v = Rr[i][j];
+#pragma unroll
+                    for (int k = 0; k < i; k++) v = fma(-Rr[k][i], Rr[k][j], v);
+                    Rr[i][j] = v * rinv[i];
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 7; j++) Qm[j * WAVE + lane] = q[j];
-            __syncthreads();
-            if (lane < 49) {                                     // R = Rb Ra (upper triangular)
-                const int i = lane / 7, j = lane % 7; double v = 0.0;
-                for (int k = i; k <= j; k++) v = fma(Rb[i * 7 + k], Ra[k * 7 + j], v);
-                Rm[lane] = v;
-            }
-            __syncthreads();
-            if (lane < 7) {                                      // Ri = R^-1, column `lane` by back substitution (through LDS)
-                const int j = lane;
-                for (int i = 6; i >= 0; i--) {
+            for (int j = 0; j < 7; j++) {                                                 // Ri = R^-1 (upper), column by column
+                Rv[j][j] = rinv[j];
+#pragma unroll
+                for (int i = j - 1; i >= 0; i--) {
                     double v = 0.0;
-                    if (i <= j) {
-                        v = (i == j) ? 1.0 : 0.0;
-                        for (int k = i + 1; k <= j; k++) v -= Rm[i * 7 + k] * Ri[k * 7 + j];
-                        v = v / Rm[i * 7 + i];
-                    }
-                    Ri[i * 7 + j] = v;
+#pragma unroll
+                    for (int k = i + 1; k <= j; k++) v = fma(-Rr[i][k], Rv[k][j], v);
+                    Rv[i][j] = v * rinv[i];
                 }
             }
-            __syncthreads();
-            if (lane < 36) {                                     // Pi_term = (Ri Ri')[0:6,0:6]
-                const int i = lane / 6, j = lane % 6; double v = 0.0;
-                for (int k = (i > j ? i : j); k < 7; k++) v = fma(Ri[i * 7 + k], Ri[j * 7 + k], v);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 7; i++)
+#pragma unroll
+                    for (int j = 0; j < 7; j++) Ri[i * 7 + j] = Rv[i][j];
+            }
+            if (lane < 36) {                                     // Pi_term = (Ri Ri')[0:6,0:6] straight from the registers
+                double v = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        double e_ = 0.0;
+#pragma unroll
+                        for (int k = (i > j ? i : j); k < 7; k++) e_ = fma(Rv[i][k], Rv[j][k], e_);
+                        if (lane == i * 6 + j) v = e_;
+                    }
                 PiT[lane] = v;
             }
             __syncthreads();
         }
         TSTAMP(12);
-        if (lane < 36) { const int i = lane / 6, j = lane % 6; Pi[i * 8 + j] = Qf2[lane] + (term ? PiT[lane] : 0.0); }
+        // Pi_N = [[2Qf + Pi_term, 0], [0, 0]]
+        { double v = 0.0; if (lg < 6 && lc < 6) v = Qf2[lg * 6 + lc] + (term ? PiT[lg * 6 + lc] : 0.0); Pi[lane] = v; }
         __syncthreads();
-        int numeric_bad = 0;
 #pragma unroll 1
         for (int k = N - 1; k >= 0; k--) {
-            const double *Ak = A + k * 36, *Bk = Bm + k * 12;
-            if (lane < 36) {                                     // T1 = Pxx A
-                const int i = lane / 6, j = lane % 6; double v = 0.0;
+            // augmented stage map [x'; u] = Ar [x; u], Ar = [[A, B], [0, I]] (8 x 8); all 64 lanes run the same code on tile entry (lg, lc)
+            const double *ABk = AB + k * 48;
+            {   // T = Pi Ar
+                double v = lc >= 6 ? Pi[lg * 8 + lc] : 0.0;
 #pragma unroll
-                for (int l = 0; l < 6; l++) v = fma(Pi[i * 8 + l], Ak[l * 6 + j], v);
-                T1[lane] = v;
-            } else if (lane < 48) {                              // T2 = Pxx B + Pxu
-                const int q = lane - 36, i = q >> 1, c = q & 1; double v = Pi[i * 8 + 6 + c];
-#pragma unroll
-                for (int l = 0; l < 6; l++) v = fma(Pi[i * 8 + l], Bk[l * 2 + c], v);
-                T2[q] = v;
+                for (int l = 0; l < 6; l++) v = fma(Pi[lg * 8 + l], ABk[l * 8 + lc], v);
+                Tm[lane] = v;
             }
             __syncthreads();
-            if (lane < 36) {                                     // Mxx = Hx + A' T1
-                const int i = lane / 6, j = lane % 6;
-                double v = Q2[lane] + kap[2 * k] * Fx[i] * Fx[j] + kap[2 * k + 1] * Fx[6 + i] * Fx[6 + j];
+            {   // Mr = Ar' T + W
+                double v = lg >= 6 ? Tm[lane] : 0.0;
 #pragma unroll
-                for (int l = 0; l < 6; l++) v = fma(Ak[l * 6 + i], T1[l * 6 + j], v);
-                Mxx[lane] = v;
-            } else if (lane < 48) {                              // Mxu = A' T2
-                const int q = lane - 36, i = q >> 1, c = q & 1; double v = 0.0;
+                for (int l = 0; l < 6; l++) v = fma(ABk[l * 8 + lg], Tm[l * 8 + lc], v);
+                const double wx = wq2 + kap[2 * k] * wf0 + kap[2 * k + 1] * wf1;
+                double wu = wr2;
 #pragma unroll
-                for (int l = 0; l < 6; l++) v = fma(Ak[l * 6 + i], T2[l * 2 + c], v);
-                Mxu[q] = v;
-            } else if (lane < 52) {                              // Muu = Hu + 2dR + B'T2 + Pxu'B + Puu
-                const int q = lane - 48, c = q >> 1, d = q & 1;
-                double v = R2[q] + (c == d ? dR2[c] : 0.0) + Pi[(6 + c) * 8 + 6 + d];
-#pragma unroll
-                for (int j = 0; j < 4; j++) v = fma(th[2 * N + 4 * k + j] * Fu[j * 2 + c], Fu[j * 2 + d], v);
-#pragma unroll
-                for (int l = 0; l < 6; l++) { v = fma(Bk[l * 2 + c], T2[l * 2 + d], v); v = fma(Pi[l * 8 + 6 + c], Bk[l * 2 + d], v); }
-                Muu[q] = v;
+                for (int j = 0; j < 4; j++) wu = fma(th[2 * N + 4 * k + j], wfu[j], wu);
+                v += w_xx ? wx : (w_uu ? wu : 0.0);
+                Mr[lane] = v;
             }
             __syncthreads();
-            // every lane inverts the 2x2 pivot and forms the rows of -K it needs (saves one LDS round trip per stage)
-            const double m00 = Muu[0], m01 = Muu[1], m10 = Muu[2], m11 = Muu[3];
-            const double det = m00 * m11 - m01 * m10;
-            if (!(det > 0.0) || !(m00 > 0.0)) numeric_bad = 1;
-            const double rdet = 1.0 / det;
-            const double i00 = m11 * rdet, i01 = -m01 * rdet, i10 = -m10 * rdet, i11 = m00 * rdet;
-            // F6[c] = -K[0][c], F7[c] = -K[1][c] for c = 0..7 (c < 6: -Kx, c >= 6: -Ku = Mi 2dR)
-            auto negK = [&](int row, int c) -> double {
-                const double a0 = row == 0 ? i00 : i10, a1 = row == 0 ? i01 : i11;
-                if (c < 6) return -(a0 * Mxu[c * 2] + a1 * Mxu[c * 2 + 1]);
-                return (c == 6 ? a0 : a1) * dR2[c - 6];
-            };
-            if (lane < 36) {                                     // Pxx_new = Mxx - Mxu Kx ; Acl = A - B Kx
-                const int i = lane / 6, j = lane % 6;
-                const double f6 = negK(0, j), f7 = negK(1, j);
-                Pi[i * 8 + j] = Mxx[lane] + Mxu[i * 2] * f6 + Mxu[i * 2 + 1] * f7;
-                Phi[k * 64 + i * 8 + j] = Ak[lane] + Bk[i * 2] * f6 + Bk[i * 2 + 1] * f7;
-            } else if (lane < 48) {                              // Pxu_new = -Mxu Ku ; Bcl = -B Ku
-                const int q = lane - 36, i = q >> 1, d = q & 1;
-                const double f6 = negK(0, 6 + d), f7 = negK(1, 6 + d);
-                const double v = Mxu[i * 2] * f6 + Mxu[i * 2 + 1] * f7;
-                Pi[i * 8 + 6 + d] = v; Pi[(6 + d) * 8 + i] = v;
-                Phi[k * 64 + i * 8 + 6 + d] = Bk[i * 2] * f6 + Bk[i * 2 + 1] * f7;
-            } else if (lane < 52) {                              // Puu_new = 2dR + 2dR Ku ; Mi
-                const int q = lane - 48, c = q >> 1, d = q & 1;
-                Pi[(6 + c) * 8 + 6 + d] = (c == d ? dR2[c] : 0.0) - dR2[c] * negK(c, 6 + d);
-                Mi[k * 4 + q] = c == 0 ? (d == 0 ? i00 : i01) : (d == 0 ? i10 : i11);
-            } else {                                             // Phi rows 6,7 = -K (lanes 52..63 write 16 entries)
-                for (int e = lane - 52; e < 16; e += 12) { const int row = e >> 3, c = e & 7; Phi[k * 64 + (6 + row) * 8 + c] = negK(row, c); }
+            {   // eliminate u_k: 2x2 pivot inverted by every lane; Pi_k, Phi_k tile entries
+                const double m00 = Mr[54], m01 = Mr[55], m10 = Mr[62], m11 = Mr[63];
+                const double det = m00 * m11 - m01 * m10;
+                if (!(det > 0.0) || !(m00 > 0.0)) numeric_bad = 1;
+                const double rdet = 1.0 / det;
+                const double i00 = m11 * rdet, i01 = -m01 * rdet, i10 = -m10 * rdet, i11 = m00 * rdet;
+                // K[d][lc]: gain column for this lane's column index
+                double K0, K1;
+                if (lc < 6) { const double a6 = Mr[48 + lc], a7 = Mr[56 + lc]; K0 = i00 * a6 + i01 * a7; K1 = i10 * a6 + i11 * a7; }
+                else { const double d2 = dR2[lc - 6]; K0 = -(lc == 6 ? i00 : i01) * d2; K1 = -(lc == 6 ? i10 : i11) * d2; }
+                double mau0, mau1, base, top, be0, be1;
+                if (lg < 6) { mau0 = Mr[lg * 8 + 6]; mau1 = Mr[lg * 8 + 7]; base = lc < 6 ? Mr[lane] : 0.0; top = lc < 6 ? ABk[lg * 8 + lc] : 0.0; be0 = ABk[lg * 8 + 6]; be1 = ABk[lg * 8 + 7]; }
+                else { const double d2 = dR2[lg - 6]; mau0 = lg == 6 ? -d2 : 0.0; mau1 = lg == 7 ? -d2 : 0.0; base = (lc == lg) ? d2 : 0.0; top = 0.0; be0 = lg == 6 ? 1.0 : 0.0; be1 = lg == 7 ? 1.0 : 0.0; }
+                const double pn = base - mau0 * K0 - mau1 * K1;
+                Pi[lane] = pn; PiAll[k * 64 + lane] = pn;
+                Phi[k * 64 + lane] = top - be0 * K0 - be1 * K1;
+                if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 1 ? i01 : (lane == 2 ? i10 : i11));
             }
             __syncthreads();
         }
         if (numeric_bad) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
+#pragma unroll
+        for (int k = 0; k < N; k++) ph[k] = (k & 1) ? Phi[k * 64 + lc * 8 + lg] : Phi[k * 64 + lg * 8 + lc];
 
         TSTAMP(13);
         // ---- predictor (affine scaling) direction: h = mu -------------------------------------------------
@@ -866,28 +902,27 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         amx = wmin(amx);
         const double al = fmin(1.0, 0.995 * amx);
         TSTAMP(17);
-        // ---- multipliers of the equality rows (costates), backwards ----------------------------------------
+        // ---- multipliers of the equality rows (costates): nu_k = -(Pi_k xi_k + p_k)_x, all stages at once ----
         if constexpr (term) {
             if (lane < 6) { double v = -dx[N * 6 + lane]; for (int c = 0; c < S; c++) v = fma(SS[lane * S + c], dl[c], v); w7[lane] = v; }   // d s_T
         }
         __syncthreads();
-        if (lane < 6) {
-            double g = rx[N * 6 + lane];
+        FOR_LANES(i, 6 * N) {
+            const int k = i / 6 + 1, c = i % 6;                  // multiplier of the row defining x_k, k = 1..N
+            double g;
+            if (k == N) {
+                g = rx[N * 6 + c];
 #pragma unroll
-            for (int j = 0; j < 6; j++) g = fma(Qf2[lane * 6 + j], dx[N * 6 + j], g);
-            if constexpr (term) g -= T2p[lane] * w7[lane];
-            dnu[(N - 1) * 6 + lane] = -g;
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int k = N - 1; k >= 1; k--) {
-            if (lane < 6) {
-                double g = rx[k * 6 + lane] + Fx[lane] * dm[2 * k] + Fx[6 + lane] * dm[2 * k + 1];
+                for (int j = 0; j < 6; j++) g = fma(Qf2[c * 6 + j], dx[N * 6 + j], g);
+                if constexpr (term) g -= T2p[c] * w7[c];
+            } else {
+                g = pst[k * 8 + c];
 #pragma unroll
-                for (int j = 0; j < 6; j++) { g = fma(Q2[lane * 6 + j], dx[k * 6 + j], g); g -= A[k * 36 + j * 6 + lane] * dnu[k * 6 + j]; }
-                dnu[(k - 1) * 6 + lane] = -g;
+                for (int j = 0; j < 6; j++) g = fma(PiAll[k * 64 + c * 8 + j], dx[k * 6 + j], g);
+                g = fma(PiAll[k * 64 + c * 8 + 6], du[(k - 1) * 2], g);
+                g = fma(PiAll[k * 64 + c * 8 + 7], du[(k - 1) * 2 + 1], g);
             }
-            __syncthreads();
+            dnu[i] = -g;
         }
         double deta = 0.0;
         if constexpr (term) {
@@ -897,6 +932,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
                 for (int j = 0; j < 6; j++) v -= SS[j * S + lane] * T2p[j] * w7[j]; }
             deta = wsum(v) / (double)S;
         }
+        __syncthreads();
         TSTAMP(18);
         // ---- step ------------------------------------------------------------------------------------------
         FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
