@@ -113,7 +113,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("LMPC_BENCH_FORCE_DIST") == "1":      # the env switch exercises the RCCL code path on one GPU
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)

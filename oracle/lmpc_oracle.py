@@ -575,7 +575,8 @@ class OracleModel:
 class OracleLMPC:
     """LMPC(MPC) with timeVarying=True, PredictiveControllers.py:286-514 + MPC.solve :110-137."""
 
-    def __init__(self, params, model, solver_kw=None):
+    def __init__(self, params, model, solver_kw=None, exact=False):
+        self.exact = exact
         self.p = params; self.N = params.N; self.model = model
         self.numSS_Points, self.numSS_it = params.numSS_Points, params.numSS_it
         self.OldInput = np.zeros(2)
@@ -617,7 +618,10 @@ class OracleLMPC:
         self.SS_PointSelectedTot, self.Qfun_SelectedTot = SSsel, Qsel
         P, q, A, l, u = assemble_lmpc_qp(p, self.A, self.B, self.C, x0, self.OldInput, SSsel, Qsel)
         self.qp = (P, q, A, l, u)
-        res = osqp_solve(P, q, A, l, u, polish=True, **self.solver_kw)
+        if self.exact:
+            res, self.cert = osqp_solve_exact(P, q, A, l, u)
+        else:
+            res = osqp_solve(P, q, A, l, u, polish=True, **self.solver_kw)
         self.res = res; self.feasible = 1 if res.status == 1 else 0
         sol = res.x
         n, d = 6, 2                              # unpackSolution :364-379

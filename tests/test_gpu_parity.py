@@ -142,3 +142,103 @@ def test_device_selftest(g):
     ctx, par = common.make_lmpc_ctx(g, 4, max_batch=1)
     ctx.selftest()
     ctx.close()
+
+
+class _Map:
+    """What the drop-in classes read from the reference's Map object."""
+    def __init__(self, g):
+        self.PointAndTangent = np.array(g["track"]); self.TrackLength = float(g["trackLength"]); self.halfWidth = 0.4
+
+
+def test_dropin_lmpc_closed_loop_matches_restated_reference(g):
+    """The drop-in LMPC class (reference constructor/solve/addPoint surface) against the oracle's restatement of the
+    reference state machine solved to the certified optimum, in lock-step over a closed loop with the restated plant.
+    Covers quirk E-2 (in-place edit of the stored lap at the first solve), zt wrap, xLin/uLin shift, OldInput, timeStep."""
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd.PredictiveControllers import LMPC, MPCParams
+    from racinglmpc_amd.PredictiveModel import PredictiveModel
+    N = 12
+    mp = _Map(g)
+    par = orc.QPParams.lmpc_default(N)
+    xA, uA = g["xPID"].copy(), g["uPID"].copy()
+    xB, uB = g["xPID"].copy(), g["uPID"].copy()
+    pm = PredictiveModel(6, 2, mp, 4)
+    for _ in range(4):
+        pm.addTrajectory(xA, uA)
+    params = MPCParams(n=6, d=2, N=N, Q=par.Q, R=par.R, dR=par.dR, Fx=par.Fx, bx=(np.array([[0.4], [0.4]]),), Fu=par.Fu,
+                       bu=np.array([[0.5], [0.5], [10.0], [10.0]]), slacks=True, Qslack=par.Qslack, timeVarying=True)
+    lmpc = LMPC(48, 4, par.QterminalSlack, params, pm)
+    om = orc.OracleModel(np.array(g["track"]), 4)
+    for _ in range(4):
+        om.addTrajectory(xB, uB)
+    ol = orc.OracleLMPC(par, om, exact=True)
+    for _ in range(4):
+        lmpc.addTrajectory(xA, uA, g["xPID_glob"]); ol.addTrajectory(xB, uB)
+    rs = np.random.RandomState(5)
+    x = np.array([0.5, 0, 0, 0, 0, 0.0]); xg = x.copy()
+    worst_u, worst_x, worst_zt = 0.0, 0.0, 0.0
+    for t in range(20):
+        lmpc.solve(x); ol.solve(x)
+        assert lmpc.feasible == 1
+        worst_u = max(worst_u, np.abs(lmpc.uPred - ol.uPred).max()); worst_x = max(worst_x, np.abs(lmpc.xPred - ol.xPred).max())
+        worst_zt = max(worst_zt, np.abs(lmpc.zt - ol.zt).max(), np.abs(lmpc.zt_u - ol.zt_u).max())
+        assert lmpc.uPred.shape == (N, 2) and lmpc.xPred.shape == (N + 1, 6) and lmpc.SS_PointSelectedTot.shape == (6, 48)
+        if t == 0:
+            assert xA[5, 5] == xB[5, 5] and xA[5, 5] < -19.0            # quirk E-2 reproduced on both sides
+            assert np.array_equal(lmpc.SS_PointSelectedTot, ol.SS_PointSelectedTot)
+        u = lmpc.uPred[0, :].copy()
+        lmpc.addPoint(x, u); ol.addPoint(x, u)
+        x, xg = orc.dyn_model(om.pt, x, xg, u, rs.randn)
+    print("drop-in closed loop: worst |du| %.2e |dx| %.2e |dzt| %.2e" % (worst_u, worst_x, worst_zt))
+    assert worst_u < 1e-5 and worst_x < 1e-5 and worst_zt < 1e-5
+    assert lmpc.timeStep == 20 and len(lmpc.xStoredPredTraj_it) == 20 and lmpc.SS[3].shape[0] == 1020
+    assert np.array_equal(lmpc.Qfun[3], ol.Qfun[3])
+
+
+def test_dropin_mpc_variants(built):
+    """MPC class: LTI (A, B given) and LTV (timeVarying) variants run and agree with the fixture's certified optimum."""
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd.PredictiveControllers import MPC, MPCParams
+    from racinglmpc_amd.PredictiveModel import PredictiveModel
+    gl = common.load_ltv_golden()
+    N = 12
+    mp = _Map(gl)
+    par = orc.QPParams.mpc_default(N, 0.8)
+    pm = PredictiveModel(6, 2, mp, 1)
+    pm.addTrajectory(gl["xPID"].copy(), gl["uPID"].copy())
+    params = MPCParams(n=6, d=2, N=N, Q=par.Q, R=par.R, Fx=par.Fx, bx=(np.array([[2.], [2.]]),), Fu=par.Fu, bu=np.array([[0.5], [0.5], [10.0], [10.0]]),
+                       xRef=par.xRef, slacks=True, Qslack=par.Qslack, timeVarying=True)
+    mpc = MPC(params, pm)
+    assert np.allclose(np.array(mpc.A), gl["A"][0], atol=1e-9)          # MPC.__init__ runs computeLTVdynamics (:88-91)
+    mpc.solve(gl["x0"][0])
+    w = np.concatenate([mpc.xPred.ravel(), mpc.uPred.ravel()])
+    assert np.abs(w - gl["sol_opt"][0][:102]).max() < common.TOL_XU
+    assert np.array_equal(mpc.zt, mpc.xPred[-1]) and np.array_equal(mpc.OldInput, mpc.uPred[0])
+    # LTI: A, B from the fixture's first stage, no model
+    p2 = MPCParams(n=6, d=2, N=N, A=gl["A"][0][0], B=gl["B"][0][0], Q=par.Q, R=par.R, Fx=par.Fx, bx=(np.array([[2.], [2.]]),), Fu=par.Fu,
+                   bu=np.array([[0.5], [0.5], [10.0], [10.0]]), xRef=par.xRef, slacks=True, Qslack=par.Qslack)
+    lti = MPC(p2)
+    lti.solve(gl["x0"][0])
+    P, q, A, l, u = orc.assemble_mpc_qp(par, gl["A"][0][0], gl["B"][0][0], None, gl["x0"][0], np.zeros(2))
+    ex, cert = orc.osqp_solve_exact(P, q, A, l, u)
+    assert np.abs(np.concatenate([lti.xPred.ravel(), lti.uPred.ravel()]) - ex.x[:102]).max() < common.TOL_XU
+
+
+def test_batched_rollouts_full_lap_and_exchange(g):
+    """B closed-loop LMPC cars against the 4x PID safe set complete a lap; the per-lap exchange (world = 1 here) feeds the
+    K fastest laps back into both stores and the next lap is no slower than the PID seed lap."""
+    from racinglmpc_amd import rollout
+    ctx, par = common.make_lmpc_ctx(g, 4, max_batch=16)
+    ro = rollout.BatchedRollouts(ctx, g["track"], seed=3)
+    B = 16
+    x0 = np.tile(np.array([0.5, 0, 0, 0, 0, 0.0]), (B, 1)); x0[:, 5] = np.linspace(-0.05, 0.05, B)
+    xLin0 = g["SS0"][1:14]; uLin0 = g["uSS0"][1:13]
+    best = rollout.lap_and_exchange(ro, x0, xLin0, uLin0, K=4, T_max=400)
+    assert len(best) == 4
+    Ts = [b[4] for b in best]
+    print("rollout lap lengths (best 4 of %d):" % B, Ts)
+    assert all(100 < T < 400 for T in Ts)
+    for x, u, xg, src, T in best:
+        assert x[-1, 4] <= float(g["trackLength"]) + 1.0 and np.abs(x[:, 5]).max() < 0.6        # stayed on (soft-constrained) track
+        assert np.abs(u[:, 0]).max() <= 0.5 + 1e-9 and np.abs(u[:, 1]).max() <= 10 + 1e-9       # hard input bounds respected
+    ctx.close()
