@@ -342,6 +342,19 @@ __device__ __forceinline__ double sum_over_g(double v) {
     return v;
 }
 
+
+// r[j] = sum_c SS[j][c] v[c] - sub[j] for j < 6, using lanes (j, part) = (lane>>3, lane&7): S/8 terms each + group reduction
+template <int S> __device__ __forceinline__ void ss_times(const double *SS, const double *v, const double *sub, double *out, int lane) {
+    const int j = lane >> 3, part = lane & 7;
+    double acc = 0.0;
+    if (j < 6) {
+#pragma unroll
+        for (int c = part; c < S; c += 8) acc = fma(SS[j * S + c], v[c], acc);
+    }
+    acc = sum_over_c(acc);
+    if (j < 6 && part == 0) out[j] = acc - sub[j];
+}
+
 template <int N, int S>
 __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
     extern __shared__ double sm[];
@@ -651,8 +664,9 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         __syncthreads();
     };
 
-    int it = 0, converged = 0;
-    double gap = 0.0, rdn = 0.0, ren = 0.0;
+    int it = 0, converged = 0, sep = 0;                   // sep: separate primal/dual step lengths after a poor-progress iteration
+    double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0;
+    const double qscale = fmax(1.0, qmax);                // dual residual tolerance is relative to the cost scale
 #pragma unroll 1
     for (it = 0; it <= p.max_iter; it++) {
         TSTAMP(10);
@@ -664,7 +678,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; rt_r[j] = 1.0 / tt; gsum = fma(tt, m[r], gsum); }
         }
         if constexpr (term) {
-            if (lane < 6) { double v = -x[N * 6 + lane]; for (int c = 0; c < S; c++) v = fma(SS[lane * S + c], lam[c], v); sT[lane] = v; }
+            ss_times<S>(SS, lam, x + N * 6, sT, lane);
             __syncthreads();
         }
         FOR_LANES(i, 6 * (N + 1)) {
@@ -716,7 +730,9 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         rdn = wmax(rmax);
         const double re_sum = term ? wsum(lsum) - 1.0 : 0.0;
         ren = fmax(wmax(remax), fabs(re_sum));
-        if (gap < p.tol_gap && rdn < p.tol_res && ren < p.tol_res) { converged = 1; break; }
+        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res) { converged = 1; break; }
+        if (gap_prev >= 0.0) sep = gap > 0.3 * gap_prev;
+        gap_prev = gap;
         if (it == p.max_iter) break;
         if (!(gap == gap) || !(rdn == rdn)) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
 
@@ -786,17 +802,10 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
 #pragma unroll
                     for (int j = 0; j < 7; j++) Ri[i * 7 + j] = Rv[i][j];
             }
-            if (lane < 36) {                                     // Pi_term = (Ri Ri')[0:6,0:6] straight from the registers
-                double v = 0.0;
-#pragma unroll
-                for (int i = 0; i < 6; i++)
-#pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        double e_ = 0.0;
-#pragma unroll
-                        for (int k = (i > j ? i : j); k < 7; k++) e_ = fma(Rv[i][k], Rv[j][k], e_);
-                        if (lane == i * 6 + j) v = e_;
-                    }
+            __syncthreads();
+            if (lane < 36) {                                     // Pi_term = (Ri Ri')[0:6,0:6]
+                const int i = lane / 6, j = lane % 6; double v = 0.0;
+                for (int k = (i > j ? i : j); k < 7; k++) v = fma(Ri[i * 7 + k], Ri[j * 7 + k], v);
                 PiT[lane] = v;
             }
             __syncthreads();
@@ -858,7 +867,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         __syncthreads();
         kkt_solve(re_sum);
         TSTAMP(14);
-        double amax = 1.0, dma_r[RPL];
+        double apmax = 1.0, admax = 1.0, dma_r[RPL];        // separate primal / dual step lengths (equal steps can stall)
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
             const int r = lane + WAVE * j; dma_r[j] = 0.0;
@@ -866,28 +875,30 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
                 const double dta = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dma = -mr - th[r] * dta;
                 dt_r[j] = dta; dma_r[j] = dma;
-                if (dta < 0.0) amax = fmin(amax, -t_r[j] / dta);
-                if (dma < 0.0) amax = fmin(amax, -mr / dma);
+                if (dta < 0.0) apmax = fmin(apmax, -t_r[j] / dta);
+                if (dma < 0.0) admax = fmin(admax, -mr / dma);
             }
         }
-        amax = wmin(amax);
+        apmax = wmin(apmax); admax = wmin(admax);
+        if (!sep) { apmax = fmin(apmax, admax); admax = apmax; }
         double gaff = 0.0;
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
             const int r = lane + WAVE * j;
-            if (r < M) { gaff = fma(t_r[j] + amax * dt_r[j], m[r] + amax * dma_r[j], gaff); tp_r[j] = dt_r[j] * dma_r[j]; }
+            if (r < M) { gaff = fma(t_r[j] + apmax * dt_r[j], m[r] + admax * dma_r[j], gaff); tp_r[j] = dt_r[j] * dma_r[j]; }
         }
         gaff = wsum(gaff) / (double)M;
         double sig = gaff / gap; sig = sig * sig * sig;
+        const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);   // keep the complementarity products off the rounding floor
         // ---- corrector: h = (t mu - sigma gap + dt_aff dmu_aff) / t ----------------------------------------
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) h[r] = m[r] + (tp_r[j] - sig * gap) * rt_r[j]; }
+        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) h[r] = m[r] + (tp_r[j] - tgt) * rt_r[j]; }
         __syncthreads();
         TSTAMP(15);
         kkt_solve(re_sum);
         TSTAMP(16);
-        double amx = INFINITY;
+        double apx = INFINITY, adx = INFINITY;
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
             const int r = lane + WAVE * j;
@@ -895,16 +906,17 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
                 const double dtt = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dmm = -h[r] - th[r] * dtt;
                 dm[r] = dmm;
-                if (dtt < 0.0) amx = fmin(amx, -t_r[j] / dtt);
-                if (dmm < 0.0) amx = fmin(amx, -mr / dmm);
+                if (dtt < 0.0) apx = fmin(apx, -t_r[j] / dtt);
+                if (dmm < 0.0) adx = fmin(adx, -mr / dmm);
             }
         }
-        amx = wmin(amx);
-        const double al = fmin(1.0, 0.995 * amx);
+        apx = wmin(apx); adx = wmin(adx);
+        double al = fmin(1.0, 0.995 * apx), ald = fmin(1.0, 0.995 * adx);
+        if (!sep) { al = fmin(al, ald); ald = al; }
         TSTAMP(17);
         // ---- multipliers of the equality rows (costates): nu_k = -(Pi_k xi_k + p_k)_x, all stages at once ----
         if constexpr (term) {
-            if (lane < 6) { double v = -dx[N * 6 + lane]; for (int c = 0; c < S; c++) v = fma(SS[lane * S + c], dl[c], v); w7[lane] = v; }   // d s_T
+            ss_times<S>(SS, dl, dx + N * 6, w7, lane);                                                // d s_T
         }
         __syncthreads();
         FOR_LANES(i, 6 * N) {
@@ -938,9 +950,9 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
         FOR_LANES(i, 2 * N) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
         if constexpr (term) { FOR_LANES(c, S) lam[c] = fma(al, dl[c], lam[c]); }
-        FOR_LANES(r, M) m[r] = fma(al, dm[r], m[r]);
-        FOR_LANES(i, 6 * N) nu[i] = fma(al, dnu[i], nu[i]);
-        eta_m = fma(al, deta, eta_m);
+        FOR_LANES(r, M) m[r] = fma(ald, dm[r], m[r]);
+        FOR_LANES(i, 6 * N) nu[i] = fma(ald, dnu[i], nu[i]);
+        eta_m = fma(ald, deta, eta_m);
         __syncthreads();
     }
     TSTAMP(20);

@@ -150,9 +150,14 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=Fa
     m_lane, m_u, m_s, m_l = mu0 / t_lane, mu0 / t_u, mu0 / t_s, (mu0 / t_l if qp.term else np.zeros(0))
     mtot = 8 * N + S
     info = {}
+    sep = False; gap_prev = None          # separate primal/dual steps only after an iteration with poor progress
+    qscale = max(1.0, float(np.max(np.abs(qp.Qsel)))) if qp.term else 1.0
     for it in range(maxit):
         t_lane, t_u, t_s, t_l = slacks()
         gap = (t_lane.ravel() @ m_lane.ravel() + t_u.ravel() @ m_u.ravel() + t_s.ravel() @ m_s.ravel() + t_l @ m_l) / mtot
+        if gap_prev is not None:
+            sep = gap > 0.3 * gap_prev
+        gap_prev = gap
         # ---- residuals
         sT = qp.SS @ lam - x[N] if qp.term else None
         rx = np.zeros((N + 1, 6))
@@ -174,7 +179,7 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=Fa
         if verbose:
             print("it %2d gap %.2e rd %.2e re %.2e" % (it, gap, rd, re))
         info = dict(iters=it, gap=gap, rd=rd, re=re)
-        if gap < tol_gap and rd < tol_res and re < tol_res:
+        if gap < tol_gap and rd < tol_res * qscale and re < tol_res:
             break
         th_lane, th_u, th_s, th_l = m_lane / t_lane, m_u / t_u, m_s / t_s, (m_l / t_l if qp.term else np.zeros(0))
         f = kkt_factor(qp, th_lane, th_u, th_s, th_l, reg_l)
@@ -196,15 +201,20 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=Fa
                 if neg.any():
                     al = min(al, np.min(-v[neg] / dv[neg]))
             return al
-        aa = min(1.0, maxstep(ts, dt), maxstep(ms, dma))
-        gap_aff = sum(((t + aa * d).ravel() @ (m + aa * dm).ravel()) for t, d, m, dm in zip(ts, dt, ms, dma)) / mtot
+        aap = min(1.0, maxstep(ts, dt)); aad = min(1.0, maxstep(ms, dma))
+        if not sep:
+            aap = aad = min(aap, aad)
+        gap_aff = sum(((t + aap * d).ravel() @ (m + aad * dm).ravel()) for t, d, m, dm in zip(ts, dt, ms, dma)) / mtot
         sig = (gap_aff / gap) ** 3
-        rc = [t * m - sig * gap + d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]
+        tgt = max(sig * gap, 0.01 * tol_gap)          # keep the complementarity products off the rounding floor
+        rc = [t * m - tgt + d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]
         hs = [r / t for r, t in zip(rc, ts)]
         dx, du, ds, dl = solve(*hs)
         dt = ineq_steps(dx, du, ds, dl)
         dm = [(-r - m * d) / t for r, m, d, t in zip(rc, ms, dt, ts)]
-        al = min(1.0, 0.995 * min(maxstep(ts, dt), maxstep(ms, dm)))
+        al = min(1.0, 0.995 * maxstep(ts, dt)); ald = min(1.0, 0.995 * maxstep(ms, dm))
+        if not sep:
+            al = ald = min(al, ald)
         # costates (delta): dnu_N from terminal, then backwards
         dnu = np.zeros((N, 6))
         # dnu_N (row x_N): stationarity of the Newton system in x_N
@@ -224,8 +234,8 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=Fa
         x += al * dx; u += al * du; s += al * ds
         if qp.term:
             lam += al * dl
-        m_lane, m_u, m_s, m_l = [m + al * d for m, d in zip(ms, dm)]
-        nu += al * dnu; eta_m += al * deta
+        m_lane, m_u, m_s, m_l = [m + ald * d for m, d in zip(ms, dm)]
+        nu += ald * dnu; eta_m += ald * deta
     out = dict(x=x, u=u, s=s, lam=lam, sT=(qp.SS @ lam - x[N]) if qp.term else None,
                mu=np.concatenate([m_lane.ravel(), m_u.ravel(), m_s.ravel(), m_l]), nu=nu, eta=eta_m)
     out.update(info)

@@ -1,0 +1,141 @@
+"""-m gpu: the other BASELINE.json configurations as parity cases -- batch=4096 with a 30-lap safe set, long horizon
+N=40, reference default N=14 -- through sampled oracle comparisons and size-independent properties on the full batch."""
+import numpy as np
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def pid_laps_batched(track, n_laps, max_steps=600):
+    """30 single-lap PID trajectories, lap i at target speed 0.6 + 0.02 i, integrated with the vectorised plant
+    (racinglmpc_amd.rollout.plant_step restates SysModel.dynModel); control law = Utilities.PID.solve."""
+    from racinglmpc_amd import rollout
+    TL = float(track[-1, 3] + track[-1, 4])
+    rng = np.random.default_rng(77)
+    vt = 0.6 + 0.02 * np.arange(n_laps)
+    x = np.tile(np.array([0.5, 0, 0, 0, 0, 0.0]), (n_laps, 1)); xg = x.copy()
+    X, U = [], []
+    done = -np.ones(n_laps, int)
+    for t in range(max_steps):
+        u = np.stack([-0.6 * x[:, 5] - 0.9 * x[:, 3] + np.clip(rng.standard_normal(n_laps) * 0.25, -0.9, 0.9),
+                      1.5 * (vt - x[:, 0]) + np.clip(rng.standard_normal(n_laps) * 0.10, -0.2, 0.2)], axis=1)
+        X.append(x.copy()); U.append(u)
+        x, xg = rollout.plant_step(track, x, xg, u, rng.standard_normal((n_laps, 3)))
+        done[(done < 0) & (x[:, 4] > TL)] = t + 1
+        if np.all(done > 0):
+            break
+    X = np.stack(X, 1); U = np.stack(U, 1)
+    # keep some rows past the finish line so that safe-set windows near the end of a lap stay inside the data
+    return [(X[i, :min(done[i] + 20, X.shape[1])], U[i, :min(done[i] + 20, X.shape[1])]) for i in range(n_laps)]
+
+
+def oracle_step(par, pt, TL, laps_model, laps_ss, N, x0, xLin, uLin, uOld, zt, tstep):
+    from oracle import lmpc_oracle as orc
+    xS = [l[0] for l in laps_model]; uS = [l[1] for l in laps_model]
+    A, B, C = orc.compute_ltv_dynamics(xS, uS, list(range(4)), pt, xLin, uLin, N)
+    SS = [l[0] for l in laps_ss]; uSS = [l[1] for l in laps_ss]
+    Qf = [orc.compute_cost(l[0], TL) for l in laps_ss]
+    z = zt.copy()
+    if z[4] - x0[4] > TL / 2:
+        z[4] = np.max([z[4] - TL, 0])
+    SSsel, Qsel, Succ, SuccU = orc.terminal_components(SS, uSS, Qf, [l[0].shape[0] for l in laps_ss], z, 48, 4, None, len(laps_ss), tstep, N, TL)
+    P, q, Ao, l, u = orc.assemble_lmpc_qp(par, A, B, C, x0, uOld, SSsel, Qsel)
+    ex, cert = orc.osqp_solve_exact(P, q, Ao, l, u, want=1e-8)
+    return A, B, C, SSsel, ex.x, cert, (P, q, Ao, l, u)
+
+
+def feasibility_properties(out, inp, par, N, TLtol=1e-7):
+    """Size-independent properties of every solution in a batch."""
+    x, u, s, lam = out["xPred"], out["uPred"], out["slack"], out["lambd"]
+    B = x.shape[0]
+    A, Bm, C = out["A"], out["B"], out["C"]
+    dyn = np.einsum("bkij,bkj->bki", A, x[:, :-1]) + np.einsum("bkij,bkj->bki", Bm, u) + C - x[:, 1:]
+    assert np.abs(dyn).max() < 1e-8
+    assert np.abs(x[:, 0] - inp["x0"]).max() == 0.0
+    assert np.all(np.abs(u[:, :, 0]) <= 0.5 + TLtol) and np.all(np.abs(u[:, :, 1]) <= 10 + TLtol)
+    assert np.all(s >= -TLtol) and np.all(lam >= -TLtol) and np.abs(lam.sum(1) - 1).max() < 1e-8
+    ey = x[:, :N, 5]
+    assert np.all(ey - s[:, 0::2] <= 0.4 + TLtol) and np.all(-ey - s[:, 1::2] <= 0.4 + TLtol)
+    sT = np.einsum("bcj,bc->bj", out["ssSel"], lam) - x[:, N]
+    assert np.abs(sT - out["sTerm"]).max() < 1e-9
+
+
+def test_batch4096_safe_set_from_30_laps(built):
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    g = common.load_lmpc_golden()
+    N, B = 12, 4096
+    track = np.array(g["track"]); TL = float(g["trackLength"])
+    laps = pid_laps_batched(track, 30)
+    cfg, par = common.lmpc_config(g, N, max_batch=B, max_laps=40, max_lap_len=1024)
+    ctx = _capi.Context(cfg)
+    for x, u in laps:
+        ctx.model_add_trajectory(x, u); ctx.ss_add_trajectory(x, u)
+    order = sorted(range(30), key=lambda i: (laps[i][0].shape[0], i))          # both stores use the 4 fastest (shortest) laps
+    xq, uq = laps[29]
+    Tq = xq.shape[0] - 40
+    tb = (37 * np.arange(B)) % (Tq - N - 2)
+    rng = np.random.default_rng(1234)
+    inp = dict(x0=xq[tb] + rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02]),
+               xLin=np.stack([xq[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uq[t + 1:t + N + 1] for t in tb]),
+               uOld=uq[tb].copy(), zt=xq[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    assert np.all(out["status"] == 0), np.unique(out["status"], return_counts=True)
+    print("B=4096/30 laps: IPM iterations mean %.2f max %d" % (out["iters"].mean(), out["iters"].max()))
+    feasibility_properties(out, inp, par, N)
+    # batch-order independence: a permuted batch gives bitwise identical per-problem answers
+    perm = rng.permutation(B)[:512]
+    out2 = ctx.step_batch(inp["x0"][perm], inp["xLin"][perm], inp["uLin"][perm], inp["uOld"][perm], zt=inp["zt"][perm], timeStep=inp["timeStep"][perm])
+    assert np.array_equal(out2["xPred"], out["xPred"][perm]) and np.array_equal(out2["uPred"], out["uPred"][perm])
+    # sampled comparison with the oracle (stores in the library's order: model sorted ascending, safe set = argsort(LapTime))
+    model_sorted = [laps[i] for i in order]
+    ss_sel = [laps[i] for i in order]
+    worst = 0.0
+    for b in (0, 1, 777, 2048, 4095):
+        A, Bm, C, SSsel, opt, cert, _ = oracle_step(par, track, TL, model_sorted[:4], ss_sel[:4], N, inp["x0"][b], inp["xLin"][b], inp["uLin"][b],
+                                                    inp["uOld"][b], inp["zt"][b], int(inp["timeStep"][b]))
+        assert (np.abs(out["A"][b] - A) / (1 + np.abs(A))).max() < common.TOL_ABC
+        assert np.array_equal(out["ssSel"][b], SSsel.T)
+        worst = max(worst, np.abs(np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()]) - opt[:102]).max())
+    print("B=4096/30 laps: worst |xu - opt| on the sample %.2e" % worst)
+    assert worst < common.TOL_XU
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,B", [(40, 1024), (14, 256)])
+def test_other_horizons(built, N, B):
+    """BASELINE config 'long-horizon N=40 LMPC, batch=1024' and the reference's own N=14 (main.py:43)."""
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    g = common.load_lmpc_golden()
+    track = np.array(g["track"]); TL = float(g["trackLength"])
+    cfg, _ = common.lmpc_config(g, N, max_batch=B)
+    par = orc.QPParams.lmpc_default(N)
+    ctx = _capi.Context(cfg)
+    xP, uP = g["xPID"], g["uPID"]
+    for _ in range(4):
+        ctx.model_add_trajectory(xP, uP); ctx.ss_add_trajectory(xP, uP)
+    tb = (37 * np.arange(B)) % 900
+    rng = np.random.default_rng(1234)
+    inp = dict(x0=xP[tb] + rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02]),
+               xLin=np.stack([xP[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uP[t + 1:t + N + 1] for t in tb]),
+               uOld=uP[tb].copy(), zt=xP[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    assert np.all(out["status"] == 0), np.unique(out["status"], return_counts=True)
+    feasibility_properties(out, inp, par, N)
+    worst = 0.0
+    for b in (0, 5, B - 1):
+        A, Bm, C, SSsel, opt, cert, qp = oracle_step(par, track, TL, [(xP, uP)] * 4, [(xP, uP)] * 4, N, inp["x0"][b], inp["xLin"][b], inp["uLin"][b],
+                                                     inp["uOld"][b], inp["zt"][b], int(inp["timeStep"][b]))
+        assert (np.abs(out["A"][b] - A) / (1 + np.abs(A))).max() < common.TOL_ABC
+        assert np.array_equal(out["ssSel"][b], SSsel.T)
+        w = np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()])
+        worst = max(worst, np.abs(w - opt[:8 * N + 6]).max())
+        obj = lambda z: 0.5 * z @ qp[0] @ z + qp[1] @ z
+        full = np.concatenate([w, out["slack"][b], out["lambd"][b], out["sTerm"][b]])
+        assert abs(obj(full) - obj(opt)) <= 1e-7 * (1 + abs(obj(opt)))
+    print("N=%d B=%d: iterations mean %.2f max %d, worst |xu - opt| %.2e" % (N, B, out["iters"].mean(), out["iters"].max(), worst))
+    assert worst < common.TOL_XU
+    ctx.close()
