@@ -73,17 +73,20 @@ def device_args(ctx, inp, B, N, S):
     return a, keep
 
 
-def cpu_baseline(g, inp, N, nsample, budget_s=25.0):
-    """Reference-algorithm port (oracle/: NumPy regression/selection/assembly + restated OSQP, default settings with
-    polish -- what main.py does per step), single core, on the first `nsample` problems of the same batch."""
+def _cpu_worker(args):
+    """Full reference-algorithm step for problems [lo, hi) of the batch on one core (oracle port)."""
+    lo, hi, N = args
     from oracle import lmpc_oracle as orc
+    from tests import common
+    g = common.load_lmpc_golden()
+    inp = synth_batch(g, _CPU_B, N, seed=1234)
     par = orc.QPParams.lmpc_default(N)
     pt, TL = g["track"], float(g["trackLength"])
     xS = [g["xPID"]] * 4; uS = [g["uPID"]] * 4
     Qf = [orc.compute_cost(g["xPID"], TL)] * 4
-    done = 0
     t0 = time.perf_counter()
-    for b in range(nsample):
+    for i in range(lo, hi):
+        b = i % _CPU_B
         A, Bm, C = orc.compute_ltv_dynamics(xS, uS, [0, 1, 2, 3], pt, inp["xLin"][b], inp["uLin"][b], N)
         zt = inp["zt"][b].copy()
         if zt[4] - inp["x0"][b][4] > TL / 2:
@@ -91,12 +94,37 @@ def cpu_baseline(g, inp, N, nsample, budget_s=25.0):
         SSsel, Qsel, Succ, SuccU = orc.terminal_components(xS, uS, Qf, [1000] * 4, zt, 48, 4, None, 4, int(inp["timeStep"][b]), N, TL)
         P, q, Ao, l, u = orc.assemble_lmpc_qp(par, A, Bm, C, inp["x0"][b], inp["uOld"][b], SSsel, Qsel)
         orc.osqp_solve(P, q, Ao, l, u, polish=True)
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=done / dt, unit="solves/s", cores=1, kind="port",
-                sample="first %d problems of the bench batch, full step (NumPy regression+selection+assembly, restated OSQP eps=1e-3+polish), %.1f s" % (done, dt))
+    return hi - lo, time.perf_counter() - t0
+
+
+_CPU_B = 256
+
+
+def cpu_baseline(N, B, per_core=None, seconds=4.0):
+    """The reference's algorithm for this path as restated in oracle/ (NumPy regression + selection + assembly, restated
+    OSQP at the reference's settings eps=1e-3 + polish -- what main.py does per step), timed on the host cores of this
+    box: first on ONE core (the reference itself is single-threaded), then on all cores (one process per core, the same
+    batch split in contiguous chunks, `per_core` problems each)."""
+    import multiprocessing as mp
+    global _CPU_B
+    _CPU_B = B
+    os.environ.setdefault("OMP_NUM_THREADS", "1"); os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+    n1, t1 = _cpu_worker((0, min(B, 64), N))
+    one = n1 / t1
+    cores = os.cpu_count() or 1
+    if per_core is None:
+        per_core = max(8, int(seconds * one))          # about `seconds` of work per core
+    chunks = [(i * per_core, (i + 1) * per_core, N) for i in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, chunks)
+    wall = time.perf_counter() - t0
+    done = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)
+    return dict(value=done / busy, unit="solves/s", cores=cores, kind="port",
+                sample="%d problems of the bench batch (cyclic), %d per core on %d processes, full step a3-a19 with restated OSQP eps=1e-3+polish; "
+                       "slowest worker %.1f s (pool wall %.1f s incl. fork/imports)" % (done, per_core, cores, busy, wall),
+                single_core={"value": one, "unit": "solves/s", "cores": 1, "sample": "first %d problems, %.1f s" % (n1, t1)})
 
 
 def main():
@@ -107,7 +135,6 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="QPs per GPU per step (BASELINE configs[1]: 256)")
     ap.add_argument("--horizon", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=256)
     ap.add_argument("--sweep", action="store_true", help="also report solves/s for batch 1..8192 (extra key 'sweep')")
     args = ap.parse_args()
 
@@ -181,6 +208,7 @@ def main():
                        "solver": "Riccati-structured primal-dual interior point to certified optimum (gap<1e-11, res<1e-9)"},
             "solved_ok": n_ok, "ipm_iters_mean": float(iters.mean()), "ipm_iters_max": int(iters.max()),
             "kernel_ms": {"lmpc_solve_kernel": ms_solve, "lmpc_regress_kernel": ms_reg},
+            "solver_only_solves_per_s": B / (ms_solve * 1e-3), "regression_only_solves_per_s": B / (ms_reg * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "lmpc_solve_kernel", "algorithmic_bytes_per_launch": B * bytes_per_solve,
                          "note": "latency/FP64-issue bound path: compulsory HBM traffic is 2.46 KB per solve (SURVEY 8(d)); see DESIGN.md"},
@@ -202,8 +230,7 @@ def main():
                 c2.close()
             out["sweep_solves_per_s"] = sweep
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(g, inp, N, min(args.cpu_sample, B))
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            out["cpu_baseline"] = cpu_baseline(N, B)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
     for p in keep:
