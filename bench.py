@@ -74,19 +74,25 @@ def device_args(ctx, inp, B, N, S):
 
 
 def _cpu_worker(args):
-    """Full reference-algorithm step for problems [lo, hi) of the batch on one core (oracle port)."""
-    lo, hi, N = args
+    """Full reference-algorithm steps (oracle port) on one core for `budget` seconds, cycling over the batch from `start`."""
+    start, budget, N, B = args
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)                         # one BLAS thread per process
+    except Exception:
+        pass
     from oracle import lmpc_oracle as orc
     from tests import common
     g = common.load_lmpc_golden()
-    inp = synth_batch(g, _CPU_B, N, seed=1234)
+    inp = synth_batch(g, B, N, seed=1234)
     par = orc.QPParams.lmpc_default(N)
     pt, TL = g["track"], float(g["trackLength"])
     xS = [g["xPID"]] * 4; uS = [g["uPID"]] * 4
     Qf = [orc.compute_cost(g["xPID"], TL)] * 4
+    done = 0
     t0 = time.perf_counter()
-    for i in range(lo, hi):
-        b = i % _CPU_B
+    while time.perf_counter() - t0 < budget:
+        b = (start + done) % B
         A, Bm, C = orc.compute_ltv_dynamics(xS, uS, [0, 1, 2, 3], pt, inp["xLin"][b], inp["uLin"][b], N)
         zt = inp["zt"][b].copy()
         if zt[4] - inp["x0"][b][4] > TL / 2:
@@ -94,37 +100,26 @@ def _cpu_worker(args):
         SSsel, Qsel, Succ, SuccU = orc.terminal_components(xS, uS, Qf, [1000] * 4, zt, 48, 4, None, 4, int(inp["timeStep"][b]), N, TL)
         P, q, Ao, l, u = orc.assemble_lmpc_qp(par, A, Bm, C, inp["x0"][b], inp["uOld"][b], SSsel, Qsel)
         orc.osqp_solve(P, q, Ao, l, u, polish=True)
-    return hi - lo, time.perf_counter() - t0
+        done += 1
+    return done, time.perf_counter() - t0
 
 
-_CPU_B = 256
-
-
-def cpu_baseline(N, B, per_core=None, seconds=4.0):
+def cpu_baseline(N, B, seconds=6.0, max_procs=64):
     """The reference's algorithm for this path as restated in oracle/ (NumPy regression + selection + assembly, restated
     OSQP at the reference's settings eps=1e-3 + polish -- what main.py does per step), timed on the host cores of this
-    box: first on ONE core (the reference itself is single-threaded), then on all cores (one process per core, the same
-    batch split in contiguous chunks, `per_core` problems each)."""
+    box for a fixed wall budget: first ONE core (the reference itself is single-threaded), then min(cores, max_procs)
+    single-threaded processes working through the same batch concurrently."""
     import multiprocessing as mp
-    global _CPU_B
-    _CPU_B = B
-    os.environ.setdefault("OMP_NUM_THREADS", "1"); os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
-    n1, t1 = _cpu_worker((0, min(B, 64), N))
+    n1, t1 = _cpu_worker((0, min(seconds, 3.0), N, B))
     one = n1 / t1
-    cores = os.cpu_count() or 1
-    if per_core is None:
-        per_core = max(8, int(seconds * one))          # about `seconds` of work per core
-    chunks = [(i * per_core, (i + 1) * per_core, N) for i in range(cores)]
-    t0 = time.perf_counter()
+    cores = min(os.cpu_count() or 1, max_procs)
     with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, chunks)
-    wall = time.perf_counter() - t0
-    done = sum(r[0] for r in res)
-    busy = max(r[1] for r in res)
+        res = pool.map(_cpu_worker, [(i * 7, seconds, N, B) for i in range(cores)])
+    done = sum(r[0] for r in res); busy = max(r[1] for r in res)
     return dict(value=done / busy, unit="solves/s", cores=cores, kind="port",
-                sample="%d problems of the bench batch (cyclic), %d per core on %d processes, full step a3-a19 with restated OSQP eps=1e-3+polish; "
-                       "slowest worker %.1f s (pool wall %.1f s incl. fork/imports)" % (done, per_core, cores, busy, wall),
-                single_core={"value": one, "unit": "solves/s", "cores": 1, "sample": "first %d problems, %.1f s" % (n1, t1)})
+                sample="%d full steps (a3-a19, restated OSQP eps=1e-3 + polish) of the bench batch in %.1f s on %d single-threaded processes "
+                       "(host has %d cores)" % (done, busy, cores, os.cpu_count() or 1),
+                single_core={"value": one, "unit": "solves/s", "cores": 1, "sample": "%d steps in %.1f s" % (n1, t1)})
 
 
 def main():

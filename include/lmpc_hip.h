@@ -142,6 +142,14 @@ typedef struct {          /* all device pointers, layouts as in lmpc_step_batch 
 } lmpc_step_dev_args;
 int lmpc_step_batch_dev(lmpc_ctx *, int B, const lmpc_step_dev_args *args);   /* async on the ctx stream */
 
+/* ---- caller side of the path, next row of SURVEY 8(f): plant integrator + device-resident closed-loop laps ---- */
+int lmpc_plant_step_batch(lmpc_ctx *, int B, const double *x /*B x 6*/, const double *x_glob /*B x 6*/, const double *u /*B x 2*/,
+                          const double *noise /*B x 3 N(0,1) draws*/, double *x_next, double *x_glob_next, int *status);
+        /* Simulator.dynModel, fnc/simulator/SysModel.py:56-147 (100 Euler sub-steps, clipped noise) */
+int lmpc_rollout_lap(lmpc_ctx *, int B, int T_max, const double *x0 /*B x 6*/, const double *xLin0 /*(N+1) x 6*/, const double *uLin0 /*N x 2*/,
+                     const double *noise /*T_max x B x 3*/, double *X /*T_max x B x 6*/, double *U /*T_max x B x 2*/, double *Xglob /*T_max x B x 6*/,
+                     int *doneAt /*B: steps until s > TrackLength, -1 if not reached*/, int *status /*B, OR of step status bits*/, int *steps_run);
+        /* Simulator.sim with an LMPC controller per rollout, SysModel.py:22-54 (no addPoint: the safe set is frozen during a lap) */
 int lmpc_selftest(lmpc_ctx *);                   /* device self test of the cross-lane reduction primitives */
 int lmpc_set_profiling(lmpc_ctx *, int on);       /* HIP events around each kernel launch */
 int lmpc_get_stats(lmpc_ctx *, lmpc_stats *out);  /* drains pending events */

@@ -47,7 +47,7 @@ EXPORTS = [
     "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun",
     "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
-    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest",
+    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_plant_step_batch", "lmpc_rollout_lap",
 ]
 
 _lib = None
@@ -259,6 +259,22 @@ class Context:
 
     def step_batch_dev(self, B, args):
         _chk(self.lib.lmpc_step_batch_dev(self._h, C.c_int(B), C.byref(args)))
+
+    def plant_step_batch(self, x, x_glob, u, noise):
+        x = _f64(x); xg = _f64(x_glob); u = _f64(u); nz = _f64(noise); B = x.shape[0]
+        xn = np.zeros((B, 6)); xgn = np.zeros((B, 6)); st = np.zeros(B, np.int32)
+        _chk(self.lib.lmpc_plant_step_batch(self._h, C.c_int(B), _d(x), _d(xg), _d(u), _d(nz), _d(xn), _d(xgn), _d(st)))
+        return xn, xgn, st
+
+    def rollout_lap(self, x0, xLin0, uLin0, noise):
+        """B device-resident closed-loop laps; noise (T_max, B, 3).  Returns X (T,B,6), U (T,B,2), Xglob (T,B,6), doneAt (B), status (B)."""
+        x0 = _f64(x0); xl = _f64(xLin0); ul = _f64(uLin0); nz = _f64(noise)
+        T_max, B = nz.shape[0], x0.shape[0]
+        X = np.zeros((T_max, B, 6)); U = np.zeros((T_max, B, 2)); G = np.zeros((T_max, B, 6))
+        done = np.zeros(B, np.int32); st = np.zeros(B, np.int32); tr = C.c_int()
+        _chk(self.lib.lmpc_rollout_lap(self._h, C.c_int(B), C.c_int(T_max), _d(x0), _d(xl), _d(ul), _d(nz), _d(X), _d(U), _d(G), _d(done), _d(st), C.byref(tr)))
+        T = tr.value
+        return X[:T], U[:T], G[:T], done, st
 
     def selftest(self):
         _chk(self.lib.lmpc_selftest(self._h))

@@ -444,6 +444,87 @@ int lmpc_debug_timing(lmpc_ctx *c, const double *A, const double *Bm, const doub
     return LMPC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- plant / rollouts
+int lmpc_plant_step_batch(lmpc_ctx *c, int B, const double *x, const double *xg, const double *u, const double *noise, double *xn, double *xgn, int *status) {
+    ARGCHK(c && x && xg && u && noise && xn && xgn && B >= 1);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    double *d; HIPCHK(hipMalloc(&d, sizeof(double) * (size_t)B * 29)); int *ds; HIPCHK(hipMalloc(&ds, sizeof(int) * B));
+    double *dx = d, *dg = d + (size_t)B * 6, *du = d + (size_t)B * 12, *dn = d + (size_t)B * 14, *dxn = d + (size_t)B * 17, *dgn = d + (size_t)B * 23;
+    H2D(dx, x, (size_t)B * 6); H2D(dg, xg, (size_t)B * 6); H2D(du, u, (size_t)B * 2); H2D(dn, noise, (size_t)B * 3);
+    hipLaunchKernelGGL(lmpc_plant_kernel, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, dx, dg, du, dn, dxn, dgn, ds);
+    HIPCHK(hipGetLastError());
+    D2H(xn, dxn, (size_t)B * 6); D2H(xgn, dgn, (size_t)B * 6); D2H(status, ds, B);
+    HIPCHK(hipStreamSynchronize(c->stream)); hipFree(d); hipFree(ds);
+    return LMPC_OK;
+}
+
+int lmpc_rollout_lap(lmpc_ctx *c, int B, int T_max, const double *x0, const double *xLin0, const double *uLin0, const double *noise,
+                     double *X, double *U, double *G, int *doneAt, int *status, int *steps_run) {
+    // B closed-loop LMPC laps against the frozen safe set, entirely on the device: per simulated step one regression
+    // launch, one solve launch and one advance launch; the host only polls the finished-lap counter every 8 steps.
+    ARGCHK(c && x0 && xLin0 && uLin0 && noise && X && U && G && doneAt && B >= 1 && T_max >= 1 && c->cfg.numSS_it > 0);
+    const size_t N = c->cfg.N, S = c->cfg.numSS_points, M = 8 * N + S, Bz = B;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    std::vector<void *> keep;
+    auto dalloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr; keep.push_back(q); return q; };
+#define DA(type, name, n) type *name = (type *)dalloc(sizeof(type) * (size_t)(n)); if (!name) { for (void *q : keep) hipFree(q); return set_err(LMPC_E_HIP, "hipMalloc", "rollout buffers"); }
+    DA(double, d_x, Bz * 6) DA(double, d_xg, Bz * 6) DA(double, d_xLin, Bz * (N + 1) * 6) DA(double, d_uLin, Bz * N * 2) DA(double, d_uOld, Bz * 2)
+    DA(double, d_zt, Bz * 6) DA(double, d_xPP, Bz * (N + 1) * 6) DA(int, d_hasPred, Bz) DA(int, d_tstep, Bz) DA(int, d_done, Bz) DA(int, d_nDone, 1) DA(int, d_stAcc, Bz)
+    DA(double, d_xPred, Bz * (N + 1) * 6) DA(double, d_uPred, Bz * N * 2) DA(double, d_slack, Bz * N * 2) DA(double, d_lam, Bz * S) DA(double, d_sT, Bz * 6)
+    DA(double, d_ztN, Bz * 6) DA(double, d_ztuN, Bz * 2) DA(double, d_A, Bz * N * 36) DA(double, d_B, Bz * N * 12) DA(double, d_C, Bz * N * 6)
+    DA(double, d_resid, Bz * 3) DA(int, d_status, Bz) DA(int, d_iters, Bz) DA(int, d_rst, Bz * N)
+    DA(double, d_logX, (size_t)T_max * Bz * 6) DA(double, d_logU, (size_t)T_max * Bz * 2) DA(double, d_logG, (size_t)T_max * Bz * 6) DA(double, d_noise, (size_t)T_max * Bz * 3)
+#undef DA
+    (void)M;
+    std::vector<double> xl((size_t)B * (N + 1) * 6), ul((size_t)B * N * 2), ztv((size_t)B * 6);
+    for (int b = 0; b < B; b++) {
+        memcpy(&xl[(size_t)b * (N + 1) * 6], xLin0, sizeof(double) * (N + 1) * 6); memcpy(&ul[(size_t)b * N * 2], uLin0, sizeof(double) * N * 2);
+        const double z0[6] = {0, 0, 0, 0, 10.0, 0}; memcpy(&ztv[(size_t)b * 6], z0, sizeof(z0));          // LMPC.__init__ :330
+    }
+    std::vector<int> neg((size_t)B, -1);
+    H2D(d_x, x0, Bz * 6); H2D(d_xg, x0, Bz * 6); H2D(d_xLin, xl.data(), xl.size()); H2D(d_uLin, ul.data(), ul.size()); H2D(d_zt, ztv.data(), ztv.size());
+    H2D(d_done, neg.data(), Bz); H2D(d_noise, noise, (size_t)T_max * Bz * 3);
+    HIPCHK(hipMemsetAsync(d_uOld, 0, sizeof(double) * Bz * 2, c->stream)); HIPCHK(hipMemsetAsync(d_xPP, 0, sizeof(double) * Bz * (N + 1) * 6, c->stream));
+    HIPCHK(hipMemsetAsync(d_hasPred, 0, sizeof(int) * Bz, c->stream)); HIPCHK(hipMemsetAsync(d_tstep, 0, sizeof(int) * Bz, c->stream));
+    HIPCHK(hipMemsetAsync(d_nDone, 0, sizeof(int), c->stream)); HIPCHK(hipMemsetAsync(d_stAcc, 0, sizeof(int) * Bz, c->stream));
+    lmpc_step_dev_args a; memset(&a, 0, sizeof(a));
+    a.x0 = d_x; a.xLin = d_xLin; a.uLin = d_uLin; a.uOld = d_uOld; a.zt = d_zt; a.xPredPrev = d_xPP; a.hasPred = d_hasPred; a.timeStep = d_tstep;
+    a.xPred = d_xPred; a.uPred = d_uPred; a.slack = d_slack; a.lambda = d_lam; a.sTerm = d_sT; a.ztNext = d_ztN; a.ztuNext = d_ztuN;
+    a.A = d_A; a.Bm = d_B; a.C = d_C; a.resid = d_resid; a.status = d_status; a.iters = d_iters;
+    lmpc_rollout_state r; r.x = d_x; r.xg = d_xg; r.xLin = d_xLin; r.uLin = d_uLin; r.uOld = d_uOld; r.zt = d_zt; r.xPP = d_xPP; r.hasPred = d_hasPred;
+    r.timeStep = d_tstep; r.doneAt = d_done; r.xPred = d_xPred; r.uPred = d_uPred; r.ztNext = d_ztN; r.ztuNext = d_ztuN; r.status = d_status;
+    r.logX = d_logX; r.logU = d_logU; r.logG = d_logG; r.noise = d_noise; r.nDone = d_nDone; r.statusAcc = d_stAcc;
+    int t = 0, rc = LMPC_OK;
+    for (t = 0; t < T_max; t++) {
+        // the regression status buffer of the ctx is sized for max_batch; use a private one here
+        rc = refresh_params(c, true, true); if (rc) break;
+        const int items = B * (int)N;
+        ev_begin(c, 0);
+        hipLaunchKernelGGL(lmpc_regress_kernel, dim3(items), dim3(WAVE), 0, c->stream, c->dp, items, (const double *)d_xLin, (int)(N + 1) * 6, (const double *)d_uLin, d_A, d_B, d_C, d_rst);
+        ev_end(c); c->stats.n_regress++;
+        lmpc_solve_io io; memset(&io, 0, sizeof(io));
+        io.mode = 3; io.A = d_A; io.Bm = d_B; io.C = d_C; io.x0 = d_x; io.uOld = d_uOld; io.zt = d_zt; io.xPredPrev = d_xPP; io.hasPred = d_hasPred; io.timeStep = d_tstep;
+        io.xPred = d_xPred; io.uPred = d_uPred; io.slack = d_slack; io.lambda = d_lam; io.sTerm = d_sT; io.ztNext = d_ztN; io.ztuNext = d_ztuN;
+        io.resid = d_resid; io.status = d_status; io.iters = d_iters;
+        rc = launch_solve(c, B, io); if (rc) break;
+        hipLaunchKernelGGL(lmpc_rollout_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, t, r);
+        if ((t & 7) == 7) {
+            int nd = 0;
+            if (hipMemcpyAsync(&nd, d_nDone, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = set_err(LMPC_E_HIP, "rollout poll", ""); break; }
+            if (nd >= B) { t++; break; }
+        }
+    }
+    if (rc == LMPC_OK) {
+        const int Tr = t < T_max ? t : T_max;
+        if (steps_run) *steps_run = Tr;
+        D2H(X, d_logX, (size_t)Tr * Bz * 6); D2H(U, d_logU, (size_t)Tr * Bz * 2); D2H(G, d_logG, (size_t)Tr * Bz * 6);
+        D2H(doneAt, d_done, Bz); D2H(status, d_stAcc, Bz);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = set_err(LMPC_E_HIP, "hipStreamSynchronize", "rollout");
+    }
+    for (void *q : keep) hipFree(q);
+    return rc;
+}
+
 int lmpc_selftest(lmpc_ctx *c) {
     // cross-lane primitives (DPP + v_permlane16/32_swap reductions) against closed-form values
     ARGCHK(c);

@@ -1003,6 +1003,86 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     }
 }
 
+
+// =====================================================================================================
+// K4: plant integrator + closed-loop bookkeeping for device-resident batched rollouts.
+// One thread per rollout (the plant is 100 dependent Euler sub-steps of ~60 flops: no intra-rollout parallelism).
+// =====================================================================================================
+// Simulator.dynModel, SysModel.py:56-147.  x, xg: (B,6) curvilinear / global state; u: (B,2); nz: (B,3) N(0,1) draws.
+__device__ __forceinline__ void plant_step_one(const lmpc_dev_params &p, const double *x, const double *xg, const double *u, const double *nz,
+                                               double *xn, double *xgn, int *bad) {
+    const double m = 1.98, lf = 0.125, lr = 0.125, Iz = 0.024;
+    const double Df = 0.8 * m * 9.81 / 2.0, Cf = 1.25, Bf = 1.0, Dr = 0.8 * m * 9.81 / 2.0, Cr = 1.25, Br = 1.0;
+    const double deltaT = 0.001;
+    const double delta = u[0], a = u[1];
+    double psi = xg[3], X = xg[4], Y = xg[5];
+    double vx = x[0], vy = x[1], wz = x[2], epsi = x[3], s = x[4], ey = x[5];
+    const double sd = sin(delta), cd = cos(delta);
+    for (int i = 0; i < 100; i++) {                                  // while (i+1)*deltaT <= dt, SysModel.py:93
+        const double alpha_f = delta - atan2(vy + lf * wz, vx);
+        const double alpha_r = -atan2(vy - lf * wz, vx);
+        const double Fyf = Df * sin(Cf * atan(Bf * alpha_f));
+        const double Fyr = Dr * sin(Cr * atan(Br * alpha_r));
+        const double nvx = vx + deltaT * (a - 1 / m * Fyf * sd + wz * vy);
+        const double nvy = vy + deltaT * (1 / m * (Fyf * cd + Fyr) - wz * vx);
+        const double nwz = wz + deltaT * (1 / Iz * (lf * Fyf * cd - lr * Fyr));
+        const double sp = sin(psi), cp = cos(psi), se = sin(epsi), ce = cos(epsi);
+        const double npsi = psi + deltaT * (wz);
+        const double nX = X + deltaT * ((vx * cp - vy * sp));
+        const double nY = Y + deltaT * (vx * sp + vy * cp);
+        const double cur = track_curvature(p, s, bad);
+        const double nepsi = epsi + deltaT * (wz - (vx * ce - vy * se) / (1 - cur * ey) * cur);
+        const double ns = s + deltaT * ((vx * ce - vy * se) / (1 - cur * ey));
+        const double ney = ey + deltaT * (vx * se + vy * ce);
+        vx = nvx; vy = nvy; wz = nwz; epsi = nepsi; s = ns; ey = ney; psi = npsi; X = nX; Y = nY;
+    }
+    const double n0 = fmax(-0.05, fmin(nz[0] * 0.01, 0.05)), n1 = fmax(-0.05, fmin(nz[1] * 0.01, 0.05)), n2 = fmax(-0.05, fmin(nz[2] * 0.005, 0.05));
+    xn[0] = vx + 0.01 * n0; xn[1] = vy + 0.01 * n1; xn[2] = wz + 0.01 * n2; xn[3] = epsi; xn[4] = s; xn[5] = ey;   // :139-145
+    xgn[0] = vx; xgn[1] = vy; xgn[2] = wz; xgn[3] = psi; xgn[4] = X; xgn[5] = Y;
+}
+
+__global__ void lmpc_plant_kernel(lmpc_dev_params p, int B, const double *__restrict__ x, const double *__restrict__ xg, const double *__restrict__ u,
+                                  const double *__restrict__ nz, double *__restrict__ xn, double *__restrict__ xgn, int *__restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int bad = 0;
+    double xo[6], go[6];
+    plant_step_one(p, x + (size_t)b * 6, xg + (size_t)b * 6, u + (size_t)b * 2, nz + (size_t)b * 3, xo, go, &bad);
+    for (int j = 0; j < 6; j++) { xn[(size_t)b * 6 + j] = xo[j]; xgn[(size_t)b * 6 + j] = go[j]; }
+    if (status) status[b] = bad ? LMPC_ST_NO_SEGMENT : 0;
+}
+
+// One closed-loop step of every rollout after lmpc_step_batch_dev: log (x_t, u_t, xglob_t), integrate the plant with
+// u_t = uPred[0] (SysModel.py:34-40), then the tail of MPC.solve (:131-137): xLin/uLin shift, OldInput, zt, xPred -> prev.
+struct lmpc_rollout_state {
+    double *x, *xg, *xLin, *uLin, *uOld, *zt, *xPP; int *hasPred, *timeStep, *doneAt;        // controller + plant state (B, ...)
+    const double *xPred, *uPred, *ztNext, *ztuNext; const int *status;                        // outputs of the step just taken
+    double *logX, *logU, *logG; const double *noise; int *nDone, *statusAcc;                   // logs [T][B][..], noise [T][B][3]
+};
+__global__ void lmpc_rollout_advance_kernel(lmpc_dev_params p, int B, int t, lmpc_rollout_state r) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int N = p.N;
+    double *x = r.x + (size_t)b * 6, *xg = r.xg + (size_t)b * 6;
+    const double *uP = r.uPred + (size_t)b * N * 2, *xP = r.xPred + (size_t)b * (N + 1) * 6;
+    const double u0[2] = {uP[0], uP[1]};
+    for (int j = 0; j < 6; j++) { r.logX[((size_t)t * B + b) * 6 + j] = x[j]; r.logG[((size_t)t * B + b) * 6 + j] = xg[j]; }
+    r.logU[((size_t)t * B + b) * 2] = u0[0]; r.logU[((size_t)t * B + b) * 2 + 1] = u0[1];
+    int bad = 0; double xo[6], go[6];
+    plant_step_one(p, x, xg, u0, r.noise + ((size_t)t * B + b) * 3, xo, go, &bad);
+    for (int j = 0; j < 6; j++) { x[j] = xo[j]; xg[j] = go[j]; }
+    double *xl = r.xLin + (size_t)b * (N + 1) * 6, *ul = r.uLin + (size_t)b * N * 2, *xpp = r.xPP + (size_t)b * (N + 1) * 6;
+    for (int i = 0; i < (N + 1) * 6; i++) xpp[i] = xP[i];
+    for (int i = 0; i < N * 6; i++) xl[i] = xP[6 + i];
+    for (int j = 0; j < 6; j++) { xl[N * 6 + j] = r.ztNext[(size_t)b * 6 + j]; r.zt[(size_t)b * 6 + j] = r.ztNext[(size_t)b * 6 + j]; }
+    for (int i = 0; i < (N - 1) * 2; i++) ul[i] = uP[2 + i];
+    ul[(N - 1) * 2] = r.ztuNext[(size_t)b * 2]; ul[(N - 1) * 2 + 1] = r.ztuNext[(size_t)b * 2 + 1];
+    r.uOld[(size_t)b * 2] = u0[0]; r.uOld[(size_t)b * 2 + 1] = u0[1];
+    r.hasPred[b] = 1; r.timeStep[b] = t + 1;
+    r.statusAcc[b] |= r.status[b] | (bad ? LMPC_ST_NO_SEGMENT : 0);
+    if (r.doneAt[b] < 0 && xo[4] > p.TL) { r.doneAt[b] = t + 1; atomicAdd(r.nDone, 1); }       // lap completed, SysModel.py:45
+}
+
 // wave-reduction self test (exercised by lmpc_selftest): out[0..2] = sum, max, min of lane-dependent values
 __global__ void lmpc_selftest_kernel(double *out) {
     const int lane = threadIdx.x;

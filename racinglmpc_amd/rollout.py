@@ -56,6 +56,19 @@ class BatchedRollouts:
         self.TL = float(self.track[-1, 3] + self.track[-1, 4])
         self.rng = np.random.default_rng(seed)
 
+    def run_lap_device(self, x0, xLin0, uLin0, max_steps=400):
+        """Same contract as run_lap, but the whole lap (controller steps, plant, bookkeeping) stays on the GPU
+        (lmpc_rollout_lap): three kernel launches per simulated step, no host round trip."""
+        B = x0.shape[0]
+        noise = self.rng.standard_normal((max_steps, B, 3))
+        X, U, G, done, st = self.ctx.rollout_lap(x0, xLin0, uLin0, noise)
+        self.last_status = st
+        laps = []
+        for b in range(B):
+            T = int(done[b]) if done[b] >= 0 else X.shape[0]
+            laps.append((X[:T, b].copy(), U[:T, b].copy(), G[:T, b].copy()))
+        return laps
+
     def run_lap(self, x0, xLin0, uLin0, max_steps=400):
         """x0 (B,6) start states; xLin0 (N+1,6) / uLin0 (N,2) first linearisation trajectory (LMPC.addTrajectory :431-433).
         Returns list of (x (T,6), u (T,2), x_glob (T,6)) per rollout, the lap ending when s > TrackLength (SysModel.py:45)."""
@@ -87,11 +100,12 @@ class BatchedRollouts:
         return laps
 
 
-def lap_and_exchange(rollouts, x0_all, xLin0, uLin0, K, T_max, rank=0, world=1):
+def lap_and_exchange(rollouts, x0_all, xLin0, uLin0, K, T_max, rank=0, world=1, device=False):
     """One LMPC iteration over all ranks: every rank runs its shard, the K globally fastest laps are exchanged
     (all-gather) and appended to the model store and the safe set of the local context in identical order."""
     lo, hi = parallel.shard(x0_all.shape[0], rank, world)
-    laps = rollouts.run_lap(x0_all[lo:hi], xLin0, uLin0) if hi > lo else []
+    run = rollouts.run_lap_device if device else rollouts.run_lap
+    laps = run(x0_all[lo:hi], xLin0, uLin0) if hi > lo else []
     best = parallel.exchange_laps(laps, K, T_max)
     for x, u, xg, src, T in best:
         rollouts.ctx.ss_add_trajectory(x, u)

@@ -242,3 +242,53 @@ def test_batched_rollouts_full_lap_and_exchange(g):
         assert x[-1, 4] <= float(g["trackLength"]) + 1.0 and np.abs(x[:, 5]).max() < 0.6        # stayed on (soft-constrained) track
         assert np.abs(u[:, 0]).max() <= 0.5 + 1e-9 and np.abs(u[:, 1]).max() <= 10 + 1e-9       # hard input bounds respected
     ctx.close()
+
+
+def test_plant_kernel_matches_reference_plant(g):
+    """K4 (lmpc_plant_kernel) vs the oracle's restatement of Simulator.dynModel (which is bit-exact against the
+    reference, tests/test_oracle_golden.py): only the transcendental functions differ (device libm vs NumPy)."""
+    from oracle import lmpc_oracle as orc
+    ctx, par = common.make_lmpc_ctx(g, 4, max_batch=4)
+    rng = np.random.default_rng(11)
+    idx = rng.integers(0, 990, size=64)
+    x = g["xPID"][idx].copy(); xg = g["xPID_glob"][idx].copy(); u = g["uPID"][idx].copy()
+    x[:, 4] = np.mod(x[:, 4], float(g["trackLength"])) + (idx % 3) * float(g["trackLength"]) * (idx % 2)     # some beyond one lap
+    nz = rng.standard_normal((64, 3)) * 3.0                                                               # exercises the clipping
+    xn, xgn, st = ctx.plant_step_batch(x, xg, u, nz)
+    assert np.all(st == 0)
+    pt = np.array(g["track"])
+    worst = 0.0
+    for b in range(64):
+        it = iter(nz[b])
+        xo, go = orc.dyn_model(pt, x[b], xg[b], u[b], lambda: next(it))
+        worst = max(worst, np.abs(xn[b] - xo).max(), np.abs(xgn[b] - go).max())
+    print("plant kernel worst abs err", worst)
+    assert worst < 1e-12
+    ctx.close()
+
+
+def test_device_resident_rollouts(g):
+    """lmpc_rollout_lap (regression + solve + plant + bookkeeping on the GPU for a whole lap) reproduces the host-driven
+    loop (same controller calls, NumPy plant) when fed the same noise."""
+    from racinglmpc_amd import rollout
+    B = 8
+    x0 = np.tile(np.array([0.5, 0, 0, 0, 0, 0.0]), (B, 1)); x0[:, 5] = np.linspace(-0.04, 0.04, B)
+    xLin0 = g["SS0"][1:14]; uLin0 = g["uSS0"][1:13]
+    ctx, par = common.make_lmpc_ctx(g, 4, max_batch=B)
+    ro_d = rollout.BatchedRollouts(ctx, g["track"], seed=9)
+    laps_d = ro_d.run_lap_device(x0, xLin0, uLin0, max_steps=320)
+    assert np.all(ro_d.last_status == 0)
+    ro_h = rollout.BatchedRollouts(ctx, g["track"], seed=9)
+    noise = ro_h.rng.standard_normal((320, B, 3))                       # the same draws run_lap_device consumed
+
+    class _Replay:
+        def __init__(self, z): self.z, self.t = z, 0
+        def standard_normal(self, shape):
+            out = self.z[self.t]; self.t += 1; return out
+    ro_h.rng = _Replay(noise)
+    laps_h = ro_h.run_lap(x0, xLin0, uLin0, max_steps=320)
+    for (xd, ud, gd), (xh, uh, gh) in zip(laps_d, laps_h):
+        assert xd.shape == xh.shape and 150 < xd.shape[0] < 320
+        assert np.abs(xd - xh).max() < 1e-6 and np.abs(ud - uh).max() < 1e-6
+    print("device rollouts: lap lengths", [l[0].shape[0] for l in laps_d])
+    ctx.close()
