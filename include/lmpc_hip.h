@@ -146,10 +146,15 @@ int lmpc_step_batch_dev(lmpc_ctx *, int B, const lmpc_step_dev_args *args);   /*
 int lmpc_plant_step_batch(lmpc_ctx *, int B, const double *x /*B x 6*/, const double *x_glob /*B x 6*/, const double *u /*B x 2*/,
                           const double *noise /*B x 3 N(0,1) draws*/, double *x_next, double *x_glob_next, int *status);
         /* Simulator.dynModel, fnc/simulator/SysModel.py:56-147 (100 Euler sub-steps, clipped noise) */
-int lmpc_rollout_lap(lmpc_ctx *, int B, int T_max, const double *x0 /*B x 6*/, const double *xLin0 /*(N+1) x 6*/, const double *uLin0 /*N x 2*/,
-                     const double *noise /*T_max x B x 3*/, double *X /*T_max x B x 6*/, double *U /*T_max x B x 2*/, double *Xglob /*T_max x B x 6*/,
-                     int *doneAt /*B: steps until s > TrackLength, -1 if not reached*/, int *status /*B, OR of step status bits*/, int *steps_run);
-        /* Simulator.sim with an LMPC controller per rollout, SysModel.py:22-54 (no addPoint: the safe set is frozen during a lap) */
+int lmpc_rollout_begin(lmpc_ctx *, int B, int T_max, const double *x0 /*B x 6*/, const double *xglob0 /*B x 6*/,
+                       const double *xLin0 /*B x (N+1) x 6*/, const double *uLin0 /*B x N x 2*/, const double *noise /*T_max x B x 3*/);
+int lmpc_rollout_run(lmpc_ctx *, int max_steps, int *steps_total, int *n_done);
+int lmpc_rollout_fetch(lmpc_ctx *, int t0, int t1, double *X /*(t1-t0) x B x 6*/, double *U /*.. x B x 2*/, double *Xglob,
+                       int *doneAt /*B*/, int *status /*B*/, double *finalX /*B x 6*/, double *finalXglob /*B x 6*/);
+int lmpc_rollout_end(lmpc_ctx *);
+        /* Simulator.sim with one LMPC controller per rollout, SysModel.py:22-54, state resident on the device */
+int lmpc_ss_extend_lap(lmpc_ctx *, int lap, const double *x /*n x 6*/, const double *u /*n x 2*/, int n);
+        /* LMPC.addPoint (:466-474) applied to any stored lap: n points appended with s + TrackLength, Qfun counting down */
 int lmpc_selftest(lmpc_ctx *);                   /* device self test of the cross-lane reduction primitives */
 int lmpc_set_profiling(lmpc_ctx *, int on);       /* HIP events around each kernel launch */
 int lmpc_get_stats(lmpc_ctx *, lmpc_stats *out);  /* drains pending events */

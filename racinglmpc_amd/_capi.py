@@ -47,7 +47,7 @@ EXPORTS = [
     "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun",
     "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
-    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_plant_step_batch", "lmpc_rollout_lap",
+    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_plant_step_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap",
 ]
 
 _lib = None
@@ -266,15 +266,31 @@ class Context:
         _chk(self.lib.lmpc_plant_step_batch(self._h, C.c_int(B), _d(x), _d(xg), _d(u), _d(nz), _d(xn), _d(xgn), _d(st)))
         return xn, xgn, st
 
-    def rollout_lap(self, x0, xLin0, uLin0, noise):
-        """B device-resident closed-loop laps; noise (T_max, B, 3).  Returns X (T,B,6), U (T,B,2), Xglob (T,B,6), doneAt (B), status (B)."""
-        x0 = _f64(x0); xl = _f64(xLin0); ul = _f64(uLin0); nz = _f64(noise)
-        T_max, B = nz.shape[0], x0.shape[0]
-        X = np.zeros((T_max, B, 6)); U = np.zeros((T_max, B, 2)); G = np.zeros((T_max, B, 6))
-        done = np.zeros(B, np.int32); st = np.zeros(B, np.int32); tr = C.c_int()
-        _chk(self.lib.lmpc_rollout_lap(self._h, C.c_int(B), C.c_int(T_max), _d(x0), _d(xl), _d(ul), _d(nz), _d(X), _d(U), _d(G), _d(done), _d(st), C.byref(tr)))
-        T = tr.value
-        return X[:T], U[:T], G[:T], done, st
+    def rollout_begin(self, x0, xglob0, xLin0, uLin0, noise):
+        x0 = _f64(x0); xg = _f64(xglob0); xl = _f64(xLin0); ul = _f64(uLin0); nz = _f64(noise)
+        B = x0.shape[0]
+        assert xl.shape == (B, self.N + 1, 6) and ul.shape == (B, self.N, 2) and nz.shape[1:] == (B, 3)
+        self._ro = (B, nz.shape[0])
+        _chk(self.lib.lmpc_rollout_begin(self._h, C.c_int(B), C.c_int(nz.shape[0]), _d(x0), _d(xg), _d(xl), _d(ul), _d(nz)))
+
+    def rollout_run(self, max_steps):
+        t = C.c_int(); nd = C.c_int()
+        _chk(self.lib.lmpc_rollout_run(self._h, C.c_int(int(max_steps)), C.byref(t), C.byref(nd)))
+        return t.value, nd.value
+
+    def rollout_fetch(self, t0, t1):
+        B = self._ro[0]; n = t1 - t0
+        X = np.zeros((n, B, 6)); U = np.zeros((n, B, 2)); G = np.zeros((n, B, 6))
+        done = np.zeros(B, np.int32); st = np.zeros(B, np.int32); fx = np.zeros((B, 6)); fg = np.zeros((B, 6))
+        _chk(self.lib.lmpc_rollout_fetch(self._h, C.c_int(t0), C.c_int(t1), _d(X), _d(U), _d(G), _d(done), _d(st), _d(fx), _d(fg)))
+        return X, U, G, done, st, fx, fg
+
+    def rollout_end(self):
+        _chk(self.lib.lmpc_rollout_end(self._h))
+
+    def ss_extend_lap(self, lap, x, u):
+        x = _f64(x); u = _f64(u)
+        _chk(self.lib.lmpc_ss_extend_lap(self._h, C.c_int(int(lap)), _d(x), _d(u), C.c_int(x.shape[0])))
 
     def selftest(self):
         _chk(self.lib.lmpc_selftest(self._h))

@@ -32,6 +32,7 @@ struct lmpc_ctx {
     size_t lds_bytes;
     int (*solve_launch)(lmpc_ctx *, int, const lmpc_solve_io &);
     int profiling; std::vector<evpair> events; lmpc_stats stats;
+    struct lmpc_rollout_session *ro;
 };
 
 template <int N, int S> static int solve_launch_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
@@ -102,7 +103,7 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     ARGCHK(cfg->track_rows >= 0 && cfg->track_rows <= LMPC_MAX_TRACK_ROWS);
     ARGCHK(cfg->max_batch >= 1 && cfg->max_laps >= 1 && cfg->max_lap_len >= 8);
     lmpc_ctx *c = new lmpc_ctx();
-    c->cfg = *cfg; c->profiling = 0; memset(&c->stats, 0, sizeof(c->stats));
+    c->cfg = *cfg; c->profiling = 0; c->ro = nullptr; memset(&c->stats, 0, sizeof(c->stats));
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) { delete c; return set_err(LMPC_E_HIP, "hipSetDevice", hipGetErrorString(e)); }
     HIPCHK(hipStreamCreate(&c->stream));
@@ -126,10 +127,12 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     return LMPC_OK;
 }
 
+static void rollout_free(lmpc_ctx *c);
 int lmpc_destroy(lmpc_ctx *c) {
     if (!c) return LMPC_OK;
     hipSetDevice(c->cfg.device);
     hipStreamSynchronize(c->stream);
+    rollout_free(c);
     for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     void *ptrs[] = {c->mstore, c->sstore, c->w_x0, c->w_xLin, c->w_uLin, c->w_uOld, c->w_zt, c->w_xPP, c->w_A, c->w_B, c->w_C, c->w_ssSel, c->w_qSel,
                     c->w_succ, c->w_succU, c->w_ztUsed, c->w_xPred, c->w_uPred, c->w_slack, c->w_lam, c->w_sT, c->w_mu, c->w_ztN, c->w_ztuN, c->w_resid,
@@ -458,71 +461,119 @@ int lmpc_plant_step_batch(lmpc_ctx *c, int B, const double *x, const double *xg,
     return LMPC_OK;
 }
 
-int lmpc_rollout_lap(lmpc_ctx *c, int B, int T_max, const double *x0, const double *xLin0, const double *uLin0, const double *noise,
-                     double *X, double *U, double *G, int *doneAt, int *status, int *steps_run) {
-    // B closed-loop LMPC laps against the frozen safe set, entirely on the device: per simulated step one regression
-    // launch, one solve launch and one advance launch; the host only polls the finished-lap counter every 8 steps.
-    ARGCHK(c && x0 && xLin0 && uLin0 && noise && X && U && G && doneAt && B >= 1 && T_max >= 1 && c->cfg.numSS_it > 0);
-    const size_t N = c->cfg.N, S = c->cfg.numSS_points, M = 8 * N + S, Bz = B;
-    HIPCHK(hipSetDevice(c->cfg.device));
+struct lmpc_rollout_session {
+    int B, T_max, t;
     std::vector<void *> keep;
-    auto dalloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr; keep.push_back(q); return q; };
-#define DA(type, name, n) type *name = (type *)dalloc(sizeof(type) * (size_t)(n)); if (!name) { for (void *q : keep) hipFree(q); return set_err(LMPC_E_HIP, "hipMalloc", "rollout buffers"); }
+    double *d_x, *d_xg, *d_xLin, *d_uLin, *d_uOld, *d_zt, *d_xPP, *d_xPred, *d_uPred, *d_slack, *d_lam, *d_sT, *d_ztN, *d_ztuN, *d_A, *d_B, *d_C, *d_resid;
+    double *d_logX, *d_logU, *d_logG, *d_noise, *d_finX, *d_finG;
+    int *d_hasPred, *d_tstep, *d_done, *d_nDone, *d_stAcc, *d_status, *d_iters, *d_rst;
+};
+
+static void rollout_free(lmpc_ctx *c) {
+    if (!c->ro) return;
+    for (void *q : c->ro->keep) hipFree(q);
+    delete c->ro; c->ro = nullptr;
+}
+
+int lmpc_rollout_begin(lmpc_ctx *c, int B, int T_max, const double *x0, const double *xg0, const double *xLin0, const double *uLin0, const double *noise) {
+    // B closed-loop LMPC laps, state resident on the device.  xLin0 / uLin0: per-rollout first linearisation trajectories
+    // (B x (N+1) x 6, B x N x 2) -- LMPC.addTrajectory :431-433.  noise: T_max x B x 3 N(0,1) draws.
+    ARGCHK(c && x0 && xg0 && xLin0 && uLin0 && noise && B >= 1 && T_max >= 1 && c->cfg.numSS_it > 0);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    rollout_free(c);
+    lmpc_rollout_session *r = new lmpc_rollout_session(); c->ro = r; r->B = B; r->T_max = T_max; r->t = 0;
+    const size_t N = c->cfg.N, S = c->cfg.numSS_points, Bz = B;
+    bool ok = true;
+    auto dalloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) { ok = false; return nullptr; } r->keep.push_back(q); return q; };
+#define DA(type, name, n) r->name = (type *)dalloc(sizeof(type) * (size_t)(n));
     DA(double, d_x, Bz * 6) DA(double, d_xg, Bz * 6) DA(double, d_xLin, Bz * (N + 1) * 6) DA(double, d_uLin, Bz * N * 2) DA(double, d_uOld, Bz * 2)
     DA(double, d_zt, Bz * 6) DA(double, d_xPP, Bz * (N + 1) * 6) DA(int, d_hasPred, Bz) DA(int, d_tstep, Bz) DA(int, d_done, Bz) DA(int, d_nDone, 1) DA(int, d_stAcc, Bz)
     DA(double, d_xPred, Bz * (N + 1) * 6) DA(double, d_uPred, Bz * N * 2) DA(double, d_slack, Bz * N * 2) DA(double, d_lam, Bz * S) DA(double, d_sT, Bz * 6)
     DA(double, d_ztN, Bz * 6) DA(double, d_ztuN, Bz * 2) DA(double, d_A, Bz * N * 36) DA(double, d_B, Bz * N * 12) DA(double, d_C, Bz * N * 6)
-    DA(double, d_resid, Bz * 3) DA(int, d_status, Bz) DA(int, d_iters, Bz) DA(int, d_rst, Bz * N)
+    DA(double, d_resid, Bz * 3) DA(int, d_status, Bz) DA(int, d_iters, Bz) DA(int, d_rst, Bz * N) DA(double, d_finX, Bz * 6) DA(double, d_finG, Bz * 6)
     DA(double, d_logX, (size_t)T_max * Bz * 6) DA(double, d_logU, (size_t)T_max * Bz * 2) DA(double, d_logG, (size_t)T_max * Bz * 6) DA(double, d_noise, (size_t)T_max * Bz * 3)
 #undef DA
-    (void)M;
-    std::vector<double> xl((size_t)B * (N + 1) * 6), ul((size_t)B * N * 2), ztv((size_t)B * 6);
-    for (int b = 0; b < B; b++) {
-        memcpy(&xl[(size_t)b * (N + 1) * 6], xLin0, sizeof(double) * (N + 1) * 6); memcpy(&ul[(size_t)b * N * 2], uLin0, sizeof(double) * N * 2);
-        const double z0[6] = {0, 0, 0, 0, 10.0, 0}; memcpy(&ztv[(size_t)b * 6], z0, sizeof(z0));          // LMPC.__init__ :330
-    }
+    if (!ok) { rollout_free(c); return set_err(LMPC_E_HIP, "hipMalloc", "rollout buffers"); }
+    std::vector<double> ztv((size_t)B * 6, 0.0);
+    for (int b = 0; b < B; b++) ztv[(size_t)b * 6 + 4] = 10.0;                                   // LMPC.__init__ :330
     std::vector<int> neg((size_t)B, -1);
-    H2D(d_x, x0, Bz * 6); H2D(d_xg, x0, Bz * 6); H2D(d_xLin, xl.data(), xl.size()); H2D(d_uLin, ul.data(), ul.size()); H2D(d_zt, ztv.data(), ztv.size());
-    H2D(d_done, neg.data(), Bz); H2D(d_noise, noise, (size_t)T_max * Bz * 3);
-    HIPCHK(hipMemsetAsync(d_uOld, 0, sizeof(double) * Bz * 2, c->stream)); HIPCHK(hipMemsetAsync(d_xPP, 0, sizeof(double) * Bz * (N + 1) * 6, c->stream));
-    HIPCHK(hipMemsetAsync(d_hasPred, 0, sizeof(int) * Bz, c->stream)); HIPCHK(hipMemsetAsync(d_tstep, 0, sizeof(int) * Bz, c->stream));
-    HIPCHK(hipMemsetAsync(d_nDone, 0, sizeof(int), c->stream)); HIPCHK(hipMemsetAsync(d_stAcc, 0, sizeof(int) * Bz, c->stream));
-    lmpc_step_dev_args a; memset(&a, 0, sizeof(a));
-    a.x0 = d_x; a.xLin = d_xLin; a.uLin = d_uLin; a.uOld = d_uOld; a.zt = d_zt; a.xPredPrev = d_xPP; a.hasPred = d_hasPred; a.timeStep = d_tstep;
-    a.xPred = d_xPred; a.uPred = d_uPred; a.slack = d_slack; a.lambda = d_lam; a.sTerm = d_sT; a.ztNext = d_ztN; a.ztuNext = d_ztuN;
-    a.A = d_A; a.Bm = d_B; a.C = d_C; a.resid = d_resid; a.status = d_status; a.iters = d_iters;
-    lmpc_rollout_state r; r.x = d_x; r.xg = d_xg; r.xLin = d_xLin; r.uLin = d_uLin; r.uOld = d_uOld; r.zt = d_zt; r.xPP = d_xPP; r.hasPred = d_hasPred;
-    r.timeStep = d_tstep; r.doneAt = d_done; r.xPred = d_xPred; r.uPred = d_uPred; r.ztNext = d_ztN; r.ztuNext = d_ztuN; r.status = d_status;
-    r.logX = d_logX; r.logU = d_logU; r.logG = d_logG; r.noise = d_noise; r.nDone = d_nDone; r.statusAcc = d_stAcc;
-    int t = 0, rc = LMPC_OK;
-    for (t = 0; t < T_max; t++) {
-        // the regression status buffer of the ctx is sized for max_batch; use a private one here
-        rc = refresh_params(c, true, true); if (rc) break;
+    H2D(r->d_x, x0, Bz * 6); H2D(r->d_xg, xg0, Bz * 6); H2D(r->d_xLin, xLin0, Bz * (N + 1) * 6); H2D(r->d_uLin, uLin0, Bz * N * 2); H2D(r->d_zt, ztv.data(), ztv.size());
+    H2D(r->d_done, neg.data(), Bz); H2D(r->d_noise, noise, (size_t)T_max * Bz * 3);
+    HIPCHK(hipMemsetAsync(r->d_uOld, 0, sizeof(double) * Bz * 2, c->stream)); HIPCHK(hipMemsetAsync(r->d_xPP, 0, sizeof(double) * Bz * (N + 1) * 6, c->stream));
+    HIPCHK(hipMemsetAsync(r->d_hasPred, 0, sizeof(int) * Bz, c->stream)); HIPCHK(hipMemsetAsync(r->d_tstep, 0, sizeof(int) * Bz, c->stream));
+    HIPCHK(hipMemsetAsync(r->d_nDone, 0, sizeof(int), c->stream)); HIPCHK(hipMemsetAsync(r->d_stAcc, 0, sizeof(int) * Bz, c->stream));
+    HIPCHK(hipMemsetAsync(r->d_finX, 0, sizeof(double) * Bz * 6, c->stream)); HIPCHK(hipMemsetAsync(r->d_finG, 0, sizeof(double) * Bz * 6, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LMPC_OK;
+}
+
+int lmpc_rollout_run(lmpc_ctx *c, int max_steps, int *steps_total, int *n_done) {
+    // advance every rollout by up to max_steps simulated steps (three launches per step, no host round trip except a
+    // finished-lap poll every 8 steps); stops early once every rollout has crossed the finish line
+    ARGCHK(c && c->ro && max_steps >= 1);
+    lmpc_rollout_session *r = c->ro;
+    const int B = r->B; const size_t N = c->cfg.N;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    lmpc_rollout_state st; st.x = r->d_x; st.xg = r->d_xg; st.xLin = r->d_xLin; st.uLin = r->d_uLin; st.uOld = r->d_uOld; st.zt = r->d_zt; st.xPP = r->d_xPP;
+    st.hasPred = r->d_hasPred; st.timeStep = r->d_tstep; st.doneAt = r->d_done; st.xPred = r->d_xPred; st.uPred = r->d_uPred; st.ztNext = r->d_ztN; st.ztuNext = r->d_ztuN;
+    st.status = r->d_status; st.logX = r->d_logX; st.logU = r->d_logU; st.logG = r->d_logG; st.noise = r->d_noise; st.nDone = r->d_nDone; st.statusAcc = r->d_stAcc;
+    st.finX = r->d_finX; st.finG = r->d_finG;
+    int nd = 0, rc = LMPC_OK;
+    const int t_end = std::min(r->T_max, r->t + max_steps);
+    while (r->t < t_end) {
+        rc = refresh_params(c, true, true); if (rc) return rc;
         const int items = B * (int)N;
         ev_begin(c, 0);
-        hipLaunchKernelGGL(lmpc_regress_kernel, dim3(items), dim3(WAVE), 0, c->stream, c->dp, items, (const double *)d_xLin, (int)(N + 1) * 6, (const double *)d_uLin, d_A, d_B, d_C, d_rst);
+        hipLaunchKernelGGL(lmpc_regress_kernel, dim3(items), dim3(WAVE), 0, c->stream, c->dp, items, (const double *)r->d_xLin, (int)(N + 1) * 6, (const double *)r->d_uLin,
+                           r->d_A, r->d_B, r->d_C, r->d_rst);
         ev_end(c); c->stats.n_regress++;
         lmpc_solve_io io; memset(&io, 0, sizeof(io));
-        io.mode = 3; io.A = d_A; io.Bm = d_B; io.C = d_C; io.x0 = d_x; io.uOld = d_uOld; io.zt = d_zt; io.xPredPrev = d_xPP; io.hasPred = d_hasPred; io.timeStep = d_tstep;
-        io.xPred = d_xPred; io.uPred = d_uPred; io.slack = d_slack; io.lambda = d_lam; io.sTerm = d_sT; io.ztNext = d_ztN; io.ztuNext = d_ztuN;
-        io.resid = d_resid; io.status = d_status; io.iters = d_iters;
-        rc = launch_solve(c, B, io); if (rc) break;
-        hipLaunchKernelGGL(lmpc_rollout_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, t, r);
-        if ((t & 7) == 7) {
-            int nd = 0;
-            if (hipMemcpyAsync(&nd, d_nDone, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = set_err(LMPC_E_HIP, "rollout poll", ""); break; }
-            if (nd >= B) { t++; break; }
+        io.mode = 3; io.A = r->d_A; io.Bm = r->d_B; io.C = r->d_C; io.x0 = r->d_x; io.uOld = r->d_uOld; io.zt = r->d_zt; io.xPredPrev = r->d_xPP; io.hasPred = r->d_hasPred;
+        io.timeStep = r->d_tstep; io.xPred = r->d_xPred; io.uPred = r->d_uPred; io.slack = r->d_slack; io.lambda = r->d_lam; io.sTerm = r->d_sT; io.ztNext = r->d_ztN;
+        io.ztuNext = r->d_ztuN; io.resid = r->d_resid; io.status = r->d_status; io.iters = r->d_iters;
+        rc = launch_solve(c, B, io); if (rc) return rc;
+        hipLaunchKernelGGL(lmpc_rollout_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, r->t, st);
+        HIPCHK(hipGetLastError());
+        r->t++;
+        if ((r->t & 7) == 0 || r->t == t_end) {
+            HIPCHK(hipMemcpyAsync(&nd, r->d_nDone, sizeof(int), hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+            if (nd >= B) break;
         }
     }
-    if (rc == LMPC_OK) {
-        const int Tr = t < T_max ? t : T_max;
-        if (steps_run) *steps_run = Tr;
-        D2H(X, d_logX, (size_t)Tr * Bz * 6); D2H(U, d_logU, (size_t)Tr * Bz * 2); D2H(G, d_logG, (size_t)Tr * Bz * 6);
-        D2H(doneAt, d_done, Bz); D2H(status, d_stAcc, Bz);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = set_err(LMPC_E_HIP, "hipStreamSynchronize", "rollout");
+    if (steps_total) *steps_total = r->t;
+    if (n_done) *n_done = nd;
+    return LMPC_OK;
+}
+
+int lmpc_rollout_fetch(lmpc_ctx *c, int t0, int t1, double *X, double *U, double *G, int *doneAt, int *status, double *finalX, double *finalG) {
+    // logs of steps [t0, t1): X/G (t1-t0) x B x 6, U (t1-t0) x B x 2; doneAt: steps until s > TrackLength (-1: not yet);
+    // finalX / finalG: state right after the crossing step (the reference's xF before the TrackLength shift, SysModel.py:50)
+    ARGCHK(c && c->ro && t0 >= 0 && t1 >= t0 && t1 <= c->ro->t);
+    lmpc_rollout_session *r = c->ro; const size_t Bz = r->B, n = (size_t)(t1 - t0);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (n) { D2H(X, r->d_logX + (size_t)t0 * Bz * 6, n * Bz * 6); D2H(U, r->d_logU + (size_t)t0 * Bz * 2, n * Bz * 2); D2H(G, r->d_logG + (size_t)t0 * Bz * 6, n * Bz * 6); }
+    D2H(doneAt, r->d_done, Bz); D2H(status, r->d_stAcc, Bz); D2H(finalX, r->d_finX, Bz * 6); D2H(finalG, r->d_finG, Bz * 6);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LMPC_OK;
+}
+
+int lmpc_rollout_end(lmpc_ctx *c) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream)); rollout_free(c); return LMPC_OK; }
+
+int lmpc_ss_extend_lap(lmpc_ctx *c, int lap, const double *x, const double *u, int n) {
+    // batched-mode form of LMPC.addPoint (:466-474) for ANY stored lap: append n points shifted by TrackLength in s,
+    // Q-function continuing to count down.  (In the reference the points of lap j extend lap j-1 one by one.)
+    ARGCHK(c && x && u && n >= 0 && lap >= 0 && lap < (int)c->s_len.size());
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (c->s_len[lap] + n > c->cfg.max_lap_len) return set_err(LMPC_E_CAPACITY, "lap longer than max_lap_len", "");
+    double *base = c->sstore + (size_t)lap * LMPC_COLS * c->cfg.max_lap_len;
+    for (int i = 0; i < n; i++) {
+        const double q = c->s_qlast[lap] - 1.0; const int row = c->s_len[lap];
+        hipLaunchKernelGGL(lmpc_store_row_kernel, dim3(1), dim3(64), 0, c->stream, base, c->cfg.max_lap_len, row,
+                           x[i * 6 + 0], x[i * 6 + 1], x[i * 6 + 2], x[i * 6 + 3], x[i * 6 + 4] + c->cfg.trackLength, x[i * 6 + 5], u[i * 2], u[i * 2 + 1], q);
+        c->s_len[lap] = row + 1; c->s_qlast[lap] = q;
     }
-    for (void *q : keep) hipFree(q);
-    return rc;
+    HIPCHK(hipGetLastError());
+    return LMPC_OK;
 }
 
 int lmpc_selftest(lmpc_ctx *c) {

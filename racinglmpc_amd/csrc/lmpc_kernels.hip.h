@@ -1058,6 +1058,7 @@ struct lmpc_rollout_state {
     double *x, *xg, *xLin, *uLin, *uOld, *zt, *xPP; int *hasPred, *timeStep, *doneAt;        // controller + plant state (B, ...)
     const double *xPred, *uPred, *ztNext, *ztuNext; const int *status;                        // outputs of the step just taken
     double *logX, *logU, *logG; const double *noise; int *nDone, *statusAcc;                   // logs [T][B][..], noise [T][B][3]
+    double *finX, *finG;                                                                       // state right after the crossing step
 };
 __global__ void lmpc_rollout_advance_kernel(lmpc_dev_params p, int B, int t, lmpc_rollout_state r) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1080,7 +1081,10 @@ __global__ void lmpc_rollout_advance_kernel(lmpc_dev_params p, int B, int t, lmp
     r.uOld[(size_t)b * 2] = u0[0]; r.uOld[(size_t)b * 2 + 1] = u0[1];
     r.hasPred[b] = 1; r.timeStep[b] = t + 1;
     r.statusAcc[b] |= r.status[b] | (bad ? LMPC_ST_NO_SEGMENT : 0);
-    if (r.doneAt[b] < 0 && xo[4] > p.TL) { r.doneAt[b] = t + 1; atomicAdd(r.nDone, 1); }       // lap completed, SysModel.py:45
+    if (r.doneAt[b] < 0 && xo[4] > p.TL) {                                                     // lap completed, SysModel.py:45
+        r.doneAt[b] = t + 1; atomicAdd(r.nDone, 1);
+        for (int j = 0; j < 6; j++) { r.finX[(size_t)b * 6 + j] = xo[j]; r.finG[(size_t)b * 6 + j] = go[j]; }
+    }
 }
 
 // wave-reduction self test (exercised by lmpc_selftest): out[0..2] = sum, max, min of lane-dependent values

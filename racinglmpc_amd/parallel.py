@@ -27,21 +27,25 @@ def _dist():
 
 
 def pack_laps(laps, K, T_max):
-    """laps: list of (x (T,6), u (T,2), x_glob (T,6)).  Keeps the K shortest (ties: lower local index), pads to T_max.
-    Returns (records float64 [K, T_max, 14], lengths int64 [K]); unused slots have length -1."""
+    """laps: list of (x (T,6), u (T,2), x_glob (T,6)[, extra (<=14,)]).  Keeps the K shortest (ties: lower local index),
+    pads to T_max rows + 1 row for `extra` (e.g. the state right after the finish line).
+    Returns (records float64 [K, T_max + 1, 14], lengths int64 [K]); unused slots have length -1."""
     order = sorted(range(len(laps)), key=lambda i: (laps[i][0].shape[0], i))[:K]
-    rec = np.zeros((K, T_max, REC_COLS)); ln = -np.ones(K, dtype=np.int64)
+    rec = np.zeros((K, T_max + 1, REC_COLS)); ln = -np.ones(K, dtype=np.int64)
     for j, i in enumerate(order):
-        x, u, xg = laps[i]
+        x, u, xg = laps[i][0], laps[i][1], laps[i][2]
         T = x.shape[0]
         if T > T_max:
             raise ValueError("lap of %d steps exceeds the exchange record size %d" % (T, T_max))
         rec[j, :T, 0:6] = x; rec[j, :T, 6:8] = u; rec[j, :T, 8:14] = xg; ln[j] = T
+        if len(laps[i]) > 3:
+            e = np.asarray(laps[i][3], float).reshape(-1)
+            rec[j, T_max, :e.shape[0]] = e
     return rec, ln
 
 
 def exchange_laps(laps, K, T_max):
-    """All-gather every rank's K fastest laps and return the global K fastest as [(x, u, x_glob, src_rank, T)],
+    """All-gather every rank's K fastest laps and return the global K fastest as [(x, u, x_glob, src_rank, T, extra)],
     ordered by (T, src_rank, local order) -- identical on every rank."""
     rec, ln = pack_laps(laps, K, T_max)
     dist = _dist()
@@ -62,8 +66,21 @@ def exchange_laps(laps, K, T_max):
     cand.sort()
     out = []
     for T, r, j in cand[:K]:
-        out.append((recs[r, j, :T, 0:6].copy(), recs[r, j, :T, 6:8].copy(), recs[r, j, :T, 8:14].copy(), r, T))
+        out.append((recs[r, j, :T, 0:6].copy(), recs[r, j, :T, 6:8].copy(), recs[r, j, :T, 8:14].copy(), r, T, recs[r, j, T_max].copy()))
     return out
+
+
+def broadcast_array(arr, src=0):
+    """Every rank receives rank `src`'s array (same shape/dtype everywhere)."""
+    dist = _dist()
+    if dist is None:
+        return np.array(arr)
+    import torch
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
 
 
 def allreduce_max(value):

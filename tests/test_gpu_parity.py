@@ -238,7 +238,7 @@ def test_batched_rollouts_full_lap_and_exchange(g):
     Ts = [b[4] for b in best]
     print("rollout lap lengths (best 4 of %d):" % B, Ts)
     assert all(100 < T < 400 for T in Ts)
-    for x, u, xg, src, T in best:
+    for x, u, xg, src, T, extra in best:
         assert x[-1, 4] <= float(g["trackLength"]) + 1.0 and np.abs(x[:, 5]).max() < 0.6        # stayed on (soft-constrained) track
         assert np.abs(u[:, 0]).max() <= 0.5 + 1e-9 and np.abs(u[:, 1]).max() <= 10 + 1e-9       # hard input bounds respected
     ctx.close()
@@ -287,8 +287,28 @@ def test_device_resident_rollouts(g):
             out = self.z[self.t]; self.t += 1; return out
     ro_h.rng = _Replay(noise)
     laps_h = ro_h.run_lap(x0, xLin0, uLin0, max_steps=320)
-    for (xd, ud, gd), (xh, uh, gh) in zip(laps_d, laps_h):
+    for (xd, ud, gd, fin), (xh, uh, gh) in zip(laps_d, laps_h):
         assert xd.shape == xh.shape and 150 < xd.shape[0] < 320
         assert np.abs(xd - xh).max() < 1e-6 and np.abs(ud - uh).max() < 1e-6
     print("device rollouts: lap lengths", [l[0].shape[0] for l in laps_d])
+    ctx.close()
+
+
+def test_lmpc_generations_improve_lap_time(g):
+    """Iterated batched LMPC (device-resident laps, fastest laps fed back, stored laps extended past the finish line):
+    lap times do not get worse from generation to generation and every rollout finishes its lap."""
+    from racinglmpc_amd import rollout
+    B = 32
+    ctx, par = common.make_lmpc_ctx(g, 4, max_batch=B)
+    ro = rollout.BatchedRollouts(ctx, g["track"], seed=21)
+    x0 = np.tile(np.array([0.5, 0, 0, 0, 0, 0.0]), (B, 1)); x0[:, 5] = np.linspace(-0.05, 0.05, B)
+    gen = rollout.LmpcGeneration(ro, B, K=4, T_max=400, ext=40)
+    times = []
+    for it in range(3):
+        best = gen.run(x0, g["SS0"][1:14], g["uSS0"][1:13])
+        assert np.all(ro.last_status == 0), np.unique(ro.last_status)
+        times.append([b[4] for b in best])
+    print("generation lap times (steps):", times)
+    assert max(times[0]) < 300 and times[1][0] <= times[0][0] and times[2][0] <= times[1][0] + 2
+    assert times[2][0] < times[0][0]
     ctx.close()

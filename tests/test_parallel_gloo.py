@@ -21,6 +21,8 @@ for i in range(lo, hi):
     T = 120 + (7 * i) % 23                       # deterministic lap lengths, some ties across ranks
     laps.append((rng.normal(size=(T, 6)) + i, rng.normal(size=(T, 2)), rng.normal(size=(T, 6))))
 best = parallel.exchange_laps(laps, K=4, T_max=160)
+bc = parallel.broadcast_array(np.arange(6.0) + 10 * rank, src=0)
+assert np.array_equal(bc, np.arange(6.0))
 mx = parallel.allreduce_max(float(rank + 1))
 np.savez(os.path.join(sys.argv[2], "rank%d.npz" % rank), lens=np.array([b[4] for b in best]), src=np.array([b[3] for b in best]),
          x0=np.array([b[0][0, 0] for b in best]), chk=np.array([b[0].sum() + b[1].sum() + b[2].sum() for b in best]), mx=mx, lo=lo, hi=hi)
