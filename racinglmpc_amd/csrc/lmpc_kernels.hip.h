@@ -323,7 +323,8 @@ template <int N, int S> struct solve_lds {
     static constexpr int okap = ok0 + 2 * N, orDs = okap + 2 * N, oeta = orDs + 2 * N, oe = oeta + 2 * N;
     static constexpr int oPi = oe + 2 * N, oT = oPi + 64, oMr = oT + 64;
     static constexpr int oRi = oMr + 64, orsq = oRi + 56, oct = orsq + WAVE;
-    static constexpr int oSS = oct + WAVE, oQsel = oSS + 6 * S, oy7 = oQsel + S, oz7 = oy7 + 8, ow7 = oz7 + 8, oPiT = ow7 + 8, osT = oPiT + 36;
+    static constexpr int oMt = oct + WAVE, oWl = oMt + (S > 0 ? 8 * WAVE : 0), oMc = oWl + (S > 0 ? 64 : 0);   // M transposed (col-major, 8 per column), Gram matrix, M c~
+    static constexpr int oSS = oMc + 8, oQsel = oSS + 6 * S, oy7 = oQsel + S, oz7 = oy7 + 8, ow7 = oz7 + 8, oPiT = ow7 + 8, osT = oPiT + 36;
     static constexpr int opar = osT + 8, tot = opar + PAR_TOT;
 };
 
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     double *phi = gam;                                     // gamma is dead (kept in registers) once the backward sweep starts
     double *kap = sm + LL::okap, *rDs = sm + LL::orDs, *eta = sm + LL::oeta, *ee = sm + LL::oe;
     double *Pi = sm + LL::oPi, *Tm = sm + LL::oT, *Mr = sm + LL::oMr;
-    double *Ri = sm + LL::oRi, *rsq = sm + LL::orsq, *ct = sm + LL::oct;
+    double *Ri = sm + LL::oRi, *rsq = sm + LL::orsq, *ct = sm + LL::oct, *Mt = sm + LL::oMt, *Wl = sm + LL::oWl, *McL = sm + LL::oMc;
     double *SS = sm + LL::oSS, *Qsel = sm + LL::oQsel, *y7 = sm + LL::oy7, *z7 = sm + LL::oz7, *w7 = sm + LL::ow7, *PiT = sm + LL::oPiT, *sT = sm + LL::osT;
     double *par = sm + LL::opar;
     const double *Fx = par + PAR_FX, *Fu = par + PAR_FU, *bx = par + PAR_BX, *bu = par + PAR_BU, *Q2 = par + PAR_Q2, *Qf2 = par + PAR_QF2,
@@ -557,25 +558,18 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         double c_t = 0.0;
         if constexpr (term) {
             if (lane < S) c_t = (rl[lane] + h[8 * N + lane]) * rsq[lane];
-            double yy[7];
-#pragma unroll
-            for (int j = 0; j < 7; j++) yy[j] = wsum(mcol[j] * c_t);        // M c~
-            if (lane < 7) {                                                 // y7 = Ri' (M c~) ; sT <- Ri' d0 + y7 (scratch)
-                double v = 0.0;
-#pragma unroll
-                for (int j = 0; j < 7; j++) if (j <= lane) v = fma(Ri[j * 7 + lane], yy[j], v);
-                y7[lane] = v;
-                sT[lane] = Ri[6 * 7 + lane] * (-re_sum) + v;
-            }
+            ct[lane] = c_t;
         }
         __syncthreads();
-        if (lane < 8) {                                         // terminal costate p_N = (rx_N + [Ri (Ri' d0 + y7)]_{0:6}, 0)
-            double v = 0.0;
-            if (lane < 6) {
-                v = rx[N * 6 + lane];
-                if constexpr (term) { for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], sT[j], v); }
+        if constexpr (term) {
+            // M c~ : lane (j, part) adds 8 of the 64 columns, the 8 lanes of a group are summed with DPP
+            double acc = 0.0;
+            if (lg < 7) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc = fma(Mt[(lc + 8 * q) * 8 + lg], ct[lc + 8 * q], acc);
             }
-            pst[N * 8 + lane] = v;
+            acc = sum_over_c(acc);
+            if (lg < 7 && lc == 0) McL[lg] = acc;
         }
         FOR_LANES(i, 8 * N) {                                   // gamma_k = [gx' - Kx' gu' ; -Ku' gu'] = [gx';0] + Phi[6:8,:]' gu'
             const int k = i >> 3, c = i & 7;
@@ -584,6 +578,24 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             v = fma(Phi[k * 64 + 48 + c], gup[2 * k], v);
             v = fma(Phi[k * 64 + 56 + c], gup[2 * k + 1], v);
             gam[i] = v;
+        }
+        __syncthreads();
+        if constexpr (term) {
+            if (lane < 7) {                                     // y7 = Ri' (M c~) ; sT <- Ri' d0 + y7 (scratch)
+                double v = 0.0;
+                for (int j = 0; j <= lane; j++) v = fma(Ri[j * 7 + lane], McL[j], v);
+                y7[lane] = v;
+                sT[lane] = Ri[6 * 7 + lane] * (-re_sum) + v;
+            }
+            __syncthreads();
+        }
+        if (lane < 8) {                                         // terminal costate p_N = (rx_N + [Ri (Ri' d0 + y7)]_{0:6}, 0)
+            double v = 0.0;
+            if (lane < 6) {
+                v = rx[N * 6 + lane];
+                if constexpr (term) { for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], sT[j], v); }
+            }
+            pst[N * 8 + lane] = v;
         }
         __syncthreads();
         TSTAMP(30);
@@ -766,10 +778,32 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             for (int i = 0; i < 7; i++)
 #pragma unroll
                 for (int j = 0; j < 7; j++) { Rr[i][j] = 0.0; Rv[i][j] = 0.0; }
+            // Gram matrix W = M M' (7 x 7, K = 64 columns) on the matrix cores: v_mfma_f64_16x16x4 over 16 K-chunks.
+            // operand layout: lane = 16 k + i holds M[i][4 s + k] for both A and B (W is M times its own transpose);
+            // accumulator: lane l, register r holds W[4 r + l / 16][l % 16].
+#pragma unroll
+            for (int j = 0; j < 7; j++) Mt[lane * 8 + j] = mcol[j];
+            Mt[lane * 8 + 7] = 0.0;
+            __syncthreads();
+            {
+                typedef double v4d __attribute__((ext_vector_type(4)));
+                v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                const int kk = lane >> 4, ii = lane & 15;
+                const bool live = ii < 8;
+#pragma unroll
+                for (int s_ = 0; s_ < 16; s_ += 2) {
+                    double a0 = Mt[(4 * s_ + kk) * 8 + (ii & 7)], a1 = Mt[(4 * (s_ + 1) + kk) * 8 + (ii & 7)];
+                    a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+                }
+                if (ii < 8) { Wl[kk * 8 + ii] = acc0[0] + acc1[0]; Wl[(4 + kk) * 8 + ii] = acc0[1] + acc1[1]; }
+            }
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < 7; i++)
 #pragma unroll
-                for (int j = i; j < 7; j++) Rr[i][j] = wsum(mcol[i] * mcol[j]);          // W (upper)
+                for (int j = i; j < 7; j++) Rr[i][j] = Wl[i * 8 + j];                     // W (upper), uniform broadcast reads
 #pragma unroll
             for (int i = 0; i < 7; i++) {                                                 // Cholesky, row by row
                 double d_ = Rr[i][i];
