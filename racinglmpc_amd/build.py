@@ -4,7 +4,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "lmpc_capi.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "lmpc_kernels.hip.h"), os.path.join(os.path.dirname(_HERE), "include", "lmpc_hip.h")]
+DEPS = [SRC, os.path.join(_HERE, "csrc", "lmpc_kernels.hip.h"), os.path.join(_HERE, "csrc", "lmpc_solve_mw.hip.h"), os.path.join(os.path.dirname(_HERE), "include", "lmpc_hip.h")]
 OUT = os.path.join(_HERE, "liblmpc_hip.so")
 
 

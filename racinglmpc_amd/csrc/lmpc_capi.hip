@@ -2,9 +2,11 @@
 // Owns the device lap stores, work buffers, stream and HIP-event timers; launches the kernels of
 // lmpc_kernels.hip.h.  No CPU compute path exists here: if HIP fails, the call fails.
 #include "lmpc_kernels.hip.h"
+#include "lmpc_solve_mw.hip.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -31,6 +33,8 @@ struct lmpc_ctx {
     int *w_hasPred, *w_tstep, *w_status, *w_iters, *w_rstatus;
     size_t lds_bytes;
     int (*solve_launch)(lmpc_ctx *, int, const lmpc_solve_io &);
+    int (*solve_launch_mw)(lmpc_ctx *, int, const lmpc_solve_io &);   // 4 waves per QP, used for small batches
+    int mw_max_batch;
     int profiling; std::vector<evpair> events; lmpc_stats stats;
     struct lmpc_rollout_session *ro;
 };
@@ -39,11 +43,17 @@ template <int N, int S> static int solve_launch_t(lmpc_ctx *c, int B, const lmpc
     hipLaunchKernelGGL((lmpc_solve_kernel<N, S>), dim3(B), dim3(WAVE), c->lds_bytes, c->stream, c->dp, B, io);
     return LMPC_OK;
 }
+template <int N, int S> static int solve_launch_mw_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
+    hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 4>), dim3(B), dim3(WAVE * 4), c->lds_bytes, c->stream, c->dp, B, io);
+    return LMPC_OK;
+}
 template <int N, int S> static bool try_pick(lmpc_ctx *c, int n, int s) {
     if (n != N || s != S) return false;
     c->lds_bytes = (size_t)solve_lds<N, S>::tot * sizeof(double);
     if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
     c->solve_launch = &solve_launch_t<N, S>;
+    c->solve_launch_mw = &solve_launch_mw_t<N, S>;
     return true;
 }
 static bool pick_solver(lmpc_ctx *c) {
@@ -103,7 +113,12 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     ARGCHK(cfg->track_rows >= 0 && cfg->track_rows <= LMPC_MAX_TRACK_ROWS);
     ARGCHK(cfg->max_batch >= 1 && cfg->max_laps >= 1 && cfg->max_lap_len >= 8);
     lmpc_ctx *c = new lmpc_ctx();
-    c->cfg = *cfg; c->profiling = 0; c->ro = nullptr; memset(&c->stats, 0, sizeof(c->stats));
+    c->cfg = *cfg; c->profiling = 0; c->ro = nullptr;
+    {   // batches that leave SIMDs idle (B <= number of CUs) run the 4-waves-per-QP kernel
+        const char *e = getenv("LMPC_MW_MAX_BATCH"); hipDeviceProp_t prop; int cus = 256;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        c->mw_max_batch = e ? atoi(e) : cus;
+    } memset(&c->stats, 0, sizeof(c->stats));
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) { delete c; return set_err(LMPC_E_HIP, "hipSetDevice", hipGetErrorString(e)); }
     HIPCHK(hipStreamCreate(&c->stream));
@@ -279,7 +294,7 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
     const bool term = c->cfg.numSS_it > 0;
     int rc = refresh_params(c, false, term && (io.mode & 1)); if (rc) return rc;
     ev_begin(c, 1);
-    rc = c->solve_launch(c, B, io);
+    rc = (B <= c->mw_max_batch && !io.tbuf) ? c->solve_launch_mw(c, B, io) : c->solve_launch(c, B, io);
     ev_end(c);
     if (rc) return rc;
     HIPCHK(hipGetLastError());

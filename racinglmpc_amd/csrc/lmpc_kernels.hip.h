@@ -315,11 +315,11 @@ template <int N, int S> struct solve_lds {
     static constexpr int oAB = 0, oC = oAB + 48 * N;                      // AB[k] = [A_k | B_k] (6 x 8), C_k
     static constexpr int ox = oC + 6 * N, ou = ox + 6 * (N + 1), os = ou + 2 * N, olam = os + 2 * N;
     static constexpr int odx = olam + S, odu = odx + 6 * (N + 1), ods = odu + 2 * N, odl = ods + 2 * N;
-    static constexpr int onu = odl + S, odnu = onu + 6 * N;
-    static constexpr int om = odnu + 6 * N, oth = om + M, oh = oth + M, odm = oh + M;
-    static constexpr int orx = odm + M, oru = orx + 6 * (N + 1), ors = oru + 2 * N, orl = ors + 2 * N;
+    static constexpr int onu = odl + S;
+    static constexpr int om = onu + 6 * N, oth = om + M, oh = oth + M, odm = oh;            // dm overwrites h row by row (corrector post), see kernel
+    static constexpr int orx = oh + M, oru = orx + 6 * (N + 1), ors = oru + 2 * N, orl = ors + 2 * N;
     static constexpr int oPhi = orl + S, oPiAll = oPhi + 64 * N, oMi = oPiAll + 64 * N, ogam = oMi + 4 * N, ogup = ogam + 8 * N,
-                         opst = ogup + 2 * N, ok0 = opst + 8 * (N + 1);
+                         opst = ogup + 2 * N, ok0 = opst + 8 * (N + 1), odnu = ogam;              // dnu reuses gamma (dead after the sweeps)
     static constexpr int okap = ok0 + 2 * N, orDs = okap + 2 * N, oeta = orDs + 2 * N, oe = oeta + 2 * N;
     static constexpr int oPi = oe + 2 * N, oT = oPi + 64, oMr = oT + 64;
     static constexpr int oRi = oMr + 64, orsq = oRi + 56, oct = orsq + WAVE;

@@ -1,0 +1,694 @@
+// racinglmpc_amd/csrc/lmpc_solve_mw.hip.h -- multi-wave variant of lmpc_solve_kernel for SMALL batches.
+//
+// Same algorithm and the same LDS layout as lmpc_solve_kernel<N,S> (lmpc_kernels.hip.h), but one QP is worked on by a
+// work-group of NW wavefronts (one per SIMD of a CU).  With B <= #CUs a single wave per QP leaves three SIMDs of every
+// CU idle and the solve is bound by the dependent-issue latency of that one instruction stream; here
+//   * the sequential recursions (terminal Cholesky, Riccati stage loop, register sweeps) stay on wave 0, ordered inside
+//     the wave by s_waitcnt only (no work-group barrier),
+//   * every row-/entry-parallel phase (residuals, barrier bookkeeping, right-hand sides, step lengths, costates, update)
+//     is spread over all NW*64 threads, different loops landing on different waves so that they issue concurrently,
+//   * wave-level reductions are combined across waves through a few LDS slots.
+// The host picks this kernel when B is small (lmpc_capi.hip: pick_solver).
+#pragma once
+#include "lmpc_kernels.hip.h"
+
+#define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int N, int S, int NW>
+__global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params p, int B, lmpc_solve_io io) {
+    extern __shared__ double sm[];
+    using LL = solve_lds<N, S>;
+    constexpr int M = LL::M;
+    constexpr bool term = S > 0;
+    constexpr int NT = WAVE * NW;
+    constexpr int RPL = (M + NT - 1) / NT;                  // inequality rows per thread
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lg = lane >> 3, lc = lane & 7;
+    const bool w0 = wave == 0;
+    double *AB = sm + LL::oAB, *C = sm + LL::oC, *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
+    double *dx = sm + LL::odx, *du = sm + LL::odu, *ds = sm + LL::ods, *dl = sm + LL::odl, *nu = sm + LL::onu, *dnu = sm + LL::odnu;
+    double *m = sm + LL::om, *th = sm + LL::oth, *h = sm + LL::oh, *dm = sm + LL::odm;
+    double *rx = sm + LL::orx, *ru = sm + LL::oru, *rs = sm + LL::ors, *rl = sm + LL::orl;
+    double *Phi = sm + LL::oPhi, *PiAll = sm + LL::oPiAll, *Mi = sm + LL::oMi, *gam = sm + LL::ogam, *gup = sm + LL::ogup, *pst = sm + LL::opst;
+    double *kap = sm + LL::okap, *rDs = sm + LL::orDs, *eta = sm + LL::oeta, *ee = sm + LL::oe;
+    double *Pi = sm + LL::oPi, *Tm = sm + LL::oT, *Mr = sm + LL::oMr;
+    double *Ri = sm + LL::oRi, *rsq = sm + LL::orsq, *ct = sm + LL::oct, *Mt = sm + LL::oMt, *Wl = sm + LL::oWl, *McL = sm + LL::oMc;
+    double *SS = sm + LL::oSS, *Qsel = sm + LL::oQsel, *y7 = sm + LL::oy7, *z7 = sm + LL::oz7, *w7 = sm + LL::ow7, *PiT = sm + LL::oPiT, *sT = sm + LL::osT;
+    double *par = sm + LL::opar;
+    const double *Fx = par + PAR_FX, *Fu = par + PAR_FU, *bx = par + PAR_BX, *bu = par + PAR_BU, *Q2 = par + PAR_Q2, *Qf2 = par + PAR_QF2,
+                 *R2 = par + PAR_R2, *dR2 = par + PAR_DR2, *T2p = par + PAR_T2, *xRef = par + PAR_XREF;
+    __shared__ double red[12 * 4];                           // cross-wave reduction slots
+    __shared__ double phi_sh[8 * N];
+    __shared__ int st_sh, bad_sh;
+    __shared__ int sel_start[LMPC_MAX_USED_LAPS];
+    double *phi = phi_sh;
+    if (tid == 0) { st_sh = 0; bad_sh = 0; }
+    // stage the parameter block
+    if (tid < 12) par[PAR_FX + tid] = p.Fx[tid];
+    if (tid < 8) par[PAR_FU + tid] = p.Fu[tid];
+    if (tid < 2) { par[PAR_BX + tid] = p.bx[tid]; par[PAR_DR2 + tid] = p.dR2[tid]; }
+    if (tid < 4) { par[PAR_BU + tid] = p.bu[tid]; par[PAR_R2 + tid] = p.R2[tid]; }
+    if (tid < 36) { par[PAR_Q2 + tid] = p.Q2[tid]; par[PAR_QF2 + tid] = p.Qf2[tid]; }
+    if (tid < 6) { par[PAR_T2 + tid] = p.T2[tid]; par[PAR_XREF + tid] = p.xRef[tid]; }
+    if (tid == 0) { par[PAR_AS] = p.a_s; par[PAR_CS] = p.c_s; }
+    __syncthreads();
+    const double a_s = par[PAR_AS], c_s = par[PAR_CS];
+
+    auto red_put = [&](int slot, double v) { if (lane == 0) red[slot * 4 + wave] = v; };
+    auto red_sum = [&](int slot) { double r = red[slot * 4]; for (int w = 1; w < NW; w++) r += red[slot * 4 + w]; return r; };
+    auto red_max = [&](int slot) { double r = red[slot * 4]; for (int w = 1; w < NW; w++) r = fmax(r, red[slot * 4 + w]); return r; };
+    auto red_min = [&](int slot) { double r = red[slot * 4]; for (int w = 1; w < NW; w++) r = fmin(r, red[slot * 4 + w]); return r; };
+
+    // ------------------------------------------------------------------------------------------------
+    // K2: safe-set selection, one lap per wave.  LMPC.addTerminalComponents :392-412 and selectPoints :478-514.
+    // ------------------------------------------------------------------------------------------------
+    if constexpr (term) {
+        if (io.mode & 1) {
+            double ztv[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) ztv[j] = io.zt[(size_t)b * 6 + j];
+            const double x04 = io.x0[(size_t)b * 6 + 4];
+            if (ztv[4] - x04 > p.TL / 2) ztv[4] = fmax(ztv[4] - p.TL, 0.0);        // :392-393
+            if (io.ztUsed && tid < 6) { double v = ztv[0];
+#pragma unroll
+                for (int j = 1; j < 6; j++) if (tid == j) v = ztv[j];
+                io.ztUsed[(size_t)b * 6 + tid] = v; }
+            const int hasPred = io.hasPred ? io.hasPred[b] : 0;                     // Q-function shift bookkeeping (:502-512)
+            int crossed = 0;
+            if (hasPred) {
+                int c_ = 0;
+                if (lane <= N) c_ = (io.xPredPrev[((size_t)b * (N + 1) + lane) * 6 + 4] > p.TL) ? 1 : 0;
+                crossed = (int)__popcll(__ballot(c_));
+            }
+            const int tstep = io.timeStep ? io.timeStep[b] : 0;
+            const int ppl = p.ppl, npw = ppl + 1;                                   // numSS_Points/numSS_it + 1 (=13)
+            for (int l = wave; l < p.L; l += NW) {
+                const double *base = p.sstore + (size_t)p.sslot[l] * LMPC_COLS * p.lap_stride;
+                const int T = p.sslen[l], ls = p.lap_stride;
+                double best = INFINITY; int bi = 0x7fffffff;
+                for (int r = lane; r < T; r += WAVE) {
+                    double nrm = fabs(base[r] - ztv[0]);                            // la.norm(x - zt, 1, axis=1)
+                    nrm = nrm + fabs(base[ls + r] - ztv[1]);
+                    nrm = nrm + fabs(base[2 * ls + r] - ztv[2]);
+                    nrm = nrm + fabs(base[3 * ls + r] - ztv[3]);
+                    nrm = nrm + fabs(base[4 * ls + r] - ztv[4]);
+                    nrm = nrm + fabs(base[5 * ls + r] - ztv[5]);
+                    if (nrm < best) { best = nrm; bi = r; }
+                }
+                wave_argmin(best, bi);                                              // np.argmin: first minimum
+                const int MinNorm = bi;
+                const int start = ((double)MinNorm - (double)npw / 2.0 >= 0.0) ? MinNorm - npw / 2 : MinNorm;   // :492-495
+                if (lane == 0) { sel_start[l] = start; if (start + npw > T) atomicOr(&st_sh, LMPC_ST_WINDOW); }
+                double shift = 0.0;                                                 // :502-512
+                if (hasPred && crossed > 0) {
+                    if (p.sslapid[l] < p.cur_it - 1) shift = base[8 * ls];
+                    else shift = (double)tstep + (double)(N - crossed);
+                }
+                if (lane < ppl) {
+                    int r0 = start + lane; r0 = r0 > T - 1 ? T - 1 : r0;
+                    int r1 = start + lane + 1; r1 = r1 > T - 1 ? T - 1 : r1;
+                    const int col = l * ppl + lane;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        const double v = base[j * ls + r0];
+                        SS[j * S + col] = v;
+                        if (io.ssSelOut) io.ssSelOut[((size_t)b * S + col) * 6 + j] = v;
+                        if (io.succOut) io.succOut[((size_t)b * S + col) * 6 + j] = base[j * ls + r1];
+                    }
+                    if (io.succUOut) { io.succUOut[((size_t)b * S + col) * 2] = base[6 * ls + r1]; io.succUOut[((size_t)b * S + col) * 2 + 1] = base[7 * ls + r1]; }
+                    const double qv = base[8 * ls + r0] + shift;
+                    Qsel[col] = qv;
+                    if (io.qSelOut) io.qSelOut[(size_t)b * S + col] = qv;
+                }
+            }
+        } else {
+            for (int c = tid; c < S; c += NT) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) SS[j * S + c] = io.ssSelIn[((size_t)b * S + c) * 6 + j];
+                Qsel[c] = io.qSelIn[(size_t)b * S + c];
+            }
+        }
+        __syncthreads();
+    }
+    if (!(io.mode & 2)) { if (tid == 0) io.status[b] = st_sh; return; }
+
+    // ------------------------------------------------------------------------------------------------
+    // K3: QP solve (same formulation as lmpc_solve_kernel).
+    // ------------------------------------------------------------------------------------------------
+    for (int i = tid; i < 36 * N; i += NT) { const int k = i / 36, r = (i % 36) / 6, c = i % 6; AB[k * 48 + r * 8 + c] = io.A[(size_t)b * 36 * N + i]; }
+    for (int i = tid; i < 12 * N; i += NT) { const int k = i / 12, r = (i % 12) >> 1, c = i & 1; AB[k * 48 + r * 8 + 6 + c] = io.Bm[(size_t)b * 12 * N + i]; }
+    for (int i = tid; i < 6 * N; i += NT) { C[i] = io.C[(size_t)b * 6 * N + i]; nu[i] = 0.0; }
+    if (tid < 6) x[tid] = io.x0[(size_t)b * 6 + tid];
+    for (int i = tid; i < 2 * N; i += NT) u[i] = 0.0;
+    const double uOld0 = io.uOld[(size_t)b * 2 + 0], uOld1 = io.uOld[(size_t)b * 2 + 1];
+    __syncthreads();
+    if (w0) {
+#pragma unroll 1
+        for (int k = 0; k < N; k++) {                      // strictly interior start: u = 0, x by roll-out
+            if (lane < 6) {
+                double v = C[k * 6 + lane];
+#pragma unroll
+                for (int j = 0; j < 6; j++) v = fma(AB[k * 48 + lane * 8 + j], x[k * 6 + j], v);
+                x[(k + 1) * 6 + lane] = v;
+            }
+            WSYNC();
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * N; i += NT) {
+        const int k = i >> 1, j = i & 1; double f = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) f = fma(Fx[j * 6 + c], x[k * 6 + c], f);
+        s[i] = fmax(f - bx[j], 0.0) + 1.0;
+    }
+    double qmax = 0.0;
+    if constexpr (term) {
+        for (int c = lane; c < S; c += WAVE) { if (w0) lam[c] = 1.0 / (double)S; qmax = fmax(qmax, fabs(Qsel[c])); }
+        qmax = wmax(qmax);                                  // every wave computes the same value
+    }
+    const double mu0 = fmax(1.0, 0.01 * (term ? qmax : 1.0));
+    if (tid < 4 && !(bu[tid] > 0.0)) atomicOr(&st_sh, LMPC_ST_NOT_INTERIOR);
+    double eta_m = 0.0;
+    __syncthreads();
+
+    auto rowF = [&](int r, const double *xx, const double *uu, const double *ss_, const double *ll) -> double {
+        if (r < 2 * N) { const int k = r >> 1, j = r & 1; double f = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) f = fma(Fx[j * 6 + c], xx[k * 6 + c], f);
+            return f - ss_[r]; }
+        if (r < 6 * N) { const int q = r - 2 * N, k = q >> 2, j = q & 3; return Fu[j * 2] * uu[k * 2] + Fu[j * 2 + 1] * uu[k * 2 + 1]; }
+        if (r < 8 * N) return -ss_[r - 6 * N];
+        return -ll[r - 8 * N];
+    };
+    auto rowb = [&](int r) -> double { if (r < 2 * N) return bx[r & 1]; if (r < 6 * N) return bu[(r - 2 * N) & 3]; return 0.0; };
+
+    double t_r[RPL], rt_r[RPL], tp_r[RPL], dt_r[RPL];      // per-thread row state (row = tid + NT j)
+#pragma unroll
+    for (int j = 0; j < RPL; j++) {
+        const int r = tid + NT * j;
+        t_r[j] = 1.0; rt_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
+        if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; m[r] = mu0 / tt; }
+    }
+    // loop-invariant pieces of the stage Hessian W for this lane's (a, c) = (lg, lc) tile entry (used by wave 0)
+    const bool w_xx = lg < 6 && lc < 6, w_uu = lg >= 6 && lc >= 6;
+    const double wq2 = w_xx ? Q2[lg * 6 + lc] : 0.0;
+    const double wf0 = w_xx ? Fx[lg] * Fx[lc] : 0.0, wf1 = w_xx ? Fx[6 + lg] * Fx[6 + lc] : 0.0;
+    double wr2 = 0.0, wfu[4] = {0.0, 0.0, 0.0, 0.0};
+    if (w_uu) {
+        wr2 = R2[(lg - 6) * 2 + (lc - 6)] + (lg == lc ? dR2[lg - 6] : 0.0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) wfu[j] = Fu[j * 2 + (lg - 6)] * Fu[j * 2 + (lc - 6)];
+    }
+    double ph[N];
+    double mcol[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) mcol[j] = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; k++) ph[k] = 0.0;
+    __syncthreads();
+
+    // thread ranges of the concurrent loops (different loops start on different waves)
+    constexpr int O1 = NW > 1 ? WAVE : 0, O2 = NW > 2 ? 2 * WAVE : O1, O3 = NW > 3 ? 3 * WAVE : O2;
+#define FOR_OFF(i, n, off) for (int i = (tid >= (off) ? tid - (off) : tid - (off) + NT); i < (n); i += NT)
+
+    // one Newton-system solve for the right-hand side currently in (rx,ru,rs,rl,h); result in dx,du,ds,dl
+    auto kkt_solve = [&](double re_sum) {
+        FOR_OFF(i, 2 * N, O1) {                                 // slack elimination, per lane row (k,j)
+            const double hl = h[i], hs = h[6 * N + i];
+            const double e_ = -(rs[i] + hl + hs);
+            ee[i] = e_; eta[i] = hl + th[i] * e_ * rDs[i];
+        }
+        FOR_OFF(i, 2 * N, O2) {                                 // gu' = ru - Fu' h_u
+            const int k = i >> 1, c = i & 1; double v = ru[i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v -= Fu[j * 2 + c] * h[2 * N + 4 * k + j];
+            gup[i] = v;
+        }
+        double c_t = 0.0;
+        if constexpr (term) {
+            if (w0) {
+                if (lane < S) c_t = (rl[lane] + h[8 * N + lane]) * rsq[lane];
+                ct[lane] = c_t;
+            }
+        }
+        __syncthreads();
+        if (w0) {
+            if constexpr (term) {
+                double acc = 0.0;                               // M c~ : lane (j, part) adds 8 of the 64 columns
+                if (lg < 7) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) acc = fma(Mt[(lc + 8 * q) * 8 + lg], ct[lc + 8 * q], acc);
+                }
+                acc = sum_over_c(acc);
+                if (lg < 7 && lc == 0) McL[lg] = acc;
+                WSYNC();
+                if (lane < 7) {                                 // y7 = Ri' (M c~) ; sT <- Ri' d0 + y7 (scratch)
+                    double v = 0.0;
+                    for (int j = 0; j <= lane; j++) v = fma(Ri[j * 7 + lane], McL[j], v);
+                    y7[lane] = v;
+                    sT[lane] = Ri[6 * 7 + lane] * (-re_sum) + v;
+                }
+                WSYNC();
+            }
+            if (lane < 8) {                                     // terminal costate p_N
+                double v = 0.0;
+                if (lane < 6) {
+                    v = rx[N * 6 + lane];
+                    if constexpr (term) { for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], sT[j], v); }
+                }
+                pst[N * 8 + lane] = v;
+            }
+        }
+        FOR_OFF(i, 8 * N, O1) {                                 // gamma_k = [gx';0] + Phi[6:8,:]' gu'
+            const int k = i >> 3, c = i & 7;
+            double v = 0.0;
+            if (c < 6) { v = rx[k * 6 + c]; v -= Fx[c] * eta[2 * k] + Fx[6 + c] * eta[2 * k + 1]; }
+            v = fma(Phi[k * 64 + 48 + c], gup[2 * k], v);
+            v = fma(Phi[k * 64 + 56 + c], gup[2 * k + 1], v);
+            gam[i] = v;
+        }
+        __syncthreads();
+        if (w0) {   // backward sweep p_k = Phi_k' p_{k+1} + gamma_k in registers (see lmpc_solve_kernel)
+            double gm[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) gm[k] = (k & 1) ? gam[k * 8 + lg] : gam[k * 8 + lc];
+            double pv = ((N - 1) & 1) ? pst[N * 8 + lc] : pst[N * 8 + lg];
+#pragma unroll
+            for (int k = N - 1; k >= 0; k--) {
+                double pr = ph[k] * pv;
+                if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; if (lc == 0) pst[k * 8 + lg] = pv; }
+                else { pr = sum_over_g(pr); pv = pr + gm[k]; if (lg == 0) pst[k * 8 + lc] = pv; }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 8 * N; i += NT) {                 // phi_k = [-B k0 ; -k0], k0_k = Mi_k (gu' + B' p_x + p_u) recomputed per entry
+            const int k = i >> 3, c = i & 7;
+            double w0_ = gup[2 * k] + pst[(k + 1) * 8 + 6], w1_ = gup[2 * k + 1] + pst[(k + 1) * 8 + 7];
+#pragma unroll
+            for (int j = 0; j < 6; j++) { w0_ = fma(AB[k * 48 + j * 8 + 6], pst[(k + 1) * 8 + j], w0_); w1_ = fma(AB[k * 48 + j * 8 + 7], pst[(k + 1) * 8 + j], w1_); }
+            const double k00 = Mi[k * 4] * w0_ + Mi[k * 4 + 1] * w1_, k01 = Mi[k * 4 + 2] * w0_ + Mi[k * 4 + 3] * w1_;
+            phi[i] = c < 6 ? -(AB[k * 48 + c * 8 + 6] * k00 + AB[k * 48 + c * 8 + 7] * k01) : (c == 6 ? -k00 : -k01);
+        }
+        if (tid < 6) dx[tid] = 0.0;
+        __syncthreads();
+        if (w0) {   // forward sweep xi_{k+1} = Phi_k xi_k + phi_k in registers
+            double fm[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
+            double xi = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                double pr = ph[k] * xi;
+                int idx;
+                if (k & 1) { pr = sum_over_g(pr); idx = lc; } else { pr = sum_over_c(pr); idx = lg; }
+                xi = pr + fm[k];
+                const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
+                if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
+            }
+        }
+        __syncthreads();
+        FOR_OFF(i, 2 * N, O1) {
+            const int k = i >> 1, j = i & 1; double f = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) f = fma(Fx[j * 6 + c], dx[k * 6 + c], f);
+            ds[i] = (th[i] * f + ee[i]) * rDs[i];
+        }
+        if constexpr (term) {
+            if (w0) {
+                if (lane < 7) {                                 // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum)
+                    double v = y7[lane];
+                    for (int j = 0; j <= lane; j++) v = fma(Ri[j * 7 + lane], j < 6 ? dx[N * 6 + j] : -re_sum, v);
+                    z7[lane] = v;
+                }
+                WSYNC();
+                if (lane < 7) {                                 // omega' = Ri z7
+                    double v = 0.0;
+                    for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], z7[j], v);
+                    w7[lane] = v;
+                }
+                WSYNC();
+                double v = -c_t;                                // v = -c~ + M' omega'
+#pragma unroll
+                for (int j = 0; j < 7; j++) v = fma(mcol[j], w7[j], v);
+                if (lane < S) dl[lane] = v * rsq[lane];
+            }
+        }
+        __syncthreads();
+    };
+
+    int it = 0, converged = 0, sep = 0;
+    double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0;
+    const double qscale = fmax(1.0, qmax);
+#pragma unroll 1
+    for (it = 0; it <= p.max_iter; it++) {
+        // ---- slacks of the inequality rows, terminal slack --------------------------------------------
+        double gsum = 0.0, rmax = 0.0, remax = 0.0;
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            const int r = tid + NT * j;
+            if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; rt_r[j] = 1.0 / tt; gsum = fma(tt, m[r], gsum); }
+        }
+        if constexpr (term) { if (wave == NW - 1) ss_times<S>(SS, lam, x + N * 6, sT, lane); }
+        __syncthreads();
+        // ---- residuals (different loops on different waves) --------------------------------------------
+        for (int i = tid; i < 6 * (N + 1); i += NT) {
+            const int k = i / 6, c = i % 6; double v = 0.0;
+            if (k >= 1) {
+                const double *Qk = k < N ? Q2 : Qf2;
+#pragma unroll
+                for (int j = 0; j < 6; j++) v = fma(Qk[c * 6 + j], x[k * 6 + j] - xRef[j], v);
+                v += nu[(k - 1) * 6 + c];
+                if (k < N) {
+                    v += Fx[c] * m[2 * k] + Fx[6 + c] * m[2 * k + 1];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) v -= AB[k * 48 + j * 8 + c] * nu[k * 6 + j];
+                } else if (term) v -= T2p[c] * sT[c];
+                rmax = fmax(rmax, fabs(v));
+            }
+            rx[i] = v;
+        }
+        FOR_OFF(i, 2 * N, O2) {
+            const int k = i >> 1, c = i & 1;
+            const double up = k > 0 ? u[(k - 1) * 2 + c] : (c == 0 ? uOld0 : uOld1);
+            double v = R2[c * 2] * u[k * 2] + R2[c * 2 + 1] * u[k * 2 + 1] + dR2[c] * (u[i] - up);
+            if (k < N - 1) v += dR2[c] * (u[i] - u[(k + 1) * 2 + c]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) v = fma(Fu[j * 2 + c], m[2 * N + 4 * k + j], v);
+#pragma unroll
+            for (int j = 0; j < 6; j++) v -= AB[k * 48 + j * 8 + 6 + c] * nu[k * 6 + j];
+            ru[i] = v; rmax = fmax(rmax, fabs(v));
+            const double vs = a_s * s[i] + c_s - m[i] - m[6 * N + i];
+            rs[i] = vs; rmax = fmax(rmax, fabs(vs));
+        }
+        double lsum = 0.0;
+        if constexpr (term) {
+            FOR_OFF(c, S, O3) {
+                double v = Qsel[c] - m[8 * N + c] + eta_m;
+#pragma unroll
+                for (int j = 0; j < 6; j++) v = fma(SS[j * S + c], T2p[j] * sT[j], v);
+                rl[c] = v; rmax = fmax(rmax, fabs(v)); lsum += lam[c];
+            }
+        }
+        FOR_OFF(i, 6 * N, O1 + 16) {                             // dynamics residual (monitoring only)
+            const int k = i / 6, c = i % 6;
+            double v = x[(k + 1) * 6 + c] - C[i] - AB[k * 48 + c * 8 + 6] * u[k * 2] - AB[k * 48 + c * 8 + 7] * u[k * 2 + 1];
+#pragma unroll
+            for (int j = 0; j < 6; j++) v -= AB[k * 48 + c * 8 + j] * x[k * 6 + j];
+            remax = fmax(remax, fabs(v));
+        }
+        red_put(0, wsum(gsum)); red_put(1, wmax(rmax)); red_put(2, wsum(lsum)); red_put(3, wmax(remax));
+        __syncthreads();
+        gap = red_sum(0) / (double)M;
+        rdn = red_max(1);
+        const double re_sum = term ? red_sum(2) - 1.0 : 0.0;
+        ren = fmax(red_max(3), fabs(re_sum));
+        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res) { converged = 1; break; }
+        if (gap_prev >= 0.0) sep = gap > 0.3 * gap_prev;
+        gap_prev = gap;
+        if (it == p.max_iter) break;
+        if (!(gap == gap) || !(rdn == rdn)) { if (tid == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
+
+        // ---- barrier weights ----------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < RPL; j++) { const int r = tid + NT * j; if (r < M) th[r] = m[r] * rt_r[j]; }
+        __syncthreads();
+        FOR_OFF(i, 2 * N, O1) {
+            const double d_ = 1.0 / (a_s + th[i] + th[6 * N + i]);
+            rDs[i] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
+        }
+        FOR_OFF(r, M, O2) h[r] = m[r];                           // predictor right-hand side: h = mu
+        // ---- factorisation: wave 0 alone, ordered by s_waitcnt ---------------------------------------------
+        if (w0) {
+            int numeric_bad = 0;
+            if constexpr (term) {
+#pragma unroll
+                for (int j = 0; j < 7; j++) mcol[j] = 0.0;
+                if (lane < S) {
+                    const double rs_ = 1.0 / sqrt(th[8 * N + lane] + p.reg); rsq[lane] = rs_;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) mcol[j] = SS[j * S + lane] * rs_;
+                    mcol[6] = rs_;
+                } else {
+                    rsq[lane] = 1.0;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = 1.0 / sqrt(T2p[j]);
+                }
+                double Rr[7][7], Rv[7][7], rinv[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++)
+#pragma unroll
+                    for (int j = 0; j < 7; j++) { Rr[i][j] = 0.0; Rv[i][j] = 0.0; }
+#pragma unroll
+                for (int j = 0; j < 7; j++) Mt[lane * 8 + j] = mcol[j];
+                Mt[lane * 8 + 7] = 0.0;
+                WSYNC();
+                {   // Gram matrix W = M M' on the matrix cores (see lmpc_solve_kernel)
+                    typedef double v4d __attribute__((ext_vector_type(4)));
+                    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                    const int kk = lane >> 4, ii = lane & 15;
+                    const bool live = ii < 8;
+#pragma unroll
+                    for (int s_ = 0; s_ < 16; s_ += 2) {
+                        double a0 = Mt[(4 * s_ + kk) * 8 + (ii & 7)], a1 = Mt[(4 * (s_ + 1) + kk) * 8 + (ii & 7)];
+                        a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0;
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+                    }
+                    if (ii < 8) { Wl[kk * 8 + ii] = acc0[0] + acc1[0]; Wl[(4 + kk) * 8 + ii] = acc0[1] + acc1[1]; }
+                }
+                WSYNC();
+#pragma unroll
+                for (int i = 0; i < 7; i++)
+#pragma unroll
+                    for (int j = i; j < 7; j++) Rr[i][j] = Wl[i * 8 + j];
+#pragma unroll
+                for (int i = 0; i < 7; i++) {                                                 // Cholesky, row by row
+                    double d_ = Rr[i][i];
+#pragma unroll
+                    for (int k = 0; k < i; k++) d_ = fma(-Rr[k][i], Rr[k][i], d_);
+                    if (!(d_ > 0.0)) { numeric_bad = 1; d_ = 1.0; }
+                    const double rii = sqrt(d_); rinv[i] = 1.0 / rii; Rr[i][i] = rii;
+#pragma unroll
+                    for (int j = i + 1; j < 7; j++) {
+                        double v = Rr[i][j];
+#pragma unroll
+                        for (int k = 0; k < i; k++) v = fma(-Rr[k][i], Rr[k][j], v);
+                        Rr[i][j] = v * rinv[i];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 7; j++) {                                                 // Ri = R^-1 (upper)
+                    Rv[j][j] = rinv[j];
+#pragma unroll
+                    for (int i = j - 1; i >= 0; i--) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int k = i + 1; k <= j; k++) v = fma(-Rr[i][k], Rv[k][j], v);
+                        Rv[i][j] = v * rinv[i];
+                    }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 7; i++)
+#pragma unroll
+                        for (int j = 0; j < 7; j++) Ri[i * 7 + j] = Rv[i][j];
+                }
+                WSYNC();
+                if (lane < 36) {                                 // Pi_term = (Ri Ri')[0:6,0:6]
+                    const int i = lane / 6, j = lane % 6; double v = 0.0;
+                    for (int k = (i > j ? i : j); k < 7; k++) v = fma(Ri[i * 7 + k], Ri[j * 7 + k], v);
+                    PiT[lane] = v;
+                }
+                WSYNC();
+            }
+            { double v = 0.0; if (lg < 6 && lc < 6) v = Qf2[lg * 6 + lc] + (term ? PiT[lg * 6 + lc] : 0.0); Pi[lane] = v; }
+            WSYNC();
+            __builtin_amdgcn_s_barrier();                        // B_KAP: pairs with the helpers' barrier below; kap / rDs written by another wave are complete
+#pragma unroll 1
+            for (int k = N - 1; k >= 0; k--) {
+                const double *ABk = AB + k * 48;
+                {   // T = Pi Ar
+                    double v = lc >= 6 ? Pi[lg * 8 + lc] : 0.0;
+#pragma unroll
+                    for (int l = 0; l < 6; l++) v = fma(Pi[lg * 8 + l], ABk[l * 8 + lc], v);
+                    Tm[lane] = v;
+                }
+                WSYNC();
+                {   // Mr = Ar' T + W
+                    double v = lg >= 6 ? Tm[lane] : 0.0;
+#pragma unroll
+                    for (int l = 0; l < 6; l++) v = fma(ABk[l * 8 + lg], Tm[l * 8 + lc], v);
+                    const double wx = wq2 + kap[2 * k] * wf0 + kap[2 * k + 1] * wf1;
+                    double wu = wr2;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) wu = fma(th[2 * N + 4 * k + j], wfu[j], wu);
+                    v += w_xx ? wx : (w_uu ? wu : 0.0);
+                    Mr[lane] = v;
+                }
+                WSYNC();
+                {   // eliminate u_k
+                    const double m00 = Mr[54], m01 = Mr[55], m10 = Mr[62], m11 = Mr[63];
+                    const double det = m00 * m11 - m01 * m10;
+                    if (!(det > 0.0) || !(m00 > 0.0)) numeric_bad = 1;
+                    const double rdet = 1.0 / det;
+                    const double i00 = m11 * rdet, i01 = -m01 * rdet, i10 = -m10 * rdet, i11 = m00 * rdet;
+                    double K0, K1;
+                    if (lc < 6) { const double a6 = Mr[48 + lc], a7 = Mr[56 + lc]; K0 = i00 * a6 + i01 * a7; K1 = i10 * a6 + i11 * a7; }
+                    else { const double d2 = dR2[lc - 6]; K0 = -(lc == 6 ? i00 : i01) * d2; K1 = -(lc == 6 ? i10 : i11) * d2; }
+                    double mau0, mau1, base, top, be0, be1;
+                    if (lg < 6) { mau0 = Mr[lg * 8 + 6]; mau1 = Mr[lg * 8 + 7]; base = lc < 6 ? Mr[lane] : 0.0; top = lc < 6 ? ABk[lg * 8 + lc] : 0.0; be0 = ABk[lg * 8 + 6]; be1 = ABk[lg * 8 + 7]; }
+                    else { const double d2 = dR2[lg - 6]; mau0 = lg == 6 ? -d2 : 0.0; mau1 = lg == 7 ? -d2 : 0.0; base = (lc == lg) ? d2 : 0.0; top = 0.0; be0 = lg == 6 ? 1.0 : 0.0; be1 = lg == 7 ? 1.0 : 0.0; }
+                    const double pn = base - mau0 * K0 - mau1 * K1;
+                    Pi[lane] = pn; PiAll[k * 64 + lane] = pn;
+                    Phi[k * 64 + lane] = top - be0 * K0 - be1 * K1;
+                    if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 1 ? i01 : (lane == 2 ? i10 : i11));
+                }
+                WSYNC();
+            }
+            if (numeric_bad && lane == 0) bad_sh = 1;
+#pragma unroll
+            for (int k = 0; k < N; k++) ph[k] = (k & 1) ? Phi[k * 64 + lc * 8 + lg] : Phi[k * 64 + lg * 8 + lc];
+        } else {
+            WSYNC();
+            __builtin_amdgcn_s_barrier();                        // B_KAP (helpers): their kap / rDs / h writes are complete
+        }
+        __syncthreads();
+        if (bad_sh) { if (tid == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
+
+        // ---- predictor (affine scaling) direction ----------------------------------------------------------
+        kkt_solve(re_sum);
+        double apmax = 1.0, admax = 1.0, dma_r[RPL];
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            const int r = tid + NT * j; dma_r[j] = 0.0;
+            if (r < M) {
+                const double dta = -rowF(r, dx, du, ds, dl), mr = m[r];
+                const double dma = -mr - th[r] * dta;
+                dt_r[j] = dta; dma_r[j] = dma;
+                if (dta < 0.0) apmax = fmin(apmax, -t_r[j] / dta);
+                if (dma < 0.0) admax = fmin(admax, -mr / dma);
+            }
+        }
+        red_put(4, wmin(apmax)); red_put(5, wmin(admax));
+        __syncthreads();
+        apmax = red_min(4); admax = red_min(5);
+        if (!sep) { apmax = fmin(apmax, admax); admax = apmax; }
+        double gaff = 0.0;
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            const int r = tid + NT * j;
+            if (r < M) { gaff = fma(t_r[j] + apmax * dt_r[j], m[r] + admax * dma_r[j], gaff); tp_r[j] = dt_r[j] * dma_r[j]; }
+        }
+        red_put(6, wsum(gaff));
+        __syncthreads();
+        gaff = red_sum(6) / (double)M;
+        double sig = gaff / gap; sig = sig * sig * sig;
+        const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);
+        // ---- corrector ---------------------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < RPL; j++) { const int r = tid + NT * j; if (r < M) h[r] = m[r] + (tp_r[j] - tgt) * rt_r[j]; }
+        __syncthreads();
+        kkt_solve(re_sum);
+        double apx = INFINITY, adx = INFINITY;
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            const int r = tid + NT * j;
+            if (r < M) {
+                const double dtt = -rowF(r, dx, du, ds, dl), mr = m[r];
+                const double dmm = -h[r] - th[r] * dtt;
+                dm[r] = dmm;
+                if (dtt < 0.0) apx = fmin(apx, -t_r[j] / dtt);
+                if (dmm < 0.0) adx = fmin(adx, -mr / dmm);
+            }
+        }
+        red_put(7, wmin(apx)); red_put(8, wmin(adx));
+        if constexpr (term) { if (wave == NW - 1) ss_times<S>(SS, dl, dx + N * 6, w7, lane); }          // d s_T
+        __syncthreads();
+        double al = fmin(1.0, 0.995 * red_min(7)), ald = fmin(1.0, 0.995 * red_min(8));
+        if (!sep) { al = fmin(al, ald); ald = al; }
+        // ---- multipliers of the equality rows (costates) -------------------------------------------------
+        for (int i = tid; i < 6 * N; i += NT) {
+            const int k = i / 6 + 1, c = i % 6;
+            double g;
+            if (k == N) {
+                g = rx[N * 6 + c];
+#pragma unroll
+                for (int j = 0; j < 6; j++) g = fma(Qf2[c * 6 + j], dx[N * 6 + j], g);
+                if constexpr (term) g -= T2p[c] * w7[c];
+            } else {
+                g = pst[k * 8 + c];
+#pragma unroll
+                for (int j = 0; j < 6; j++) g = fma(PiAll[k * 64 + c * 8 + j], dx[k * 6 + j], g);
+                g = fma(PiAll[k * 64 + c * 8 + 6], du[(k - 1) * 2], g);
+                g = fma(PiAll[k * 64 + c * 8 + 7], du[(k - 1) * 2 + 1], g);
+            }
+            dnu[i] = -g;
+        }
+        double deta = 0.0;
+        if constexpr (term) {
+            if (wave == NW - 1) {
+                double v = 0.0;
+                if (lane < S) { v = -rl[lane] + dm[8 * N + lane];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) v -= SS[j * S + lane] * T2p[j] * w7[j]; }
+                v = wsum(v) / (double)S;
+                if (lane == 0) red[9 * 4] = v;
+            }
+        }
+        __syncthreads();
+        if constexpr (term) deta = red[9 * 4];
+        // ---- step ------------------------------------------------------------------------------------------
+        for (int i = tid; i < 6 * (N + 1); i += NT) x[i] = fma(al, dx[i], x[i]);
+        FOR_OFF(i, 2 * N, O1) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
+        if constexpr (term) { FOR_OFF(c, S, O2) lam[c] = fma(al, dl[c], lam[c]); }
+        for (int r = tid; r < M; r += NT) m[r] = fma(ald, dm[r], m[r]);
+        FOR_OFF(i, 6 * N, O3) nu[i] = fma(ald, dnu[i], nu[i]);
+        eta_m = fma(ald, deta, eta_m);
+        __syncthreads();
+    }
+    if (!converged && tid == 0 && !(st_sh & LMPC_ST_NUMERIC)) atomicOr(&st_sh, LMPC_ST_MAXITER);
+    __syncthreads();
+
+    // ---- unpackSolution (:364-379) and feasibleStateInput (:382-384) -------------------------------------
+    for (int i = tid; i < 6 * (N + 1); i += NT) io.xPred[(size_t)b * 6 * (N + 1) + i] = x[i];
+    for (int i = tid; i < 2 * N; i += NT) { io.uPred[(size_t)b * 2 * N + i] = u[i]; if (io.slack) io.slack[(size_t)b * 2 * N + i] = s[i]; }
+    if (io.mu) for (int r = tid; r < M; r += NT) io.mu[(size_t)b * M + r] = m[r];
+    if constexpr (term) {
+        if (io.lambda) for (int c = tid; c < S; c += NT) io.lambda[(size_t)b * S + c] = lam[c];
+        if (tid < 6 && io.sTerm) {
+            double v = -x[N * 6 + tid];
+            for (int c = 0; c < S; c++) v = fma(SS[tid * S + c], lam[c], v);
+            io.sTerm[(size_t)b * 6 + tid] = v;
+        }
+        if (w0 && (io.mode & 1) && (io.ztNext || io.ztuNext)) {
+            double acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = 0.0;
+            if (lane < S) {
+                const int l = lane / p.ppl, cc = lane % p.ppl;
+                const double *base = p.sstore + (size_t)p.sslot[l] * LMPC_COLS * p.lap_stride;
+                int r1 = sel_start[l] + cc + 1; r1 = r1 > p.sslen[l] - 1 ? p.sslen[l] - 1 : r1;
+                const double lv = lam[lane];
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] = base[j * p.lap_stride + r1] * lv;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] = wsum(acc[j]);
+            if (lane < 6 && io.ztNext) { double v = acc[0];
+#pragma unroll
+                for (int j = 1; j < 6; j++) if (lane == j) v = acc[j];
+                io.ztNext[(size_t)b * 6 + lane] = v; }
+            if (lane < 2 && io.ztuNext) io.ztuNext[(size_t)b * 2 + lane] = lane == 0 ? acc[6] : acc[7];
+        }
+    } else {
+        if (tid < 6 && io.ztNext) io.ztNext[(size_t)b * 6 + tid] = x[N * 6 + tid];
+        if (tid < 2 && io.ztuNext) io.ztuNext[(size_t)b * 2 + tid] = u[(N - 1) * 2 + tid];
+    }
+    if (tid == 0) {
+        io.status[b] = st_sh; io.iters[b] = it;
+        if (io.resid) { io.resid[(size_t)b * 3] = gap; io.resid[(size_t)b * 3 + 1] = rdn; io.resid[(size_t)b * 3 + 2] = ren; }
+    }
+#undef FOR_OFF
+}

@@ -86,9 +86,15 @@ def test_batch4096_safe_set_from_30_laps(built):
     print("B=4096/30 laps: IPM iterations mean %.2f max %d" % (out["iters"].mean(), out["iters"].max()))
     feasibility_properties(out, inp, par, N)
     # batch-order independence: a permuted batch gives bitwise identical per-problem answers
-    perm = rng.permutation(B)[:512]
+    perm = rng.permutation(B)[:1024]
     out2 = ctx.step_batch(inp["x0"][perm], inp["xLin"][perm], inp["uLin"][perm], inp["uOld"][perm], zt=inp["zt"][perm], timeStep=inp["timeStep"][perm])
     assert np.array_equal(out2["xPred"], out["xPred"][perm]) and np.array_equal(out2["uPred"], out["uPred"][perm])
+    # small batches run the 4-waves-per-QP kernel variant: same answers up to summation order
+    sub = perm[:200]
+    out3 = ctx.step_batch(inp["x0"][sub], inp["xLin"][sub], inp["uLin"][sub], inp["uOld"][sub], zt=inp["zt"][sub], timeStep=inp["timeStep"][sub])
+    assert np.all(out3["status"] == 0)
+    assert np.abs(out3["xPred"] - out["xPred"][sub]).max() < 1e-7 and np.abs(out3["uPred"] - out["uPred"][sub]).max() < 1e-7
+    assert np.array_equal(out3["ssSel"], out["ssSel"][sub])
     # sampled comparison with the oracle (stores in the library's order: model sorted ascending, safe set = argsort(LapTime))
     model_sorted = [laps[i] for i in order]
     ss_sel = [laps[i] for i in order]
