@@ -187,6 +187,7 @@ def main():
         ms_solve = st.ms_solve / max(st.n_solve, 1); ms_reg = st.ms_regress / max(st.n_regress, 1)
         bytes_per_solve = 8 * (18 * N + 92)                     # SURVEY 8(d) B_solve: compulsory in+out per full step
         achieved = B * bytes_per_solve / (ms_solve * 1e-3) / 1e9
+        kname = "lmpc_solve_kernel_mw<%d,%d,4>" % (N, S) if ctx.solver_waves(B) == 4 else "lmpc_solve_kernel<%d,%d>" % (N, S)
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
@@ -205,8 +206,9 @@ def main():
             "kernel_ms": {"lmpc_solve_kernel": ms_solve, "lmpc_regress_kernel": ms_reg},
             "solver_only_solves_per_s": B / (ms_solve * 1e-3), "regression_only_solves_per_s": B / (ms_reg * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "lmpc_solve_kernel", "algorithmic_bytes_per_launch": B * bytes_per_solve,
-                         "note": "latency/FP64-issue bound path: compulsory HBM traffic is 2.46 KB per solve (SURVEY 8(d)); see DESIGN.md"},
+                         "traffic": traffic, "kernel": kname, "algorithmic_bytes_per_launch": B * bytes_per_solve,
+                         "note": "dependent-issue-latency bound path (one Newton recursion per QP); compulsory HBM traffic is 2.46 KB per solve (SURVEY 8(d)); "
+                                 "measured traffic also counts the A,B,C hand-over from the regression kernel, the L2-resident lap-store scans and the mu/ssSel outputs; see DESIGN.md"},
         }
         if args.sweep:
             sweep = {}

@@ -47,7 +47,7 @@ EXPORTS = [
     "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun",
     "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
-    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_plant_step_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap",
+    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_solver_waves", "lmpc_plant_step_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap",
 ]
 
 _lib = None
@@ -291,6 +291,9 @@ class Context:
     def ss_extend_lap(self, lap, x, u):
         x = _f64(x); u = _f64(u)
         _chk(self.lib.lmpc_ss_extend_lap(self._h, C.c_int(int(lap)), _d(x), _d(u), C.c_int(x.shape[0])))
+
+    def solver_waves(self, B):
+        return int(self.lib.lmpc_solver_waves(self._h, C.c_int(int(B))))
 
     def selftest(self):
         _chk(self.lib.lmpc_selftest(self._h))

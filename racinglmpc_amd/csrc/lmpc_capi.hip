@@ -606,6 +606,8 @@ int lmpc_selftest(lmpc_ctx *c) {
     return LMPC_OK;
 }
 
+int lmpc_solver_waves(lmpc_ctx *c, int B) { if (!c) return LMPC_E_ARG; return B <= c->mw_max_batch ? 4 : 1; }
+
 int lmpc_set_profiling(lmpc_ctx *c, int on) { ARGCHK(c); c->profiling = on ? 1 : 0; return LMPC_OK; }
 static int drain_events(lmpc_ctx *c) {
     HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
