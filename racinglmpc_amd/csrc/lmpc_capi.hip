@@ -363,7 +363,8 @@ int lmpc_step_batch_dev(lmpc_ctx *c, int B, const lmpc_step_dev_args *a) {
     const int N = c->cfg.N; const bool term = c->cfg.numSS_it > 0;
     if (term) ARGCHK(a->zt != nullptr);
     HIPCHK(hipSetDevice(c->cfg.device));
-    int rc = launch_regress(c, B, a->xLin, (N + 1) * 6, a->uLin, a->A, a->Bm, a->C, c->w_rstatus == nullptr ? nullptr : (B <= c->cfg.max_batch ? c->w_rstatus : nullptr));
+    ARGCHK(B <= c->cfg.max_batch);                      // the per-point regression status buffer is sized for max_batch
+    int rc = launch_regress(c, B, a->xLin, (N + 1) * 6, a->uLin, a->A, a->Bm, a->C, c->w_rstatus);
     if (rc) return rc;
     lmpc_solve_io io; memset(&io, 0, sizeof(io));
     io.mode = term ? 3 : 2; io.A = a->A; io.Bm = a->Bm; io.C = a->C; io.x0 = a->x0; io.uOld = a->uOld;
