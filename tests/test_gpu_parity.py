@@ -132,6 +132,46 @@ def test_status_flags(g):
     ctx.close()
 
 
+def test_more_status_flags(g):
+    """Singular local regression (reference: cvxopt raises), iteration limit, non-interior start, unsupported shapes."""
+    from racinglmpc_amd import _capi
+    # bandwidth so small that no stored row lies within h -> fewer than 5 neighbours -> singular normal matrix
+    cfg, par = common.lmpc_config(g, 12, max_batch=4)
+    cfg.h = 1e-6
+    ctx = _capi.Context(cfg)
+    for _ in range(4):
+        ctx.model_add_trajectory(g["xPID"], g["uPID"])
+    A, B, C, st = ctx.regress_batch(g["rec_xLin"][:1], g["rec_uLin"][:1])
+    assert np.all(st & _flag("ST_REG_SINGULAR")) and np.all(np.isfinite(A))
+    ctx.close()
+    # iteration limit
+    ctx, par = common.make_lmpc_ctx(g, 4, max_batch=4, max_iter=3)
+    out = ctx.qp_solve_batch(g["rec_A"][:2], g["rec_B"][:2], g["rec_C"][:2], g["rec_x0"][:2], g["rec_OldInput"][:2],
+                             np.transpose(g["rec_SSsel"][:2], (0, 2, 1)), g["rec_Qsel"][:2])
+    assert np.all(out["status"] == _flag("ST_MAXITER")) and np.all(out["iters"] == 3) and np.all(np.isfinite(out["xPred"]))
+    ctx.close()
+    # u = 0 not strictly inside the input box
+    cfg, par = common.lmpc_config(g, 12, max_batch=4)
+    cfg.bu[0] = 0.0
+    ctx = _capi.Context(cfg)
+    out = ctx.qp_solve_batch(g["rec_A"][:1], g["rec_B"][:1], g["rec_C"][:1], g["rec_x0"][:1], g["rec_OldInput"][:1],
+                             np.transpose(g["rec_SSsel"][:1], (0, 2, 1)), g["rec_Qsel"][:1])
+    assert out["status"][0] & _flag("ST_NOT_INTERIOR")
+    ctx.close()
+    # unsupported configuration fails loudly at creation, with a message
+    cfg, par = common.lmpc_config(g, 13, max_batch=4)
+    with pytest.raises(_capi.LmpcError, match="unsupported"):
+        _capi.Context(cfg)
+    # calls before any lap is stored
+    cfg, par = common.lmpc_config(g, 12, max_batch=4)
+    ctx = _capi.Context(cfg)
+    with pytest.raises(_capi.LmpcError):
+        ctx.regress_batch(g["rec_xLin"][:1], g["rec_uLin"][:1])
+    with pytest.raises(_capi.LmpcError):
+        ctx.ss_add_point(np.zeros(6), np.zeros(2))
+    ctx.close()
+
+
 def _flag(name):
     from racinglmpc_amd import _capi
     return getattr(_capi, name)
