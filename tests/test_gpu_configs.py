@@ -110,7 +110,7 @@ def test_batch4096_safe_set_from_30_laps(built):
     ctx.close()
 
 
-@pytest.mark.parametrize("N,B", [(40, 1024), (14, 256)])
+@pytest.mark.parametrize("N,B", [(40, 1024), (14, 256), (20, 300), (8, 64)])
 def test_other_horizons(built, N, B):
     """BASELINE config 'long-horizon N=40 LMPC, batch=1024' and the reference's own N=14 (main.py:43)."""
     from oracle import lmpc_oracle as orc
@@ -144,4 +144,27 @@ def test_other_horizons(built, N, B):
         assert abs(obj(full) - obj(opt)) <= 1e-7 * (1 + abs(obj(opt)))
     print("N=%d B=%d: iterations mean %.2f max %d, worst |xu - opt| %.2e" % (N, B, out["iters"].mean(), out["iters"].max(), worst))
     assert worst < common.TOL_XU
+    ctx.close()
+
+
+@pytest.mark.parametrize("N", [8, 14, 20, 40])
+def test_plain_mpc_horizons(built, N):
+    """Every built no-terminal-set variant (template S = 0): LTI MPC QP (reference MPC class, main.py:72-80) against the
+    oracle's certified optimum of the reference-form QP."""
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    gl = common.load_ltv_golden()
+    cfg, _ = common.mpc_config(gl, N, max_batch=8)
+    par = orc.QPParams.mpc_default(N, 0.8)
+    ctx = _capi.Context(cfg)
+    A1, B1 = gl["A"][0][0], gl["B"][0][0]
+    B_ = 6
+    x0 = gl["x0"][:B_]; uOld = gl["OldInput"][:B_]
+    out = ctx.qp_solve_batch(np.tile(A1[None, None], (B_, N, 1, 1)), np.tile(B1[None, None], (B_, N, 1, 1)), np.zeros((B_, N, 6)), x0, uOld)
+    assert np.all(out["status"] == 0), out["status"]
+    for b in (0, B_ - 1):
+        P, q, A, l, u = orc.assemble_mpc_qp(par, A1, B1, None, x0[b], uOld[b])
+        ex, cert = orc.osqp_solve_exact(P, q, A, l, u)
+        w = np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()])
+        assert cert < 1e-8 and np.abs(w - ex.x[:8 * N + 6]).max() < common.TOL_XU
     ctx.close()
