@@ -285,6 +285,18 @@ __device__ __forceinline__ void swap32(double v, double &a, double &b) {
     auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     a = __hiloint2double((int)r1[0], (int)r0[0]); b = __hiloint2double((int)r1[1], (int)r0[1]);
 }
+// DPP move of src into the banks (groups of 4 lanes in each row of 16) selected by BANKS; the other lanes keep `keep`
+template <int CTRL, int BANKS> __device__ __forceinline__ double dpp_blk(double keep, double src) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(src), CTRL, 0xf, BANKS, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(src), CTRL, 0xf, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_gather(double v, int byte_idx) {   // v from lane byte_idx / 4 (ds_bpermute: LDS crossbar, no memory)
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_idx, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(byte_idx, __double2loint(v)));
+}
+__device__ __forceinline__ double rdlane(double v, int src) {       // wave-uniform copy of lane src's value
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
 #define DPP_QP_X1 0xB1          // quad_perm [1,0,3,2]
 #define DPP_QP_X2 0x4E          // quad_perm [2,3,0,1]
 #define DPP_HALF_MIRROR 0x141
@@ -306,9 +318,133 @@ __device__ __forceinline__ double wsum(double v) { return wave_allreduce(v, OpSu
 __device__ __forceinline__ double wmax(double v) { return wave_allreduce(v, OpMax()); }
 __device__ __forceinline__ double wmin(double v) { return wave_allreduce(v, OpMin()); }
 
+// fast FP64 reciprocal / reciprocal square root: hardware estimate + two Newton steps (full double accuracy up to ~1 ulp;
+// an IEEE divide costs ~75 and a sqrt ~125 dependent cycles on this path, these ~35)
+__device__ __forceinline__ double frcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double frsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y;
+}
+
 // parameter block staged in LDS (lane-dependent indexing of kernel arguments would go through global memory)
 enum { PAR_FX = 0, PAR_FU = 12, PAR_BX = 20, PAR_BU = 22, PAR_Q2 = 26, PAR_QF2 = 62, PAR_R2 = 98, PAR_DR2 = 102, PAR_T2 = 104,
        PAR_XREF = 110, PAR_AS = 116, PAR_CS = 117, PAR_TOT = 118 };
+
+// ---- Riccati recursion on the matrix cores, quad-block form ---------------------------------------------------------
+// v_mfma_f64_4x4x4 multiplies four independent 4 x 4 blocks b: A_b[i][k] sits in lane 16 k + 4 b + i, B_b[k][j] in lane
+// 16 k + 4 b + j and D_b[i][j] comes back in lane 16 i + 4 b + j (probed on gfx950, tools/mfma4_layout.hip).  An 8 x 8 matrix X
+// in "quad form" is ONE register per lane: lane 16 r + 4 (2 I + J) + c holds X[4 I + r][4 J + c].  A product Z = X Y is two
+// chained instructions Z(I,J) = sum_K X(I,K) Y(K,J) whose operands are in-row block copies of the quad forms (DPP with a bank
+// mask): the B form of Y copies blocks [0,1,0,1] / [2,3,2,3] of Y's quad form, the A form of X copies blocks [0,0,1,1] /
+// [2,2,3,3] of the quad form of X'.  The sequential recursion therefore runs register to register, with no LDS round trip and
+// no barrier on the chain, and the dependent latency of this shape (~45 cycles) is less than half that of 16x16x4.
+struct ricc_consts {                                       // per-lane loop-invariant data
+    int qr, qR, qC, cA, oB0, oA0, oB1, oA1, oBe, oTop, qT;
+    bool w_xx;
+    double wq, wf0, wf1, wfu[4], d2base, ud2, idB1, idA1, idBe;
+};
+__device__ __forceinline__ ricc_consts ricc_setup(int lane, const double *Q2, const double *Fx, const double *R2, const double *dR2, const double *Fu) {
+    ricc_consts c;
+    const int qr = lane >> 4, qI = (lane >> 3) & 1, qJ = (lane >> 2) & 1, qc = lane & 3;
+    const int qR = 4 * qI + qr, qC = 4 * qJ + qc;          // tile entry (row, column) this lane owns in quad form
+    c.qr = qr; c.qR = qR; c.qC = qC;
+    // stage Hessian W: the xx / uu constants vanish outside their block, so W is one FMA chain without selects
+    const bool w_xx = qR < 6 && qC < 6, w_uu = qR >= 6 && qC >= 6;
+    c.w_xx = w_xx;
+    c.wq = w_xx ? Q2[qR * 6 + qC] : 0.0;
+    c.wf0 = w_xx ? Fx[qR] * Fx[qC] : 0.0; c.wf1 = w_xx ? Fx[6 + qR] * Fx[6 + qC] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) c.wfu[j] = 0.0;
+    if (w_uu) {
+        c.wq = R2[(qR - 6) * 2 + (qC - 6)] + (qR == qC ? dR2[qR - 6] : 0.0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) c.wfu[j] = Fu[j * 2 + (qR - 6)] * Fu[j * 2 + (qC - 6)];
+    }
+    c.d2base = (qR >= 6 && qR == qC) ? dR2[qR - 6] : 0.0;                             // Base rows of u_{k-1}
+    c.ud2 = (qr < 2 && qC == 6 + qr) ? -dR2[qr] : 0.0;                                // U = [M_ux | -dR]: columns 6, 7 (B form)
+    // stage operands that come straight from [A_k | B_k] (row-major 6 x 8 in LDS): offsets (clamped) and identity parts
+    const int cB = qC, cA = 4 * qI + qc;                                              // column read for the B form / the A form
+    c.cA = cA;
+    c.oB0 = qr * 8 + cB; c.oA0 = qr * 8 + cA;                                         // K = 0: rows 0..3 of Ar
+    c.oB1 = (qr < 2 ? 4 + qr : 0) * 8 + cB; c.oA1 = (qr < 2 ? 4 + qr : 0) * 8 + cA;   // K = 1: rows 4, 5 of Ar; rows 6, 7 are [0 | I]
+    c.idB1 = (qr >= 2 && cB == 4 + qr) ? 1.0 : 0.0; c.idA1 = (qr >= 2 && cA == 4 + qr) ? 1.0 : 0.0;
+    c.oBe = (cA < 6 ? cA : 0) * 8 + 6 + (qr & 1);                                     // [B; I] as A operand (K index = qr < 2)
+    c.idBe = (qr < 2 && cA == 6 + qr) ? 1.0 : 0.0;
+    c.oTop = (qR < 6 ? qR : 0) * 8 + (qC < 6 ? qC : 0);
+    c.qT = 4 * (16 * qc + 4 * (2 * qJ + qI) + qr);                                    // byte index of the lane holding the transposed entry
+    return c;
+}
+// Backward recursion over the augmented stages xi_k = (x_k, u_{k-1}), [x'; u] = Ar [x; u], Ar = [[A, B], [0, I]] (8 x 8):
+//   T = Pi_{k+1} Ar,  Mr = Ar' T + W_k,  eliminate u_k (2 x 2 pivot M_uu):  Pi_k = Base - U' M_uu^-1 U,  Phi_k = [[A,0],[0,0]] - [B; I] M_uu^-1 U
+// executed by ONE full wave; writes Phi_k, Pi_k (row-major 8 x 8) and M_uu^-1 to LDS for the sweeps.  Returns non-zero if a pivot is not
+// positive.  kap / th must be visible to the calling wave.
+template <int N, bool term>
+__device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *AB, const double *kap, const double *th, const double *Qf2,
+                                           const double *PiT, double *Phi, double *PiAll, double *Mi) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int qr = c.qr;
+    int bad = 0;
+    double Piq = c.w_xx ? Qf2[c.qR * 6 + c.qC] + (term ? PiT[c.qR * 6 + c.qC] : 0.0) : 0.0;   // Pi_N = [[2Qf + Pi_term, 0], [0, 0]]
+    // stage operands are fetched one stage ahead: the loads and the W arithmetic of stage k - 1 fill the latency of stage k's chain
+    double lB0, lA0, lB1, lA1, lBe, lTop, Wq;
+    auto stage_operands = [&](int k) {
+        const double *ABk = AB + k * 48;
+        lB0 = ABk[c.oB0]; lA0 = ABk[c.oA0]; lB1 = ABk[c.oB1]; lA1 = ABk[c.oA1]; lBe = ABk[c.oBe]; lTop = ABk[c.oTop];
+        double w = fma(kap[2 * k + 1], c.wf1, fma(kap[2 * k], c.wf0, c.wq));
+#pragma unroll
+        for (int j = 0; j < 4; j++) w = fma(th[2 * N + 4 * k + j], c.wfu[j], w);
+        Wq = w;
+    };
+    stage_operands(N - 1);
+#pragma unroll 1
+    for (int k = N - 1; k >= 0; k--) {
+        const double cB0 = lB0, cA0 = lA0, cW = Wq;
+        const double arB1 = qr < 2 ? lB1 : c.idB1, arA1 = qr < 2 ? lA1 : c.idA1;           // Ar (B form) and Ar' (A form), K = 1
+        const double be = c.cA < 6 ? lBe : c.idBe;                                         // [B; I] as A operand; its K >= 2 lanes meet K = 0
+        const double top = c.w_xx ? lTop : 0.0;
+        if (k > 0) stage_operands(k - 1);
+        // T = Pi Ar: A form of the symmetric Pi = in-row block copies [0,0,1,1] (K = 0) and [2,2,3,3] (K = 1) of its quad form
+        const double pA0 = dpp_blk<0x118, 0x8>(dpp_blk<0x114, 0x6>(Piq, Piq), Piq);       // row_shr:4 -> banks 1, 2; row_shr:8 -> bank 3
+        const double pA1 = dpp_blk<0x108, 0x1>(dpp_blk<0x104, 0x6>(Piq, Piq), Piq);       // row_shl:4 -> banks 1, 2; row_shl:8 -> bank 0
+        double Tq = __builtin_amdgcn_mfma_f64_4x4x4f64(pA0, cB0, 0.0, 0, 0, 0);
+        Tq = __builtin_amdgcn_mfma_f64_4x4x4f64(pA1, arB1, Tq, 0, 0, 0);
+        // Mr = Ar' T + W: B form of T = in-row block copies [0,1,0,1] (K = 0) and [2,3,2,3] (K = 1)
+        const double tB0 = dpp_blk<0x128, 0xC>(Tq, Tq), tB1 = dpp_blk<0x128, 0x3>(Tq, Tq);
+        double Mq = __builtin_amdgcn_mfma_f64_4x4x4f64(cA0, tB0, cW, 0, 0, 0);
+        Mq = __builtin_amdgcn_mfma_f64_4x4x4f64(arA1, tB1, Mq, 0, 0, 0);
+        // eliminate u_k: M_uu = Mr[6:8,6:8] sits in lanes 46, 47, 63; U = [M_ux | -dR] (2 x 8) = rows 6, 7 of Mr
+        const double m00 = rdlane(Mq, 46), m01 = rdlane(Mq, 47), m11 = rdlane(Mq, 63);
+        const double det = m00 * m11 - m01 * m01;
+        if (!(det > 0.0) || !(m00 > 0.0)) bad = 1;
+        const double rdet = frcp(det);
+        const double i00 = m11 * rdet, i01 = -m01 * rdet, i11 = m00 * rdet;
+        double sa, sb, ua, ub;
+        swap32(Mq, sa, sb);                                                                // rows 6, 7 (lanes 32..63) -> lanes 0..31
+        const double um = dpp_blk<0x128, 0x3>(sb, sb);                                     // columns 0..7 in both halves of the row (B form)
+        const double Ub = qr < 2 ? (c.qC < 6 ? um : c.ud2) : 0.0;
+        swap16(Ub, ua, ub);
+        const double Uo = (qr & 1) ? ua : ub;                                              // the other row of U
+        const double nKb = -((qr == 0 ? i00 : i11) * Ub + i01 * Uo);                       // -K = -M_uu^-1 U (B form; zero in lanes qr >= 2)
+        const double Ua = dpp_blk<0x104, 0x4>(dpp_blk<0x114, 0x2>(Ub, Ub), Ub);            // A form of U': blocks [0,0,3,3]
+        const double Bs = c.w_xx ? Mq : c.d2base;
+        const double Piu = __builtin_amdgcn_mfma_f64_4x4x4f64(Ua, nKb, Bs, 0, 0, 0);       // Pi_k = Base - U' K
+        const double Phq = __builtin_amdgcn_mfma_f64_4x4x4f64(be, nKb, top, 0, 0, 0);      // Phi_k = [[A, 0], [0, 0]] - [B; I] K
+        // Rounding leaves Pi slightly unsymmetric, the A form of the next stage reads Pi', and U above takes rows for columns:
+        // unsymmetrised, that asymmetry feeds back into the symmetric part at first order (it cost definiteness near convergence
+        // at N = 40).  One cross-lane transpose per stage removes it.
+        Piq = 0.5 * (Piu + lane_gather(Piu, c.qT));
+        Phi[k * 64 + c.qR * 8 + c.qC] = Phq; PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
+        if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 3 ? i11 : i01);
+    }
+    return bad;
+}
 
 template <int N, int S> struct solve_lds {
     static constexpr int M = 8 * N + S;
@@ -321,8 +457,7 @@ template <int N, int S> struct solve_lds {
     static constexpr int oPhi = orl + S, oPiAll = oPhi + 64 * N, oMi = oPiAll + 64 * N, ogam = oMi + 4 * N, ogup = ogam + 8 * N,
                          opst = ogup + 2 * N, ok0 = opst + 8 * (N + 1), odnu = ogam;              // dnu reuses gamma (dead after the sweeps)
     static constexpr int okap = ok0 + 2 * N, orDs = okap + 2 * N, oeta = orDs + 2 * N, oe = oeta + 2 * N;
-    static constexpr int oPi = oe + 2 * N, oT = oPi + 64, oMr = oT + 64;
-    static constexpr int oRi = oMr + 64, orsq = oRi + 56, oct = orsq + WAVE;
+    static constexpr int oRi = oe + 2 * N, orsq = oRi + 56, oct = orsq + WAVE;
     static constexpr int oMt = oct + WAVE, oWl = oMt + (S > 0 ? 8 * WAVE : 0), oMc = oWl + (S > 0 ? 64 : 0);   // M transposed (col-major, 8 per column), Gram matrix, M c~
     static constexpr int oSS = oMc + 8, oQsel = oSS + 6 * S, oy7 = oQsel + S, oz7 = oy7 + 8, ow7 = oz7 + 8, oPiT = ow7 + 8, osT = oPiT + 36;
     static constexpr int opar = osT + 8, tot = opar + PAR_TOT;
@@ -374,7 +509,6 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     double *Phi = sm + LL::oPhi, *PiAll = sm + LL::oPiAll, *Mi = sm + LL::oMi, *gam = sm + LL::ogam, *gup = sm + LL::ogup, *pst = sm + LL::opst, *k0 = sm + LL::ok0;
     double *phi = gam;                                     // gamma is dead (kept in registers) once the backward sweep starts
     double *kap = sm + LL::okap, *rDs = sm + LL::orDs, *eta = sm + LL::oeta, *ee = sm + LL::oe;
-    double *Pi = sm + LL::oPi, *Tm = sm + LL::oT, *Mr = sm + LL::oMr;
     double *Ri = sm + LL::oRi, *rsq = sm + LL::orsq, *ct = sm + LL::oct, *Mt = sm + LL::oMt, *Wl = sm + LL::oWl, *McL = sm + LL::oMc;
     double *SS = sm + LL::oSS, *Qsel = sm + LL::oQsel, *y7 = sm + LL::oy7, *z7 = sm + LL::oz7, *w7 = sm + LL::ow7, *PiT = sm + LL::oPiT, *sT = sm + LL::osT;
     double *par = sm + LL::opar;
@@ -524,16 +658,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         t_r[j] = 1.0; rt_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
         if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; m[r] = mu0 / tt; }
     }
-    // loop-invariant pieces of the stage Hessian W for this lane's (a, c) = (lg, lc) tile entry
-    const bool w_xx = lg < 6 && lc < 6, w_uu = lg >= 6 && lc >= 6;
-    const double wq2 = w_xx ? Q2[lg * 6 + lc] : 0.0;
-    const double wf0 = w_xx ? Fx[lg] * Fx[lc] : 0.0, wf1 = w_xx ? Fx[6 + lg] * Fx[6 + lc] : 0.0;
-    double wr2 = 0.0, wfu[4] = {0.0, 0.0, 0.0, 0.0};
-    if (w_uu) {
-        wr2 = R2[(lg - 6) * 2 + (lc - 6)] + (lg == lc ? dR2[lg - 6] : 0.0);
-#pragma unroll
-        for (int j = 0; j < 4; j++) wfu[j] = Fu[j * 2 + (lg - 6)] * Fu[j * 2 + (lc - 6)];
-    }
+    const ricc_consts rc = ricc_setup(lane, Q2, Fx, R2, dR2, Fu);
     double ph[N];                                          // Phi_k entry this lane multiplies with in the register sweeps
     double mcol[7];                                        // this lane's column of M = [E D^-1/2 | T7^-1/2]
 #pragma unroll
@@ -687,7 +812,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
             const int r = lane + WAVE * j;
-            if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; rt_r[j] = 1.0 / tt; gsum = fma(tt, m[r], gsum); }
+            if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; rt_r[j] = frcp(tt); gsum = fma(tt, m[r], gsum); }
         }
         if constexpr (term) {
             ss_times<S>(SS, lam, x + N * 6, sT, lane);
@@ -754,7 +879,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) th[r] = m[r] * rt_r[j]; }
         __syncthreads();
         FOR_LANES(i, 2 * N) {
-            const double d_ = 1.0 / (a_s + th[i] + th[6 * N + i]);
+            const double d_ = frcp(a_s + th[i] + th[6 * N + i]);
             rDs[i] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
         }
         int numeric_bad = 0;
@@ -764,14 +889,14 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
 #pragma unroll
             for (int j = 0; j < 7; j++) mcol[j] = 0.0;
             if (lane < S) {
-                const double rs_ = 1.0 / sqrt(th[8 * N + lane] + p.reg); rsq[lane] = rs_;
+                const double rs_ = frsqrt(th[8 * N + lane] + p.reg); rsq[lane] = rs_;
 #pragma unroll
                 for (int j = 0; j < 6; j++) mcol[j] = SS[j * S + lane] * rs_;
                 mcol[6] = rs_;
             } else {
                 rsq[lane] = 1.0;
 #pragma unroll
-                for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = 1.0 / sqrt(T2p[j]);
+                for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = frsqrt(T2p[j]);
             }
             double Rr[7][7], Rv[7][7], rinv[7];
 #pragma unroll
@@ -810,7 +935,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
 #pragma unroll
                 for (int k = 0; k < i; k++) d_ = fma(-Rr[k][i], Rr[k][i], d_);
                 if (!(d_ > 0.0)) { numeric_bad = 1; d_ = 1.0; }
-                const double rii = sqrt(d_); rinv[i] = 1.0 / rii; Rr[i][i] = rii;
+                rinv[i] = frsqrt(d_); const double rii = d_ * rinv[i]; Rr[i][i] = rii;
 #pragma unroll
                 for (int j = i + 1; j < 7; j++) {
                     double v = Rr[i][j];
@@ -845,53 +970,9 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             __syncthreads();
         }
         TSTAMP(12);
-        // Pi_N = [[2Qf + Pi_term, 0], [0, 0]]
-        { double v = 0.0; if (lg < 6 && lc < 6) v = Qf2[lg * 6 + lc] + (term ? PiT[lg * 6 + lc] : 0.0); Pi[lane] = v; }
-        __syncthreads();
-#pragma unroll 1
-        for (int k = N - 1; k >= 0; k--) {
-            // augmented stage map [x'; u] = Ar [x; u], Ar = [[A, B], [0, I]] (8 x 8); all 64 lanes run the same code on tile entry (lg, lc)
-            const double *ABk = AB + k * 48;
-            {   // T = Pi Ar
-                double v = lc >= 6 ? Pi[lg * 8 + lc] : 0.0;
-#pragma unroll
-                for (int l = 0; l < 6; l++) v = fma(Pi[lg * 8 + l], ABk[l * 8 + lc], v);
-                Tm[lane] = v;
-            }
-            __syncthreads();
-            {   // Mr = Ar' T + W
-                double v = lg >= 6 ? Tm[lane] : 0.0;
-#pragma unroll
-                for (int l = 0; l < 6; l++) v = fma(ABk[l * 8 + lg], Tm[l * 8 + lc], v);
-                const double wx = wq2 + kap[2 * k] * wf0 + kap[2 * k + 1] * wf1;
-                double wu = wr2;
-#pragma unroll
-                for (int j = 0; j < 4; j++) wu = fma(th[2 * N + 4 * k + j], wfu[j], wu);
-                v += w_xx ? wx : (w_uu ? wu : 0.0);
-                Mr[lane] = v;
-            }
-            __syncthreads();
-            {   // eliminate u_k: 2x2 pivot inverted by every lane; Pi_k, Phi_k tile entries
-                const double m00 = Mr[54], m01 = Mr[55], m10 = Mr[62], m11 = Mr[63];
-                const double det = m00 * m11 - m01 * m10;
-                if (!(det > 0.0) || !(m00 > 0.0)) numeric_bad = 1;
-                const double rdet = 1.0 / det;
-                const double i00 = m11 * rdet, i01 = -m01 * rdet, i10 = -m10 * rdet, i11 = m00 * rdet;
-                // K[d][lc]: gain column for this lane's column index
-                double K0, K1;
-                if (lc < 6) { const double a6 = Mr[48 + lc], a7 = Mr[56 + lc]; K0 = i00 * a6 + i01 * a7; K1 = i10 * a6 + i11 * a7; }
-                else { const double d2 = dR2[lc - 6]; K0 = -(lc == 6 ? i00 : i01) * d2; K1 = -(lc == 6 ? i10 : i11) * d2; }
-                double mau0, mau1, base, top, be0, be1;
-                if (lg < 6) { mau0 = Mr[lg * 8 + 6]; mau1 = Mr[lg * 8 + 7]; base = lc < 6 ? Mr[lane] : 0.0; top = lc < 6 ? ABk[lg * 8 + lc] : 0.0; be0 = ABk[lg * 8 + 6]; be1 = ABk[lg * 8 + 7]; }
-                else { const double d2 = dR2[lg - 6]; mau0 = lg == 6 ? -d2 : 0.0; mau1 = lg == 7 ? -d2 : 0.0; base = (lc == lg) ? d2 : 0.0; top = 0.0; be0 = lg == 6 ? 1.0 : 0.0; be1 = lg == 7 ? 1.0 : 0.0; }
-                const double pn = base - mau0 * K0 - mau1 * K1;
-                Pi[lane] = pn; PiAll[k * 64 + lane] = pn;
-                Phi[k * 64 + lane] = top - be0 * K0 - be1 * K1;
-                if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 1 ? i01 : (lane == 2 ? i10 : i11));
-            }
-            __syncthreads();
-        }
+        numeric_bad |= ricc_factor<N, term>(rc, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
         if (numeric_bad) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < N; k++) ph[k] = (k & 1) ? Phi[k * 64 + lc * 8 + lg] : Phi[k * 64 + lg * 8 + lc];
 
@@ -909,8 +990,8 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
                 const double dta = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dma = -mr - th[r] * dta;
                 dt_r[j] = dta; dma_r[j] = dma;
-                if (dta < 0.0) apmax = fmin(apmax, -t_r[j] / dta);
-                if (dma < 0.0) admax = fmin(admax, -mr / dma);
+                if (dta < 0.0) apmax = fmin(apmax, -t_r[j] * frcp(dta));
+                if (dma < 0.0) admax = fmin(admax, -mr * frcp(dma));
             }
         }
         apmax = wmin(apmax); admax = wmin(admax);
@@ -940,8 +1021,8 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
                 const double dtt = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dmm = -h[r] - th[r] * dtt;
                 dm[r] = dmm;
-                if (dtt < 0.0) apx = fmin(apx, -t_r[j] / dtt);
-                if (dmm < 0.0) adx = fmin(adx, -mr / dmm);
+                if (dtt < 0.0) apx = fmin(apx, -t_r[j] * frcp(dtt));
+                if (dmm < 0.0) adx = fmin(adx, -mr * frcp(dmm));
             }
         }
         apx = wmin(apx); adx = wmin(adx);

@@ -33,7 +33,6 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
     double *rx = sm + LL::orx, *ru = sm + LL::oru, *rs = sm + LL::ors, *rl = sm + LL::orl;
     double *Phi = sm + LL::oPhi, *PiAll = sm + LL::oPiAll, *Mi = sm + LL::oMi, *gam = sm + LL::ogam, *gup = sm + LL::ogup, *pst = sm + LL::opst;
     double *kap = sm + LL::okap, *rDs = sm + LL::orDs, *eta = sm + LL::oeta, *ee = sm + LL::oe;
-    double *Pi = sm + LL::oPi, *Tm = sm + LL::oT, *Mr = sm + LL::oMr;
     double *Ri = sm + LL::oRi, *rsq = sm + LL::orsq, *ct = sm + LL::oct, *Mt = sm + LL::oMt, *Wl = sm + LL::oWl, *McL = sm + LL::oMc;
     double *SS = sm + LL::oSS, *Qsel = sm + LL::oQsel, *y7 = sm + LL::oy7, *z7 = sm + LL::oz7, *w7 = sm + LL::ow7, *PiT = sm + LL::oPiT, *sT = sm + LL::osT;
     double *par = sm + LL::opar;
@@ -192,15 +191,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
         if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; m[r] = mu0 / tt; }
     }
     // loop-invariant pieces of the stage Hessian W for this lane's (a, c) = (lg, lc) tile entry (used by wave 0)
-    const bool w_xx = lg < 6 && lc < 6, w_uu = lg >= 6 && lc >= 6;
-    const double wq2 = w_xx ? Q2[lg * 6 + lc] : 0.0;
-    const double wf0 = w_xx ? Fx[lg] * Fx[lc] : 0.0, wf1 = w_xx ? Fx[6 + lg] * Fx[6 + lc] : 0.0;
-    double wr2 = 0.0, wfu[4] = {0.0, 0.0, 0.0, 0.0};
-    if (w_uu) {
-        wr2 = R2[(lg - 6) * 2 + (lc - 6)] + (lg == lc ? dR2[lg - 6] : 0.0);
-#pragma unroll
-        for (int j = 0; j < 4; j++) wfu[j] = Fu[j * 2 + (lg - 6)] * Fu[j * 2 + (lc - 6)];
-    }
+    const ricc_consts rc = ricc_setup(lane, Q2, Fx, R2, dR2, Fu);
     double ph[N];
     double mcol[7];
 #pragma unroll
@@ -348,7 +339,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
             const int r = tid + NT * j;
-            if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; rt_r[j] = 1.0 / tt; gsum = fma(tt, m[r], gsum); }
+            if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; rt_r[j] = frcp(tt); gsum = fma(tt, m[r], gsum); }
         }
         if constexpr (term) { if (wave == NW - 1) ss_times<S>(SS, lam, x + N * 6, sT, lane); }
         __syncthreads();
@@ -415,7 +406,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
         for (int j = 0; j < RPL; j++) { const int r = tid + NT * j; if (r < M) th[r] = m[r] * rt_r[j]; }
         __syncthreads();
         FOR_OFF(i, 2 * N, O1) {
-            const double d_ = 1.0 / (a_s + th[i] + th[6 * N + i]);
+            const double d_ = frcp(a_s + th[i] + th[6 * N + i]);
             rDs[i] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
         }
         FOR_OFF(r, M, O2) h[r] = m[r];                           // predictor right-hand side: h = mu
@@ -426,14 +417,14 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
 #pragma unroll
                 for (int j = 0; j < 7; j++) mcol[j] = 0.0;
                 if (lane < S) {
-                    const double rs_ = 1.0 / sqrt(th[8 * N + lane] + p.reg); rsq[lane] = rs_;
+                    const double rs_ = frsqrt(th[8 * N + lane] + p.reg); rsq[lane] = rs_;
 #pragma unroll
                     for (int j = 0; j < 6; j++) mcol[j] = SS[j * S + lane] * rs_;
                     mcol[6] = rs_;
                 } else {
                     rsq[lane] = 1.0;
 #pragma unroll
-                    for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = 1.0 / sqrt(T2p[j]);
+                    for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = frsqrt(T2p[j]);
                 }
                 double Rr[7][7], Rv[7][7], rinv[7];
 #pragma unroll
@@ -469,7 +460,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
 #pragma unroll
                     for (int k = 0; k < i; k++) d_ = fma(-Rr[k][i], Rr[k][i], d_);
                     if (!(d_ > 0.0)) { numeric_bad = 1; d_ = 1.0; }
-                    const double rii = sqrt(d_); rinv[i] = 1.0 / rii; Rr[i][i] = rii;
+                    rinv[i] = frsqrt(d_); const double rii = d_ * rinv[i]; Rr[i][i] = rii;
 #pragma unroll
                     for (int j = i + 1; j < 7; j++) {
                         double v = Rr[i][j];
@@ -503,50 +494,10 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
                 }
                 WSYNC();
             }
-            { double v = 0.0; if (lg < 6 && lc < 6) v = Qf2[lg * 6 + lc] + (term ? PiT[lg * 6 + lc] : 0.0); Pi[lane] = v; }
             WSYNC();
             __builtin_amdgcn_s_barrier();                        // B_KAP: pairs with the helpers' barrier below; kap / rDs written by another wave are complete
-#pragma unroll 1
-            for (int k = N - 1; k >= 0; k--) {
-                const double *ABk = AB + k * 48;
-                {   // T = Pi Ar
-                    double v = lc >= 6 ? Pi[lg * 8 + lc] : 0.0;
-#pragma unroll
-                    for (int l = 0; l < 6; l++) v = fma(Pi[lg * 8 + l], ABk[l * 8 + lc], v);
-                    Tm[lane] = v;
-                }
-                WSYNC();
-                {   // Mr = Ar' T + W
-                    double v = lg >= 6 ? Tm[lane] : 0.0;
-#pragma unroll
-                    for (int l = 0; l < 6; l++) v = fma(ABk[l * 8 + lg], Tm[l * 8 + lc], v);
-                    const double wx = wq2 + kap[2 * k] * wf0 + kap[2 * k + 1] * wf1;
-                    double wu = wr2;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) wu = fma(th[2 * N + 4 * k + j], wfu[j], wu);
-                    v += w_xx ? wx : (w_uu ? wu : 0.0);
-                    Mr[lane] = v;
-                }
-                WSYNC();
-                {   // eliminate u_k
-                    const double m00 = Mr[54], m01 = Mr[55], m10 = Mr[62], m11 = Mr[63];
-                    const double det = m00 * m11 - m01 * m10;
-                    if (!(det > 0.0) || !(m00 > 0.0)) numeric_bad = 1;
-                    const double rdet = 1.0 / det;
-                    const double i00 = m11 * rdet, i01 = -m01 * rdet, i10 = -m10 * rdet, i11 = m00 * rdet;
-                    double K0, K1;
-                    if (lc < 6) { const double a6 = Mr[48 + lc], a7 = Mr[56 + lc]; K0 = i00 * a6 + i01 * a7; K1 = i10 * a6 + i11 * a7; }
-                    else { const double d2 = dR2[lc - 6]; K0 = -(lc == 6 ? i00 : i01) * d2; K1 = -(lc == 6 ? i10 : i11) * d2; }
-                    double mau0, mau1, base, top, be0, be1;
-                    if (lg < 6) { mau0 = Mr[lg * 8 + 6]; mau1 = Mr[lg * 8 + 7]; base = lc < 6 ? Mr[lane] : 0.0; top = lc < 6 ? ABk[lg * 8 + lc] : 0.0; be0 = ABk[lg * 8 + 6]; be1 = ABk[lg * 8 + 7]; }
-                    else { const double d2 = dR2[lg - 6]; mau0 = lg == 6 ? -d2 : 0.0; mau1 = lg == 7 ? -d2 : 0.0; base = (lc == lg) ? d2 : 0.0; top = 0.0; be0 = lg == 6 ? 1.0 : 0.0; be1 = lg == 7 ? 1.0 : 0.0; }
-                    const double pn = base - mau0 * K0 - mau1 * K1;
-                    Pi[lane] = pn; PiAll[k * 64 + lane] = pn;
-                    Phi[k * 64 + lane] = top - be0 * K0 - be1 * K1;
-                    if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 1 ? i01 : (lane == 2 ? i10 : i11));
-                }
-                WSYNC();
-            }
+            numeric_bad |= ricc_factor<N, term>(rc, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
+            WSYNC();
             if (numeric_bad && lane == 0) bad_sh = 1;
 #pragma unroll
             for (int k = 0; k < N; k++) ph[k] = (k & 1) ? Phi[k * 64 + lc * 8 + lg] : Phi[k * 64 + lg * 8 + lc];
@@ -567,8 +518,8 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
                 const double dta = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dma = -mr - th[r] * dta;
                 dt_r[j] = dta; dma_r[j] = dma;
-                if (dta < 0.0) apmax = fmin(apmax, -t_r[j] / dta);
-                if (dma < 0.0) admax = fmin(admax, -mr / dma);
+                if (dta < 0.0) apmax = fmin(apmax, -t_r[j] * frcp(dta));
+                if (dma < 0.0) admax = fmin(admax, -mr * frcp(dma));
             }
         }
         red_put(4, wmin(apmax)); red_put(5, wmin(admax));
@@ -599,8 +550,8 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
                 const double dtt = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dmm = -h[r] - th[r] * dtt;
                 dm[r] = dmm;
-                if (dtt < 0.0) apx = fmin(apx, -t_r[j] / dtt);
-                if (dmm < 0.0) adx = fmin(adx, -mr / dmm);
+                if (dtt < 0.0) apx = fmin(apx, -t_r[j] * frcp(dtt));
+                if (dmm < 0.0) adx = fmin(adx, -mr * frcp(dmm));
             }
         }
         red_put(7, wmin(apx)); red_put(8, wmin(adx));

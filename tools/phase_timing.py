@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "racinglmpc_amd", "liblmpc_hip_timing.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DLMPC_TIMING",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared", "-DLMPC_TIMING",
                        "-o", so, os.path.join(ROOT, "racinglmpc_amd", "csrc", "lmpc_capi.hip")])
 from racinglmpc_amd import _capi
 _capi.LIB_PATH = so
