@@ -212,7 +212,7 @@ def main():
         }
         if args.sweep:
             sweep = {}
-            for bb in (1, 8, 64, 256, 1024, 4096, 8192):
+            for bb in (1, 8, 64, 256, 512, 1024, 2048, 4096, 8192):
                 c2, _ = make_ctx(g, N, bb, local)
                 i2 = synth_batch(g, bb, N)
                 a2, k2 = device_args(c2, i2, bb, N, S)

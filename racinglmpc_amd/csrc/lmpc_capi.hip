@@ -4,6 +4,7 @@
 #include "lmpc_kernels.hip.h"
 #include "lmpc_solve_mw.hip.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -22,6 +23,7 @@ struct lmpc_ctx {
     lmpc_dev_params dp;
     hipStream_t stream;
     double *mstore, *sstore;                 // device lap stores [lap][col][row]
+    unsigned *mquant; double *mqpar; int mq_chunks;   // K1 prefilter image of the model store, see quantise_lap
     std::vector<int> m_order, m_len;         // model: sorted position -> slot ; length per slot
     std::vector<int> s_len;                  // safe set: rows per lap (incl. addPoint extensions)
     std::vector<int> s_laptime;              // LMPC.LapTime (rows at addTrajectory time)
@@ -34,7 +36,7 @@ struct lmpc_ctx {
     size_t lds_bytes;
     int (*solve_launch)(lmpc_ctx *, int, const lmpc_solve_io &);
     int (*solve_launch_mw)(lmpc_ctx *, int, const lmpc_solve_io &);   // 4 waves per QP, used for small batches
-    int mw_max_batch;
+    int mw_max_batch, n_cu;
     int profiling; std::vector<evpair> events; lmpc_stats stats;
     struct lmpc_rollout_session *ro;
 };
@@ -98,6 +100,7 @@ static void fill_params(lmpc_ctx *c) {
     memcpy(p.track, f.track, sizeof(double) * 6 * f.track_rows); p.track_rows = f.track_rows; p.TL = f.trackLength;
     p.tol_gap = f.tol_gap; p.tol_res = f.tol_res; p.reg = f.reg_lambda; p.max_iter = f.max_iter;
     p.lap_stride = f.max_lap_len; p.mstore = c->mstore; p.sstore = c->sstore;
+    p.mquant = c->mquant; p.mqpar = c->mqpar; p.mq_chunks = c->mq_chunks;
 }
 
 int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
@@ -117,7 +120,7 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     {   // batches that leave SIMDs idle (B <= number of CUs) run the 4-waves-per-QP kernel
         const char *e = getenv("LMPC_MW_MAX_BATCH"); hipDeviceProp_t prop; int cus = 256;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        c->mw_max_batch = e ? atoi(e) : cus;
+        c->mw_max_batch = e ? atoi(e) : cus; c->n_cu = cus;
     } memset(&c->stats, 0, sizeof(c->stats));
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) { delete c; return set_err(LMPC_E_HIP, "hipSetDevice", hipGetErrorString(e)); }
@@ -126,6 +129,11 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     HIPCHK(hipMalloc(&c->mstore, store_elems * sizeof(double)));
     HIPCHK(hipMalloc(&c->sstore, store_elems * sizeof(double)));
     HIPCHK(hipMemset(c->mstore, 0, store_elems * sizeof(double)));
+    c->mq_chunks = (cfg->max_lap_len + K1_CHUNK - 1) / K1_CHUNK;
+    HIPCHK(hipMalloc(&c->mquant, (size_t)cfg->max_laps * 5 * cfg->max_lap_len * sizeof(unsigned)));
+    HIPCHK(hipMalloc(&c->mqpar, (size_t)cfg->max_laps * c->mq_chunks * 6 * sizeof(double)));
+    HIPCHK(hipMemset(c->mquant, 0, (size_t)cfg->max_laps * 5 * cfg->max_lap_len * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->mqpar, 0, (size_t)cfg->max_laps * c->mq_chunks * 6 * sizeof(double)));
     HIPCHK(hipMemset(c->sstore, 0, store_elems * sizeof(double)));
     const size_t B = cfg->max_batch, N = cfg->N, S = cfg->numSS_it > 0 ? cfg->numSS_points : 0, M = 8 * N + S;
 #define DALLOC(ptr, n) HIPCHK(hipMalloc(&c->ptr, std::max<size_t>((n), 1) * sizeof(*c->ptr)))
@@ -149,7 +157,7 @@ int lmpc_destroy(lmpc_ctx *c) {
     hipStreamSynchronize(c->stream);
     rollout_free(c);
     for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-    void *ptrs[] = {c->mstore, c->sstore, c->w_x0, c->w_xLin, c->w_uLin, c->w_uOld, c->w_zt, c->w_xPP, c->w_A, c->w_B, c->w_C, c->w_ssSel, c->w_qSel,
+    void *ptrs[] = {c->mstore, c->sstore, c->mquant, c->mqpar, c->w_x0, c->w_xLin, c->w_uLin, c->w_uOld, c->w_zt, c->w_xPP, c->w_A, c->w_B, c->w_C, c->w_ssSel, c->w_qSel,
                     c->w_succ, c->w_succU, c->w_ztUsed, c->w_xPred, c->w_uPred, c->w_slack, c->w_lam, c->w_sT, c->w_mu, c->w_ztN, c->w_ztuN, c->w_resid,
                     c->w_hasPred, c->w_tstep, c->w_status, c->w_iters, c->w_rstatus};
     for (void *q : ptrs) if (q) hipFree(q);
@@ -171,6 +179,39 @@ static int upload_lap(lmpc_ctx *c, double *store, int slot, const double *x, con
     return LMPC_OK;
 }
 
+// K1 prefilter image of one model-store lap (PredictiveModel.py:180-197 scans (vx, vy, wz, delta, a) . scaling of rows 0..T-2):
+// per 1024-row chunk, every scaled feature is mapped to 28-bit fixed point over the chunk's [min, max] with one common scale
+// 2^28 / (widest range).  The regress kernel ranks rows by integer L1 distances on this image and re-evaluates the survivors
+// in FP64, so the image never decides anything by itself; it only has to be within a few units of the exact scaled values.
+static int quantise_lap(lmpc_ctx *c, int slot, const double *x, const double *u, int T) {
+    const int ls = c->cfg.max_lap_len, nrows = T - 1;
+    std::vector<unsigned> q((size_t)5 * ls, 0u);
+    std::vector<double> par((size_t)c->mq_chunks * 6, 0.0);
+    auto feat = [&](int t, int k) { return (k < 3 ? x[(size_t)t * 6 + k] : u[(size_t)t * 2 + (k - 3)]) * c->cfg.scaling[k]; };
+    for (int t0 = 0, ch = 0; t0 < nrows; t0 += K1_CHUNK, ch++) {
+        const int t1 = std::min(nrows, t0 + K1_CHUNK);
+        double lo[5], rmax = 0.0;
+        for (int k = 0; k < 5; k++) {
+            double l = INFINITY, h = -INFINITY;
+            for (int t = t0; t < t1; t++) { const double v = feat(t, k); if (std::isfinite(v)) { l = std::min(l, v); h = std::max(h, v); } }
+            if (!(l <= h)) { l = 0.0; h = 0.0; }
+            lo[k] = l; rmax = std::max(rmax, std::max(h - l, 1e-9 * std::max(std::fabs(l), std::fabs(h))));
+        }
+        const double sc = 268435456.0 / std::max(rmax, 1e-300);
+        for (int k = 0; k < 5; k++) {
+            par[(size_t)ch * 6 + k] = lo[k];
+            for (int t = t0; t < t1; t++) {
+                const double v = (feat(t, k) - lo[k]) * sc;
+                q[(size_t)k * ls + t] = std::isfinite(v) ? (unsigned)std::min(std::max(v, 0.0), 268435456.0) : 0u;
+            }
+        }
+        par[(size_t)ch * 6 + 5] = sc;
+    }
+    HIPCHK(hipMemcpy(c->mquant + (size_t)slot * 5 * ls, q.data(), q.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->mqpar + (size_t)slot * c->mq_chunks * 6, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
+    return LMPC_OK;
+}
+
 int lmpc_model_add_trajectory(lmpc_ctx *c, const double *x, const double *u, int T) {
     ARGCHK(c && x && u && T >= 2);
     HIPCHK(hipSetDevice(c->cfg.device));
@@ -178,6 +219,7 @@ int lmpc_model_add_trajectory(lmpc_ctx *c, const double *x, const double *u, int
     if (slot >= c->cfg.max_laps) return set_err(LMPC_E_CAPACITY, "model store full", "");
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = upload_lap(c, c->mstore, slot, x, u, nullptr, T); if (rc) return rc;
+    rc = quantise_lap(c, slot, x, u, T); if (rc) return rc;
     c->m_len.push_back(T);
     // PredictiveModel.addTrajectory (PredictiveModel.py:35-46): append if empty or T >= last, else insert before first longer lap
     if (c->m_order.empty() || T >= c->m_len[c->m_order.back()]) c->m_order.push_back(slot);
@@ -189,7 +231,8 @@ int lmpc_model_replace_lap(lmpc_ctx *c, int pos, const double *x, const double *
     ARGCHK(c && x && u && pos >= 0 && pos < (int)c->m_order.size());
     HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
     ARGCHK(T == c->m_len[c->m_order[pos]]);
-    return upload_lap(c, c->mstore, c->m_order[pos], x, u, nullptr, T);
+    int rc = upload_lap(c, c->mstore, c->m_order[pos], x, u, nullptr, T); if (rc) return rc;
+    return quantise_lap(c, c->m_order[pos], x, u, T);
 }
 
 int lmpc_ss_add_trajectory(lmpc_ctx *c, const double *x, const double *u, int T) {
@@ -280,11 +323,21 @@ static void ev_begin(lmpc_ctx *c, int kind) {
 }
 static void ev_end(lmpc_ctx *c) { if (c->profiling) hipEventRecord(c->events.back().b, c->stream); }
 
+// K1 launch shape: queries per work-group shrink (12 -> 6 -> 4 -> ... -> 1) until the grid covers the chip (one work-group per CU is resident)
+static void k1_grid(lmpc_ctx *c, int B, int *qg, int *nblk) {
+    const int N = c->cfg.N, cands[] = {12, 6, 4, 3, 2, 1};
+    int q = 1, np = N;
+    for (int k = 0; k < 6; k++) {
+        q = k1_queries_per_block(cands[k], c->cfg.trToUse, c->cfg.maxNumPoint); np = (N + q - 1) / q;
+        if ((long long)B * np >= (long long)c->n_cu) break;
+    }
+    *qg = q; *nblk = B * np;
+}
 static int launch_regress(lmpc_ctx *c, int B, const double *d_xLin, int xstride, const double *d_uLin, double *dA, double *dB, double *dC, int *dst) {
     int rc = refresh_params(c, true, false); if (rc) return rc;
-    const int items = B * c->cfg.N;
     ev_begin(c, 0);
-    hipLaunchKernelGGL(lmpc_regress_kernel, dim3(items), dim3(WAVE), 0, c->stream, c->dp, items, d_xLin, xstride, d_uLin, dA, dB, dC, dst);
+    int qg, nblk; k1_grid(c, B, &qg, &nblk);
+    hipLaunchKernelGGL(lmpc_regress_kernel, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, d_xLin, xstride, d_uLin, dA, dB, dC, dst);
     ev_end(c);
     HIPCHK(hipGetLastError());
     c->stats.n_regress++;
@@ -538,10 +591,10 @@ int lmpc_rollout_run(lmpc_ctx *c, int max_steps, int *steps_total, int *n_done) 
     const int t_end = std::min(r->T_max, r->t + max_steps);
     while (r->t < t_end) {
         rc = refresh_params(c, true, true); if (rc) return rc;
-        const int items = B * (int)N;
         ev_begin(c, 0);
-        hipLaunchKernelGGL(lmpc_regress_kernel, dim3(items), dim3(WAVE), 0, c->stream, c->dp, items, (const double *)r->d_xLin, (int)(N + 1) * 6, (const double *)r->d_uLin,
-                           r->d_A, r->d_B, r->d_C, r->d_rst);
+        { int qg, nblk; k1_grid(c, B, &qg, &nblk);
+          hipLaunchKernelGGL(lmpc_regress_kernel, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, (const double *)r->d_xLin, (int)(N + 1) * 6, (const double *)r->d_uLin,
+                             r->d_A, r->d_B, r->d_C, r->d_rst); }
         ev_end(c); c->stats.n_regress++;
         lmpc_solve_io io; memset(&io, 0, sizeof(io));
         io.mode = 3; io.A = r->d_A; io.Bm = r->d_B; io.C = r->d_C; io.x0 = r->d_x; io.uOld = r->d_uOld; io.zt = r->d_zt; io.xPredPrev = r->d_xPP; io.hasPred = r->d_hasPred;

@@ -7,8 +7,8 @@
 //                         (replaces osqp_solve_qp, :259-283) + unpack (:364-384)
 //   lmpc_assemble_kernel: explicit reference-form QP matrices, parity checks only (:166-257, :340-362)
 //
-// Execution model: ONE 64-lane wavefront per work item (one (problem, horizon step) pair in K1, one QP
-// in K2+K3), one wave per work-group, all per-item state in LDS; cross-lane sums are wavefront
+// Execution model: K1 runs one 8-wave work-group per problem (a wave per lap); K2+K3 run ONE 64-lane wavefront per QP
+// (or four, lmpc_solve_mw.hip.h), all per-item state in LDS; cross-lane sums are wavefront
 // reductions; sequential recursions (Riccati sweeps) are lane-parallel inside a stage.
 // FP64 throughout (the reference is FP64 end to end; regression normal matrices have cond ~1e5..1e8).
 #pragma once
@@ -29,6 +29,7 @@ struct lmpc_dev_params {
     double tol_gap, tol_res, reg; int max_iter;
     int lap_stride;                 // rows per column (max_lap_len)
     const double *mstore; int mslot[LMPC_MAX_USED_LAPS]; int mlen[LMPC_MAX_USED_LAPS];
+    const unsigned *mquant; const double *mqpar; int mq_chunks;   // K1 prefilter image of the model store (28-bit fixed point) and its per-chunk (lo[5], scale)
     const double *sstore; int sslot[LMPC_MAX_USED_LAPS]; int sslen[LMPC_MAX_USED_LAPS]; int sslapid[LMPC_MAX_USED_LAPS];
     int cur_it;                     // LMPC.it (number of laps in the safe set)
 };
@@ -70,178 +71,6 @@ __device__ __forceinline__ double track_curvature(const lmpc_dev_params &p, doub
     return 0.0;
 }
 
-// =====================================================================================================
-// K1: regression + linearisation.  One wave per (problem b, horizon step i).
-// =====================================================================================================
-#define K1_MAXPTS (LMPC_MAX_USED_LAPS * 8)
-
-__global__ __launch_bounds__(WAVE) void lmpc_regress_kernel(lmpc_dev_params p, int nitems, const double *__restrict__ xLin,
-                                                            int xstride, const double *__restrict__ uLin,
-                                                            double *__restrict__ Aout, double *__restrict__ Bout,
-                                                            double *__restrict__ Cout, int *__restrict__ status) {
-    const int item = blockIdx.x;
-    if (item >= nitems) return;
-    const int lane = threadIdx.x;
-    const int b = item / p.N, i = item % p.N;
-    const double *xq = xLin + (size_t)b * xstride + (size_t)i * 6;
-    const double *uq = uLin + ((size_t)b * p.N + i) * 2;
-
-    __shared__ double pts[K1_MAXPTS][9];     // vx vy wz delta a K y_vx y_vy y_wz   (PredictiveModel.py:141-168)
-    __shared__ double gram[45];              // Q_vx(15) b_vx(5) Q_lat(15) b_vy(5) b_wz(5)
-    __shared__ double theta[3][5];
-    __shared__ double outv[54];
-    __shared__ int st_sh;
-
-    const double xi[5] = {xq[0], xq[1], xq[2], uq[0], uq[1]};     // xuLin, PredictiveModel.py:54
-    const int MAXP = p.maxNumPoint > 8 ? 8 : p.maxNumPoint;
-    int npts = 0;
-    if (lane == 0) st_sh = 0;
-
-    // ---- computeIndices for every used lap (PredictiveModel.py:180-197) ------------------------------
-    for (int c = 0; c < p.trToUse; c++) {
-        const double *base = p.mstore + (size_t)p.mslot[c] * LMPC_COLS * p.lap_stride;
-        const int T = p.mlen[c];
-        double d[8]; int id[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { d[k] = INFINITY; id[k] = 0x7fffffff; }
-        int cnt = 0;
-        for (int t = lane; t < T - 1; t += WAVE) {
-            // la.norm(diff, 1, axis=1) of (Data - x) . scaling : |.| accumulated in feature order, no contraction
-            double nrm = fabs((base[0 * p.lap_stride + t] - xi[0]) * p.scaling[0]);
-            nrm = nrm + fabs((base[1 * p.lap_stride + t] - xi[1]) * p.scaling[1]);
-            nrm = nrm + fabs((base[2 * p.lap_stride + t] - xi[2]) * p.scaling[2]);
-            nrm = nrm + fabs((base[6 * p.lap_stride + t] - xi[3]) * p.scaling[3]);
-            nrm = nrm + fabs((base[7 * p.lap_stride + t] - xi[4]) * p.scaling[4]);
-            if (nrm < p.h) {
-                cnt++;
-                if (nrm < d[7]) {        // keep the 8 smallest of this lane, ascending, earlier row first on ties
-                    d[7] = nrm; id[7] = t;
-#pragma unroll
-                    for (int k = 7; k > 0; k--) {
-                        if (d[k] < d[k - 1]) { double td = d[k]; d[k] = d[k - 1]; d[k - 1] = td; int ti = id[k]; id[k] = id[k - 1]; id[k - 1] = ti; }
-                    }
-                }
-            }
-        }
-        const int total = (int)wave_sum((double)cnt);
-        const int nsel = total >= MAXP ? MAXP : total;       // >= MaxNumPoint -> argsort[:7], else all within h
-        double seld[8]; int seli[8];
-        for (int r = 0; r < nsel; r++) {
-            double v = d[0]; int vi = id[0];
-            wave_argmin(v, vi);
-            seld[r] = v; seli[r] = vi;
-            if (d[0] == v && id[0] == vi) {                   // winner pops its head
-#pragma unroll
-                for (int k = 0; k < 7; k++) { d[k] = d[k + 1]; id[k] = id[k + 1]; }
-                d[7] = INFINITY; id[7] = 0x7fffffff;
-            }
-        }
-        if (total < MAXP) {                                   // np.where order = ascending row index
-            for (int a = 1; a < nsel; a++)
-                for (int q = a; q > 0 && seli[q] < seli[q - 1]; q--) {
-                    int ti = seli[q]; seli[q] = seli[q - 1]; seli[q - 1] = ti; double td = seld[q]; seld[q] = seld[q - 1]; seld[q - 1] = td;
-                }
-        }
-        if (lane < nsel) {
-            int r = lane; double dd = seld[0]; int ii = seli[0];
-#pragma unroll
-            for (int k = 1; k < 8; k++) if (r == k) { dd = seld[k]; ii = seli[k]; }
-            double q = dd / p.h; q = q * q;
-            double K = (1.0 - q) * 3.0 / 4.0;                  // :193
-            double *pt = pts[npts + r];
-            pt[0] = base[0 * p.lap_stride + ii]; pt[1] = base[1 * p.lap_stride + ii]; pt[2] = base[2 * p.lap_stride + ii];
-            pt[3] = base[6 * p.lap_stride + ii]; pt[4] = base[7 * p.lap_stride + ii]; pt[5] = K;
-            pt[6] = base[0 * p.lap_stride + ii + 1]; pt[7] = base[1 * p.lap_stride + ii + 1]; pt[8] = base[2 * p.lap_stride + ii + 1];
-        }
-        npts += nsel;
-    }
-    __syncthreads();
-
-    // ---- compute_Q_M / compute_b (:141-168): Q = M' diag(K) M (+ lamb I), b = -M' diag(K) y --------------
-    if (lane < 45) {
-        int sys, e;                      // sys 0: vx system (input feature a), 1: lateral (input feature delta)
-        if (lane < 20) { sys = 0; e = lane; } else { sys = 1; e = lane - 20; }
-        const int fin = sys == 0 ? 4 : 3;        // column of pts holding the input feature
-        double acc = 0.0;
-        if (e < 15) {
-            int r = 0, cc = e; while (cc >= 5 - r) { cc -= 5 - r; r++; } cc += r;      // upper-triangular (r, cc)
-            for (int q = 0; q < npts; q++) {
-                const double *pt = pts[q];
-                double fr = r < 3 ? pt[r] : (r == 3 ? pt[fin] : 1.0);
-                double fc = cc < 3 ? pt[cc] : (cc == 3 ? pt[fin] : 1.0);
-                acc = fma(fr * pt[5], fc, acc);
-            }
-            if (r == cc) acc += p.lamb;
-        } else {
-            int r = (e - 15) % 5, tgt = sys == 0 ? 0 : 1 + (e - 15) / 5;
-            for (int q = 0; q < npts; q++) {
-                const double *pt = pts[q];
-                double fr = r < 3 ? pt[r] : (r == 3 ? pt[fin] : 1.0);
-                acc = fma(fr * pt[5], pt[6 + tgt], acc);
-            }
-            acc = -acc;
-        }
-        gram[lane] = acc;
-    }
-    __syncthreads();
-
-    // ---- LMPC_LocLinReg (:170-178): unconstrained qp(Q, b)  <=>  Q theta = -b ; Cholesky 5x5 --------------
-    if (lane < 3) {
-        const double *Qv = lane == 0 ? &gram[0] : &gram[20];
-        const double *bv = lane == 0 ? &gram[15] : (lane == 1 ? &gram[35] : &gram[40]);
-        double Lm[5][5]; int bad = 0;
-        { int e = 0; for (int r = 0; r < 5; r++) for (int c = r; c < 5; c++) { Lm[c][r] = Qv[e]; Lm[r][c] = Qv[e]; e++; } }
-        for (int j = 0; j < 5; j++) {
-            double dj = Lm[j][j];
-            for (int k = 0; k < j; k++) dj -= Lm[j][k] * Lm[j][k];
-            if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
-            dj = sqrt(dj); Lm[j][j] = dj;
-            for (int r = j + 1; r < 5; r++) {
-                double v = Lm[r][j];
-                for (int k = 0; k < j; k++) v -= Lm[r][k] * Lm[j][k];
-                Lm[r][j] = v / dj;
-            }
-        }
-        double y[5];
-        for (int r = 0; r < 5; r++) { double v = -bv[r]; for (int k = 0; k < r; k++) v -= Lm[r][k] * y[k]; y[r] = v / Lm[r][r]; }
-        for (int r = 4; r >= 0; r--) { double v = y[r]; for (int k = r + 1; k < 5; k++) v -= Lm[k][r] * y[k]; y[r] = v / Lm[r][r]; }
-        for (int r = 0; r < 5; r++) theta[lane][r] = bad ? 0.0 : y[r];
-        if (bad || npts < 5) atomicOr(&st_sh, LMPC_ST_REG_SINGULAR);
-    }
-    if (lane < 54) outv[lane] = 0.0;
-    __syncthreads();
-
-    // ---- assemble A_i, B_i, C_i (:70-135) -----------------------------------------------------------------
-    if (lane == 0) {
-        double *Ai = outv, *Bi = outv + 36, *Ci = outv + 48;
-        for (int r = 0; r < 3; r++) { Ai[r * 6 + 0] = theta[r][0]; Ai[r * 6 + 1] = theta[r][1]; Ai[r * 6 + 2] = theta[r][2]; Ci[r] = theta[r][4]; }
-        Bi[0 * 2 + 1] = theta[0][3]; Bi[1 * 2 + 0] = theta[1][3]; Bi[2 * 2 + 0] = theta[2][3];
-        const double vx = xq[0], vy = xq[1], wz = xq[2], epsi = xq[3], s = xq[4], ey = xq[5], dt = p.dt;
-        int bad = 0;
-        const double cur = track_curvature(p, s, &bad);
-        if (bad) atomicOr(&st_sh, LMPC_ST_NO_SEGMENT);
-        const double den = 1 - cur * ey, ce = cos(epsi), se = sin(epsi);
-        const double xv[6] = {vx, vy, wz, epsi, s, ey};
-        double row[6], dot;
-        row[0] = -dt * ce / den * cur; row[1] = dt * se / den * cur; row[2] = dt;
-        row[3] = 1 - dt * (-vx * se - vy * ce) / den * cur; row[4] = 0;
-        row[5] = dt * (vx * ce - vy * se) / (den * den) * cur * (-cur);
-        dot = 0; for (int j = 0; j < 6; j++) { Ai[18 + j] = row[j]; dot += row[j] * xv[j]; }
-        Ci[3] = epsi + dt * (wz - (vx * ce - vy * se) / (1 - cur * ey) * cur) - dot;
-        row[0] = dt * (ce / den); row[1] = -dt * (se / den); row[2] = 0; row[3] = dt * (-vx * se - vy * ce) / den; row[4] = 1;
-        row[5] = -dt * (vx * ce - vy * se) / (den * den) * (-cur);
-        dot = 0; for (int j = 0; j < 6; j++) { Ai[24 + j] = row[j]; dot += row[j] * xv[j]; }
-        Ci[4] = s + dt * ((vx * ce - vy * se) / (1 - cur * ey)) - dot;
-        row[0] = dt * se; row[1] = dt * ce; row[2] = 0; row[3] = dt * (vx * ce - vy * se); row[4] = 0; row[5] = 1;
-        dot = 0; for (int j = 0; j < 6; j++) { Ai[30 + j] = row[j]; dot += row[j] * xv[j]; }
-        Ci[5] = ey + dt * (vx * se + vy * ce) - dot;
-    }
-    __syncthreads();
-    if (lane < 36) Aout[(size_t)item * 36 + lane] = outv[lane];
-    else if (lane < 48) Bout[(size_t)item * 12 + (lane - 36)] = outv[lane];
-    else if (lane < 54) Cout[(size_t)item * 6 + (lane - 48)] = outv[lane];
-    if (lane == 0) status[item] = st_sh;
-}
 
 // =====================================================================================================
 // K2 + K3: safe-set selection + structured primal-dual interior-point QP solve.  One wave per QP.
@@ -331,6 +160,354 @@ __device__ __forceinline__ double frsqrt(double x) {
     y = y * fma(-0.5 * x * y, y, 1.5);
     y = y * fma(-0.5 * x * y, y, 1.5);
     return y;
+}
+
+// =====================================================================================================
+// K1 (block form): regression + linearisation of ALL horizon steps of one problem by one work-group.
+//
+// Every row of every used lap is a k-NN candidate for every query (with the reference's bandwidth h = 5 all ~1000 rows of a
+// lap lie inside the kernel support), so a one-wave-per-(problem, step) mapping re-reads each lap N times per problem and is bound
+// by L2 bandwidth (that was the first version of this kernel: 79 us at batch 256, this one 30 us, bit-identical output).  Here a wave owns one lap: it loads the lap's 5 regression features ONCE into registers
+// (16 rows per lane per 1024-row chunk) and scans them for its share of the N queries.  Selecting the MaxNumPoint nearest rows
+// of a lap (PredictiveModel.py:180-197):
+//   * every lane takes the minimum of its 16 distances; the minimum inside each group of 8 lanes are 8 distinct rows, so the
+//     largest of the 8 group minima bounds the MaxNumPoint-th smallest distance (MaxNumPoint <= 8) -- one wave reduction;
+//   * rows not above that bound (a few tens of the 1024) are appended to a small LDS list with an LDS atomic counter;
+//   * each list entry's rank is counted against the list, lexicographic in (distance, row): exactly the order of the
+//     per-lane sorted lists + wave arg-min merge it replaces (ties: earlier row first), so the selection is bit-identical;
+//   * a list overflow (pathological ties) falls back to MaxNumPoint rounds of wave arg-min extraction.
+// The normal equations, the three 5x5 Cholesky solves and the analytic rows are then batched over the queries of the block
+// (threads = (query, entry) pairs) instead of running as serial tails of single lanes.
+// =====================================================================================================
+#define K1_NW 8                    // waves per work-group
+#define K1_NT (K1_NW * WAVE)
+#define K1_QG 12                   // queries per pass
+#define K1_RPL 16                  // rows per lane per chunk
+#define K1_CHUNK (K1_RPL * WAVE)
+#define K1_PTS (K1_QG * 32)        // staged points per pass (32 per query when trToUse * MaxNumPoint <= 32)
+
+template <int CTRL> __device__ __forceinline__ unsigned dpp_minu(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned wminu(unsigned v) {                       // wave-wide unsigned minimum, all lanes
+    v = dpp_minu<DPP_QP_X1>(v); v = dpp_minu<DPP_QP_X2>(v); v = dpp_minu<DPP_HALF_MIRROR>(v); v = dpp_minu<DPP_MIRROR>(v);
+    auto r0 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = r0[0] < r0[1] ? r0[0] : r0[1];
+    auto r1 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return r1[0] < r1[1] ? r1[0] : r1[1];
+}
+__device__ __forceinline__ bool k1_less(double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); }
+// rank of (d, i) among the 16 entries of its row of lanes, lexicographic: every other lane's entry passes by once
+template <int ROT> __device__ __forceinline__ void k1_row_rank(double d, int i, int &rank) {
+    if constexpr (ROT < 16) {
+        const double od = dpp_mov<0x120 + ROT>(d);
+        const int oi = __builtin_amdgcn_update_dpp(i, i, 0x120 + ROT, 0xf, 0xf, false);
+        rank += k1_less(od, oi, d, i) ? 1 : 0;
+        k1_row_rank<ROT + 1>(d, i, rank);
+    }
+}
+__device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned c) {   // |a - b| + c
+    unsigned r; asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+__device__ __forceinline__ float wminf(float v) {                           // wave-wide float minimum, all lanes
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+// queries per block for a given cap qg (host and device use the same rule); the grid is B * ceil(N / k1_queries_per_block())
+__host__ __device__ inline int k1_queries_per_block(int qg, int trToUse, int maxNumPoint) {
+    const int pp = trToUse * (maxNumPoint > 8 ? 8 : maxNumPoint);
+    int q = qg < K1_QG ? qg : K1_QG;
+    if (pp > 0 && K1_PTS / pp < q) q = K1_PTS / pp;
+    return q < 1 ? 1 : q;
+}
+
+__global__ __launch_bounds__(K1_NT) void lmpc_regress_kernel(lmpc_dev_params p, int B, int qg, const double *__restrict__ xLin, int xstride,
+                                                             const double *__restrict__ uLin, double *__restrict__ Aout,
+                                                             double *__restrict__ Bout, double *__restrict__ Cout, int *__restrict__ status) {
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    __shared__ double qf[K1_QG][5];                                        // xuLin of the queries in flight (PredictiveModel.py:54)
+    __shared__ int cseg[K1_NW][K1_QG][16]; __shared__ int ccnt[K1_NW][K1_QG];   // prefilter survivors (row indices) per wave and query
+    __shared__ double seld[K1_QG][LMPC_MAX_USED_LAPS][8]; __shared__ int seli[K1_QG][LMPC_MAX_USED_LAPS][8];
+    __shared__ int nsel[K1_QG][LMPC_MAX_USED_LAPS];
+    __shared__ double pts[K1_PTS][10];           // vx vy wz delta a K y_vx y_vy y_wz 1   (PredictiveModel.py:141-168)
+    __shared__ double gram[K1_QG][45];           // Q_vx(15) b_vx(5) Q_lat(15) b_vy(5) b_wz(5)
+    __shared__ double theta[K1_QG][3][5];
+    __shared__ double outv[K1_QG][54];
+    __shared__ int st_s[K1_QG];
+
+    const int N = p.N, L = p.trToUse;
+    const int MAXP = p.maxNumPoint > 8 ? 8 : p.maxNumPoint;
+    const int PP = L * MAXP;                                               // point slots per query (lap-major, rank-minor)
+    const int QGe = k1_queries_per_block(qg, L, p.maxNumPoint);            // queries of this block
+    const int npass = (N + QGe - 1) / QGe;
+    const int b = blockIdx.x / npass;
+    if (b >= B) return;
+    const int nsub = K1_NW / L > 0 ? K1_NW / L : 1;                        // waves sharing one lap split its queries
+    const int myc = wave % L, sgi = wave / L;
+    const double h = p.h;
+
+    {
+        const int i0 = (blockIdx.x % npass) * QGe;
+        const int nq = N - i0 < QGe ? N - i0 : QGe;
+        if (tid < nq * 5) {
+            const int qi = tid / 5, f = tid % 5;
+            qf[qi][f] = f < 3 ? xLin[(size_t)b * xstride + (size_t)(i0 + qi) * 6 + f] : uLin[((size_t)b * N + i0 + qi) * 2 + (f - 3)];
+        }
+        if (tid < nq * LMPC_MAX_USED_LAPS) nsel[tid / LMPC_MAX_USED_LAPS][tid % LMPC_MAX_USED_LAPS] = 0;
+        if (tid < nq) st_s[tid] = 0;
+        __syncthreads();
+
+        // ---- computeIndices (PredictiveModel.py:180-197): wave (lap c, query share sgi) -------------------------------
+        for (int c = myc; c < L && sgi < nsub; c += K1_NW) {               // (c += K1_NW: only when trToUse > 8 waves, never here)
+            const double *base = p.mstore + (size_t)p.mslot[c] * LMPC_COLS * p.lap_stride;
+            const int ls = p.lap_stride;
+            const int nrows = p.mlen[c] - 1;
+            for (int t0 = 0; t0 < nrows; t0 += K1_CHUNK) {
+                // Prefilter image of this lane's rows: the scaled features in 28-bit fixed point, quantised by the host when the lap was
+                // stored (lmpc_capi.hip: quantise_lap), per 1024-row chunk over the chunk's own [min, max] with ONE scale for the five
+                // features (the L1 norm weighs them equally).  One v_sad_u32 per feature gives the L1 distance; every decision is
+                // re-made in FP64 below.  A query outside [min, max] is clamped: that shifts all of a feature's |differences| by the
+                // same amount, so the order of the rows is untouched.
+                const double *qp = p.mqpar + ((size_t)p.mslot[c] * p.mq_chunks + t0 / K1_CHUNK) * 6;
+                const double qlo[5] = {qp[0], qp[1], qp[2], qp[3], qp[4]}, qsc = qp[5];
+                const unsigned *qb = p.mquant + (size_t)p.mslot[c] * 5 * ls;
+                unsigned qv[5][K1_RPL];
+#pragma unroll
+                for (int k = 0; k < 5; k++)
+#pragma unroll
+                    for (int j = 0; j < K1_RPL; j++) { const int t = t0 + lane + WAVE * j; qv[k][j] = qb[(size_t)k * ls + (t < nrows ? t : 0)]; }
+#pragma unroll
+                for (int j = 0; j < K1_RPL; j++) if (t0 + lane + WAVE * j >= nrows) qv[0][j] = 0x70000000u;   // beyond the lap: farther than any row
+                // ---- step A: integer prefilter, one query at a time; survivors (row indices) go to the query's 16-slot LDS segment ----
+                const int nqw = nq > sgi ? (nq - sgi + nsub - 1) / nsub : 0;                  // queries of this wave: qi = sgi + s nsub
+                // (two queries per trip: their reduction chains are independent and interleave)
+                for (int s = 0; s < nqw; s += 2) {
+                    const bool two = s + 1 < nqw;
+                    const int qa = sgi + s * nsub, qb2 = two ? qa + nsub : qa;
+                    unsigned ya[5], yb[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        ya[k] = (unsigned)fmin(fmax((qf[qa][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 268435456.0);
+                        yb[k] = (unsigned)fmin(fmax((qf[qb2][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 268435456.0);
+                    }
+                    unsigned ea[K1_RPL], eb[K1_RPL], ma = 0xffffffffu, mb = 0xffffffffu;
+#pragma unroll
+                    for (int j = 0; j < K1_RPL; j++) {
+                        unsigned a_ = 0, b_ = 0;
+#pragma unroll
+                        for (int k = 0; k < 5; k++) { a_ = sad_u32(qv[k][j], ya[k], a_); b_ = sad_u32(qv[k][j], yb[k], b_); }
+                        ea[j] = a_; eb[j] = b_; ma = a_ < ma ? a_ : ma; mb = b_ < mb ? b_ : mb;
+                    }
+                    // MAXP-th smallest distinct lane minimum: at least MAXP rows lie at or below it (one-instruction DPP integer minima)
+                    unsigned ba = 0u, bb = 0u;
+                    for (int r = 0; r < MAXP; r++) {
+                        ba = wminu((r == 0 || ma > ba) ? ma : 0xffffffffu);
+                        bb = wminu((r == 0 || mb > bb) ? mb : 0xffffffffu);
+                    }
+                    // quantisation error of a row: < 2 units per feature; the prefilter keeps everything that could be in the top MAXP
+                    const unsigned ta = ba > 0xffffff00u ? 0xffffffffu : ba + 12u, tb = bb > 0xffffff00u ? 0xffffffffu : bb + 12u;
+                    int na = 0, nb = 0;
+#pragma unroll
+                    for (int j = 0; j < K1_RPL; j++) {
+                        const bool ca = ea[j] <= ta, cb = eb[j] <= tb;
+                        const unsigned long long mka = __ballot(ca), mkb = __ballot(cb);
+                        if (mka | mkb) {
+                            const int pa = na + __builtin_amdgcn_mbcnt_hi((unsigned)(mka >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mka, 0));
+                            const int pb = nb + __builtin_amdgcn_mbcnt_hi((unsigned)(mkb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mkb, 0));
+                            if (ca && pa < 16) cseg[wave][s][pa] = t0 + lane + WAVE * j;
+                            if (cb && pb < 16 && two) cseg[wave][s + 1][pb] = t0 + lane + WAVE * j;
+                            na += __popcll(mka); nb += __popcll(mkb);
+                        }
+                    }
+                    if (lane == 0) { ccnt[wave][s] = na; if (two) ccnt[wave][s + 1] = nb; }
+                }
+                // ---- step B: exact FP64 distances of the survivors, four queries at a time (one per row of 16 lanes), ranked inside the
+                //      row by 15 DPP rotations; the running selection of earlier chunks rides along as extra entries ----
+                for (int s0 = 0; s0 < nqw; s0 += 4) {
+                    const int s = s0 + (lane >> 4), r = lane & 15;
+                    const bool live = s < nqw;
+                    const int qi = live ? sgi + s * nsub : 0;
+                    const int cnt = live ? ccnt[wave][live ? s : 0] : 0, ns = live ? nsel[qi][c] : 0;
+                    const bool ovf = cnt + ns > 16;
+                    double dv = INFINITY; int iv = 0x7fffffff;
+                    if (live && !ovf) {
+                        if (r < cnt) {
+                            iv = cseg[wave][s][r];
+                            const bool real = iv < nrows;
+                            iv = real ? iv : 0;
+                            // la.norm(diff, 1, axis=1) of (Data - x) . scaling : |.| accumulated in feature order, no contraction
+                            double nrm = fabs((base[0 * ls + iv] - qf[qi][0]) * p.scaling[0]);
+                            nrm = nrm + fabs((base[1 * ls + iv] - qf[qi][1]) * p.scaling[1]);
+                            nrm = nrm + fabs((base[2 * ls + iv] - qf[qi][2]) * p.scaling[2]);
+                            nrm = nrm + fabs((base[6 * ls + iv] - qf[qi][3]) * p.scaling[3]);
+                            nrm = nrm + fabs((base[7 * ls + iv] - qf[qi][4]) * p.scaling[4]);
+                            dv = real ? nrm : INFINITY;
+                        } else if (r < cnt + ns) { dv = seld[qi][c][r - cnt]; iv = seli[qi][c][r - cnt]; }
+                    }
+                    const bool in_h = dv < h;
+                    const double kd = in_h ? dv : INFINITY;                                   // rows outside h never outrank anything
+                    int rank = 0;
+                    k1_row_rank<1>(kd, iv, rank);
+                    const unsigned long long mh = __ballot(in_h);
+                    const int nin = __popcll((mh >> (lane & 48)) & 0xffffull);
+                    if (live && !ovf) {
+                        if (in_h && rank < MAXP) { seld[qi][c][rank] = dv; seli[qi][c][rank] = iv; }
+                        if (r == 0) nsel[qi][c] = nin < MAXP ? nin : MAXP;
+                    }
+                    // prefilter overflow (massive ties): MAXP rounds of exact arg-min extraction over the chunk + running selection
+                    unsigned long long mo = __ballot(live && ovf && r == 0);
+                    while (mo) {
+                        const int sl = s0 + (__builtin_ctzll(mo) >> 4); mo &= mo - 1;
+                        const int qj = sgi + sl * nsub, nsj = nsel[qj][c];
+                        const double x0 = qf[qj][0], x1 = qf[qj][1], x2 = qf[qj][2], x3 = qf[qj][3], x4 = qf[qj][4];
+                        const double od = lane < nsj ? seld[qj][c][lane] : INFINITY; const int oi = lane < nsj ? seli[qj][c][lane] : 0x7fffffff;
+                        double pd = -INFINITY; int pi = -1, got = 0;
+                        double outd = 0.0; int outi = 0;
+                        for (int rr = 0; rr < MAXP; rr++) {
+                            double bd = INFINITY; int bi = 0x7fffffff;
+                            if (k1_less(pd, pi, od, oi)) { bd = od; bi = oi; }
+                            for (int j = 0; j < K1_RPL; j++) {
+                                const int tj = t0 + lane + WAVE * j;
+                                if (tj < nrows) {
+                                    double nrm = fabs((base[0 * ls + tj] - x0) * p.scaling[0]);
+                                    nrm = nrm + fabs((base[1 * ls + tj] - x1) * p.scaling[1]);
+                                    nrm = nrm + fabs((base[2 * ls + tj] - x2) * p.scaling[2]);
+                                    nrm = nrm + fabs((base[6 * ls + tj] - x3) * p.scaling[3]);
+                                    nrm = nrm + fabs((base[7 * ls + tj] - x4) * p.scaling[4]);
+                                    if (nrm < h && k1_less(pd, pi, nrm, tj) && k1_less(nrm, tj, bd, bi)) { bd = nrm; bi = tj; }
+                                }
+                            }
+                            wave_argmin(bd, bi);
+                            if (!(bd < INFINITY)) break;
+                            if (lane == rr) { outd = bd; outi = bi; }
+                            pd = bd; pi = bi; got++;
+                        }
+                        if (lane < got) { seld[qj][c][lane] = outd; seli[qj][c][lane] = outi; }
+                        if (lane == 0) nsel[qj][c] = got;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- stage the selected points: slot = lap * MAXP + rank; empty slots carry weight K = 0 (they add exact zeros) ----
+        for (int e = tid; e < nq * PP; e += K1_NT) {
+            const int qi = e / PP, sl = e % PP, c = sl / MAXP, r = sl % MAXP;
+            const int ns = nsel[qi][c];
+            double *pt = pts[qi * PP + sl];
+            if (r < ns) {
+                int pick = r;
+                if (ns < MAXP) {                                           // fewer than MaxNumPoint inside h: np.where order = ascending row index
+                    for (int a_ = 0; a_ < ns; a_++) {
+                        int rk = 0;
+                        for (int m2 = 0; m2 < ns; m2++) rk += seli[qi][c][m2] < seli[qi][c][a_] ? 1 : 0;
+                        if (rk == r) pick = a_;
+                    }
+                }
+                const double dd = seld[qi][c][pick]; const int ii = seli[qi][c][pick];
+                const double *base = p.mstore + (size_t)p.mslot[c] * LMPC_COLS * p.lap_stride;
+                double q = dd / h; q = q * q;
+                pt[0] = base[0 * p.lap_stride + ii]; pt[1] = base[1 * p.lap_stride + ii]; pt[2] = base[2 * p.lap_stride + ii];
+                pt[3] = base[6 * p.lap_stride + ii]; pt[4] = base[7 * p.lap_stride + ii]; pt[5] = (1.0 - q) * 3.0 / 4.0;        // :193
+                pt[6] = base[0 * p.lap_stride + ii + 1]; pt[7] = base[1 * p.lap_stride + ii + 1]; pt[8] = base[2 * p.lap_stride + ii + 1]; pt[9] = 1.0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 10; k++) pt[k] = 0.0;
+            }
+        }
+        __syncthreads();
+
+        // ---- compute_Q_M / compute_b (:141-168): Q = M' diag(K) M (+ lamb I), b = -M' diag(K) y ---------------------------
+        // 35 distinct sums per query: the vx system (15 + 5), and of the lateral system only what involves delta (5) and its two
+        // right-hand sides (10); the 10 entries of Q_lat over (vx, vy, wz, 1) are the same sums as in Q_vx and are copied.
+        for (int e2 = tid; e2 < nq * 35; e2 += K1_NT) {
+            const int qi = e2 / 35, le = e2 % 35;
+            int r, cc, sys = le < 20 ? 0 : 1, tgt = -1, e;
+            if (le < 15) { e = le; r = 0; cc = e; while (cc >= 5 - r) { cc -= 5 - r; r++; } cc += r; }            // upper-triangular (r, cc)
+            else if (le < 20) { e = le; r = le - 15; cc = 0; tgt = 0; }
+            else if (le < 25) { const int k = le - 20; r = k < 3 ? k : 3; cc = k < 4 ? 3 : 4; e = r * 5 - r * (r - 1) / 2 + (cc - r); }
+            else { const int j = le - 25; r = j % 5; cc = 0; tgt = 1 + j / 5; e = 15 + j; }
+            const int fin = sys == 0 ? 4 : 3;        // column of pts holding the input feature: a (vx system) / delta (lateral)
+            const int o1 = r < 3 ? r : (r == 3 ? fin : 9), o2 = tgt >= 0 ? 6 + tgt : (cc < 3 ? cc : (cc == 3 ? fin : 9));
+            const double (*pq)[10] = &pts[qi * PP];
+            double acc = 0.0;
+#pragma unroll 4
+            for (int q = 0; q < PP; q++) acc = fma(pq[q][o1] * pq[q][5], pq[q][o2], acc);
+            if (tgt >= 0) acc = -acc; else if (r == cc) acc += p.lamb;
+            gram[qi][sys * 20 + e] = acc;
+            if (le < 15 && r != 3 && cc != 3) gram[qi][20 + e] = acc;
+        }
+        __syncthreads();
+
+        // ---- LMPC_LocLinReg (:170-178): unconstrained qp(Q, b)  <=>  Q theta = -b ; Cholesky 5x5, one thread per system ----
+        if (tid < nq * 3) {
+            const int qi = tid / 3, sy = tid % 3;
+            const double *Qv = sy == 0 ? &gram[qi][0] : &gram[qi][20];
+            const double *bv = sy == 0 ? &gram[qi][15] : (sy == 1 ? &gram[qi][35] : &gram[qi][40]);
+            double Lm[5][5]; int bad = 0;
+            { int e = 0; for (int r = 0; r < 5; r++) for (int c = r; c < 5; c++) { Lm[c][r] = Qv[e]; Lm[r][c] = Qv[e]; e++; } }
+            for (int j = 0; j < 5; j++) {
+                double dj = Lm[j][j];
+                for (int k = 0; k < j; k++) dj -= Lm[j][k] * Lm[j][k];
+                if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
+                dj = sqrt(dj); Lm[j][j] = dj;
+                for (int r = j + 1; r < 5; r++) {
+                    double v = Lm[r][j];
+                    for (int k = 0; k < j; k++) v -= Lm[r][k] * Lm[j][k];
+                    Lm[r][j] = v / dj;
+                }
+            }
+            double y[5];
+            for (int r = 0; r < 5; r++) { double v = -bv[r]; for (int k = 0; k < r; k++) v -= Lm[r][k] * y[k]; y[r] = v / Lm[r][r]; }
+            for (int r = 4; r >= 0; r--) { double v = y[r]; for (int k = r + 1; k < 5; k++) v -= Lm[k][r] * y[k]; y[r] = v / Lm[r][r]; }
+            for (int r = 0; r < 5; r++) theta[qi][sy][r] = bad ? 0.0 : y[r];
+            int npts = 0;
+            for (int c = 0; c < L; c++) npts += nsel[qi][c];
+            if (bad || npts < 5) atomicOr(&st_s[qi], LMPC_ST_REG_SINGULAR);
+        }
+        for (int e = tid; e < nq * 54; e += K1_NT) outv[e / 54][e % 54] = 0.0;
+        __syncthreads();
+
+        // ---- assemble A_i, B_i, C_i (:70-135), one thread per query ------------------------------------------------------
+        if (tid < nq) {
+            const int qi = tid;
+            const double *xq = xLin + (size_t)b * xstride + (size_t)(i0 + qi) * 6;
+            double *Ai = outv[qi], *Bi = outv[qi] + 36, *Ci = outv[qi] + 48;
+            for (int r = 0; r < 3; r++) { Ai[r * 6 + 0] = theta[qi][r][0]; Ai[r * 6 + 1] = theta[qi][r][1]; Ai[r * 6 + 2] = theta[qi][r][2]; Ci[r] = theta[qi][r][4]; }
+            Bi[0 * 2 + 1] = theta[qi][0][3]; Bi[1 * 2 + 0] = theta[qi][1][3]; Bi[2 * 2 + 0] = theta[qi][2][3];
+            const double vx = xq[0], vy = xq[1], wz = xq[2], epsi = xq[3], s = xq[4], ey = xq[5], dt = p.dt;
+            int bad = 0;
+            const double cur = track_curvature(p, s, &bad);
+            if (bad) atomicOr(&st_s[qi], LMPC_ST_NO_SEGMENT);
+            const double den = 1 - cur * ey, ce = cos(epsi), se = sin(epsi);
+            const double xv[6] = {vx, vy, wz, epsi, s, ey};
+            double row[6], dot;
+            row[0] = -dt * ce / den * cur; row[1] = dt * se / den * cur; row[2] = dt;
+            row[3] = 1 - dt * (-vx * se - vy * ce) / den * cur; row[4] = 0;
+            row[5] = dt * (vx * ce - vy * se) / (den * den) * cur * (-cur);
+            dot = 0; for (int j = 0; j < 6; j++) { Ai[18 + j] = row[j]; dot += row[j] * xv[j]; }
+            Ci[3] = epsi + dt * (wz - (vx * ce - vy * se) / (1 - cur * ey) * cur) - dot;
+            row[0] = dt * (ce / den); row[1] = -dt * (se / den); row[2] = 0; row[3] = dt * (-vx * se - vy * ce) / den; row[4] = 1;
+            row[5] = -dt * (vx * ce - vy * se) / (den * den) * (-cur);
+            dot = 0; for (int j = 0; j < 6; j++) { Ai[24 + j] = row[j]; dot += row[j] * xv[j]; }
+            Ci[4] = s + dt * ((vx * ce - vy * se) / (1 - cur * ey)) - dot;
+            row[0] = dt * se; row[1] = dt * ce; row[2] = 0; row[3] = dt * (vx * ce - vy * se); row[4] = 0; row[5] = 1;
+            dot = 0; for (int j = 0; j < 6; j++) { Ai[30 + j] = row[j]; dot += row[j] * xv[j]; }
+            Ci[5] = ey + dt * (vx * se + vy * ce) - dot;
+        }
+        __syncthreads();
+        for (int e = tid; e < nq * 54; e += K1_NT) {
+            const int qi = e / 54, le = e % 54; const size_t item = (size_t)b * N + i0 + qi;
+            if (le < 36) Aout[item * 36 + le] = outv[qi][le];
+            else if (le < 48) Bout[item * 12 + (le - 36)] = outv[qi][le];
+            else Cout[item * 6 + (le - 48)] = outv[qi][le];
+        }
+        if (tid < nq) status[(size_t)b * N + i0 + tid] = st_s[tid];
+        __syncthreads();
+    }
 }
 
 // parameter block staged in LDS (lane-dependent indexing of kernel arguments would go through global memory)
