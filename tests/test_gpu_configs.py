@@ -168,3 +168,58 @@ def test_plain_mpc_horizons(built, N):
         w = np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()])
         assert cert < 1e-8 and np.abs(w - ex.x[:8 * N + 6]).max() < common.TOL_XU
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["short_laps", "multi_chunk", "few_inside_h", "maxp8", "maxp3", "ties", "massive_ties"])
+def test_regression_edge_cases(built, case, monkeypatch):
+    """K1 against the oracle's computeIndices / regressionAndLinearization on lap stores that exercise every selection path:
+    laps shorter than a wave, laps longer than one 1024-row chunk, fewer than MaxNumPoint rows inside h (np.where order),
+    MaxNumPoint 3 and 8, exact distance ties (lower row first) and a flood of ties (prefilter overflow -> arg-min extraction)."""
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    g = common.load_lmpc_golden()
+    rng = np.random.default_rng(hash(case) % 2**31)
+    xP, uP = g["xPID"], g["uPID"]
+    N, B = 12, 24
+    opts = dict(short_laps=dict(T=[40, 70, 64, 65], L=4), multi_chunk=dict(T=[1500, 2300, 1025], L=3), few_inside_h=dict(T=[600, 700, 800, 900], L=4, h=0.16, lamb=1e-7),
+                maxp8=dict(T=[500, 640], L=2, maxp=8), maxp3=dict(T=[400, 450, 500, 300], L=4, maxp=3), ties=dict(T=[300, 300, 300], L=3, ties=8),
+                massive_ties=dict(T=[400, 500], L=2, ties=150))[case]
+    cfg, par = common.lmpc_config(g, N, max_batch=B, max_lap_len=4096)
+    cfg.trToUse = opts["L"]; cfg.h = opts.get("h", 5.0); cfg.lamb = opts.get("lamb", 0.0); cfg.maxNumPoint = opts.get("maxp", 7)
+    monkeypatch.setattr(orc, "H_BAND", cfg.h); monkeypatch.setattr(orc, "LAMB", cfg.lamb); monkeypatch.setattr(orc, "MAXNUMPOINT", cfg.maxNumPoint)
+    ctx = _capi.Context(cfg)
+    model = orc.OracleModel(np.array(g["track"]), opts["L"])
+    for T in opts["T"]:
+        t0 = int(rng.integers(0, 1000 - 20))
+        idx = (t0 + np.arange(T)) % 999
+        x = xP[idx] + rng.normal(size=(T, 6)) * np.array([.05, .02, .05, .01, 0.0, .02]); u = uP[idx] + rng.normal(size=(T, 2)) * 0.02
+        if "ties" in opts:                       # duplicate one (state, input) row: equal distances to every query
+            k = opts["ties"]; src = T // 3
+            rows = rng.choice(np.arange(1, T - 2), size=k, replace=False)
+            x[rows, 0:3] = x[src, 0:3]; u[rows] = u[src]
+        ctx.model_add_trajectory(x, u); model.addTrajectory(x, u)
+    tb = rng.integers(0, 980, size=B)
+    xLin = np.stack([xP[t:t + N + 1] for t in tb]) + rng.normal(size=(B, N + 1, 6)) * np.array([.03, .01, .03, .01, 0.0, .01])
+    uLin = np.stack([uP[t:t + N] for t in tb])
+    if "ties" in opts:                           # queries next to the duplicated row, so that the ties are among the nearest
+        xs, us = model.xStored[0], model.uStored[0]
+        xLin[:, :, 0:3] = xs[len(xs) // 3, 0:3] + rng.normal(size=(B, N + 1, 3)) * 1e-3; uLin[:] = us[len(us) // 3]
+    A, Bm, C, st = ctx.regress_batch(xLin, uLin)
+    worst = 0.0; n_ok = 0
+    for b in range(B):
+        for i in range(N):
+            xu = np.hstack((xLin[b, i, 0:3], uLin[b, i]))
+            npts = sum(len(orc.compute_indices(model.xStored[it], model.uStored[it], xu)[0]) for it in model.usedIt)
+            if npts < 5:
+                assert st[b, i] & _capi.ST_REG_SINGULAR
+                continue
+            Ai, Bi, Ci = orc.regression_and_linearization(model.xStored, model.uStored, model.usedIt, model.pt, xLin[b, i], uLin[b, i])
+            if not (np.all(np.isfinite(Ai)) and np.all(np.isfinite(Bi))):
+                continue
+            assert st[b, i] == 0, (case, b, i, st[b, i])
+            for got, ref in ((A[b, i], Ai), (Bm[b, i], Bi), (C[b, i], Ci)):
+                worst = max(worst, (np.abs(got - ref) / (1.0 + np.abs(ref))).max())
+            n_ok += 1
+    print(case, "checked", n_ok, "worst rel err", worst)
+    assert n_ok > B * N // 4 and worst < common.TOL_ABC
+    ctx.close()
