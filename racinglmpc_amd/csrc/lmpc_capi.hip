@@ -347,7 +347,7 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
     const bool term = c->cfg.numSS_it > 0;
     int rc = refresh_params(c, false, term && (io.mode & 1)); if (rc) return rc;
     ev_begin(c, 1);
-    rc = (B <= c->mw_max_batch && !io.tbuf) ? c->solve_launch_mw(c, B, io) : c->solve_launch(c, B, io);
+    rc = (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->solve_launch_mw(c, B, io) : c->solve_launch(c, B, io);
     ev_end(c);
     if (rc) return rc;
     HIPCHK(hipGetLastError());

@@ -13,6 +13,11 @@
 #include "lmpc_kernels.hip.h"
 
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#ifdef LMPC_TIMING
+#define TSMW(id) do { if (io.tbuf && b == 0 && tid == 0 && tcnt < 4000) { io.tbuf[2 * tcnt] = (id); io.tbuf[2 * tcnt + 1] = (long long)__builtin_readcyclecounter(); tcnt++; } } while (0)
+#else
+#define TSMW(id) do { } while (0)
+#endif
 
 template <int N, int S, int NW>
 __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params p, int B, lmpc_solve_io io) {
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
 #define FOR_OFF(i, n, off) for (int i = (tid >= (off) ? tid - (off) : tid - (off) + NT); i < (n); i += NT)
 
     // one Newton-system solve for the right-hand side currently in (rx,ru,rs,rl,h); result in dx,du,ds,dl
+    int tcnt = 0;
     auto kkt_solve = [&](double re_sum) {
         FOR_OFF(i, 2 * N, O1) {                                 // slack elimination, per lane row (k,j)
             const double hl = h[i], hs = h[6 * N + i];
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
             gam[i] = v;
         }
         __syncthreads();
+        TSMW(30);
         if (w0) {   // backward sweep p_k = Phi_k' p_{k+1} + gamma_k in registers (see lmpc_solve_kernel)
             double gm[N];
 #pragma unroll
@@ -274,6 +281,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
             }
         }
         __syncthreads();
+        TSMW(31);
         for (int i = tid; i < 8 * N; i += NT) {                 // phi_k = [-B k0 ; -k0], k0_k = Mi_k (gu' + B' p_x + p_u) recomputed per entry
             const int k = i >> 3, c = i & 7;
             double w0_ = gup[2 * k] + pst[(k + 1) * 8 + 6], w1_ = gup[2 * k + 1] + pst[(k + 1) * 8 + 7];
@@ -284,6 +292,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
         }
         if (tid < 6) dx[tid] = 0.0;
         __syncthreads();
+        TSMW(32);
         if (w0) {   // forward sweep xi_{k+1} = Phi_k xi_k + phi_k in registers
             double fm[N];
 #pragma unroll
@@ -300,6 +309,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
             }
         }
         __syncthreads();
+        TSMW(33);
         FOR_OFF(i, 2 * N, O1) {
             const int k = i >> 1, j = i & 1; double f = 0.0;
 #pragma unroll
@@ -334,6 +344,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
     const double qscale = fmax(1.0, qmax);
 #pragma unroll 1
     for (it = 0; it <= p.max_iter; it++) {
+        TSMW(10);
         // ---- slacks of the inequality rows, terminal slack --------------------------------------------
         double gsum = 0.0, rmax = 0.0, remax = 0.0;
 #pragma unroll
@@ -401,6 +412,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
         if (it == p.max_iter) break;
         if (!(gap == gap) || !(rdn == rdn)) { if (tid == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
 
+        TSMW(11);
         // ---- barrier weights ----------------------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < RPL; j++) { const int r = tid + NT * j; if (r < M) th[r] = m[r] * rt_r[j]; }
@@ -496,6 +508,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
             }
             WSYNC();
             __builtin_amdgcn_s_barrier();                        // B_KAP: pairs with the helpers' barrier below; kap / rDs written by another wave are complete
+            TSMW(12);
             numeric_bad |= ricc_factor<N, term>(rc, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
             WSYNC();
             if (numeric_bad && lane == 0) bad_sh = 1;
@@ -508,8 +521,10 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
         __syncthreads();
         if (bad_sh) { if (tid == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
 
+        TSMW(13);
         // ---- predictor (affine scaling) direction ----------------------------------------------------------
         kkt_solve(re_sum);
+        TSMW(14);
         double apmax = 1.0, admax = 1.0, dma_r[RPL];
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
@@ -537,11 +552,13 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
         gaff = red_sum(6) / (double)M;
         double sig = gaff / gap; sig = sig * sig * sig;
         const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);
+        TSMW(15);
         // ---- corrector ---------------------------------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < RPL; j++) { const int r = tid + NT * j; if (r < M) h[r] = m[r] + (tp_r[j] - tgt) * rt_r[j]; }
         __syncthreads();
         kkt_solve(re_sum);
+        TSMW(16);
         double apx = INFINITY, adx = INFINITY;
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
@@ -559,6 +576,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
         __syncthreads();
         double al = fmin(1.0, 0.995 * red_min(7)), ald = fmin(1.0, 0.995 * red_min(8));
         if (!sep) { al = fmin(al, ald); ald = al; }
+        TSMW(17);
         // ---- multipliers of the equality rows (costates) -------------------------------------------------
         for (int i = tid; i < 6 * N; i += NT) {
             const int k = i / 6 + 1, c = i % 6;
@@ -590,6 +608,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
         }
         __syncthreads();
         if constexpr (term) deta = red[9 * 4];
+        TSMW(18);
         // ---- step ------------------------------------------------------------------------------------------
         for (int i = tid; i < 6 * (N + 1); i += NT) x[i] = fma(al, dx[i], x[i]);
         FOR_OFF(i, 2 * N, O1) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
@@ -602,6 +621,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
     if (!converged && tid == 0 && !(st_sh & LMPC_ST_NUMERIC)) atomicOr(&st_sh, LMPC_ST_MAXITER);
     __syncthreads();
 
+    TSMW(20); TSMW(21);
     // ---- unpackSolution (:364-379) and feasibleStateInput (:382-384) -------------------------------------
     for (int i = tid; i < 6 * (N + 1); i += NT) io.xPred[(size_t)b * 6 * (N + 1) + i] = x[i];
     for (int i = tid; i < 2 * N; i += NT) { io.uPred[(size_t)b * 2 * N + i] = u[i]; if (io.slack) io.slack[(size_t)b * 2 * N + i] = s[i]; }
