@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the measurement set of one round on the GPU box (run through gpurun from the repo root):
 #   tools/collect_profiles.sh r1g
-# writes gpurun_out/<tag>_bench.json, _bench_sweep.json, _kernel_stats.csv, _pmc_pass{1..4}.csv; copy them to profiles/ and run
+# writes gpurun_out/<tag>_bench.json, _bench_sweep.json, _kernel_stats.csv, _pmc_pass{1..6}.csv; copy them to profiles/ and run
 # tools/make_traffic.py profiles/<tag> to refresh profiles/traffic.json (read by bench.py's roofline object).
 set -u
 TAG=${1:-r1x}
@@ -15,7 +15,7 @@ CMD="python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- $CMD > /dev/null 2>&1
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 i=1
-for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES"; do
+for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64"; do
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d /tmp/prof_pmc$i -- $CMD > /dev/null 2>&1
   f=$(find /tmp/prof_pmc$i -name "*counter_collection.csv" | head -1)
   # keep the two hot kernels only (the files are large otherwise)
