@@ -143,6 +143,10 @@ typedef struct {          /* all device pointers, layouts as in lmpc_step_batch 
 int lmpc_step_batch_dev(lmpc_ctx *, int B, const lmpc_step_dev_args *args);   /* async on the ctx stream */
 
 /* ---- caller side of the path, next row of SURVEY 8(f): plant integrator + device-resident closed-loop laps ---- */
+/* Map.getGlobalPosition (Track.py:135-189), batched: curvilinear (s, ey) -> inertial (X, Y) for n points on the track given
+ * in lmpc_config.track (plotting / logging export, plot.py:50-175).  status[e] = LMPC_ST_NO_SEGMENT where the reference raises. */
+int lmpc_global_position_batch(lmpc_ctx *, int n, const double *s /*n*/, const double *ey /*n*/, double *xy /*n x 2*/, int *status /*n*/);
+
 int lmpc_plant_step_batch(lmpc_ctx *, int B, const double *x /*B x 6*/, const double *x_glob /*B x 6*/, const double *u /*B x 2*/,
                           const double *noise /*B x 3 N(0,1) draws*/, double *x_next, double *x_glob_next, int *status);
         /* Simulator.dynModel, fnc/simulator/SysModel.py:56-147 (100 Euler sub-steps, clipped noise) */

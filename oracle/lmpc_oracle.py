@@ -108,6 +108,44 @@ def curvature(pt, s):
     return pt[int(hit[0]), 5]
 
 
+def _wrap_angle(a):
+    """Track.py:367-375."""
+    if a < -np.pi:
+        return 2 * np.pi + a
+    if a > np.pi:
+        return a - 2 * np.pi
+    return a
+
+
+def get_global_position(pt, s, ey):
+    """Map.getGlobalPosition, Track.py:135-189: curvilinear (s, ey) -> inertial (X, Y).  Raises where the reference raises
+    (s on no segment, e.g. s == k * TrackLength after the wrap loop)."""
+    TrackLength = pt[-1, 3] + pt[-1, 4]
+    while s > TrackLength:
+        s = s - TrackLength
+    index = np.all([[s >= pt[:, 3]], [s < pt[:, 3] + pt[:, 4]]], axis=0)
+    hit = np.where(np.squeeze(index))[0]
+    if hit.size != 1:
+        raise ValueError("getGlobalPosition: s=%r is on no track segment" % (s,))
+    i = int(hit[0])
+    if pt[i, 5] == 0.0:                                  # straight segment: linear interpolation + normal offset (:150-163)
+        xf, yf, xs, ys, psi = pt[i, 0], pt[i, 1], pt[i - 1, 0], pt[i - 1, 1], pt[i, 2]
+        deltaL = pt[i, 4]; reltaL = s - pt[i, 3]
+        x = (1 - reltaL / deltaL) * xs + reltaL / deltaL * xf + ey * np.cos(psi + np.pi / 2)
+        y = (1 - reltaL / deltaL) * ys + reltaL / deltaL * yf + ey * np.sin(psi + np.pi / 2)
+    else:                                                # arc (:164-187)
+        r = 1 / pt[i, 5]; ang = pt[i - 1, 2]
+        direction = 1 if r >= 0 else -1
+        CenterX = pt[i - 1, 0] + np.abs(r) * np.cos(ang + direction * np.pi / 2)
+        CenterY = pt[i - 1, 1] + np.abs(r) * np.sin(ang + direction * np.pi / 2)
+        spanAng = (s - pt[i, 3]) / (np.pi * np.abs(r)) * np.pi
+        angleNormal = _wrap_angle(direction * np.pi / 2 + ang)
+        angle = -(np.pi - np.abs(angleNormal)) * (1 if angleNormal >= 0 else -1)
+        x = CenterX + (np.abs(r) - direction * ey) * np.cos(angle + direction * spanAng)
+        y = CenterY + (np.abs(r) - direction * ey) * np.sin(angle + direction * spanAng)
+    return x, y
+
+
 # --------------------------------------------------------------------------------------
 # LTV model regression  (fnc/controller/PredictiveModel.py)
 # --------------------------------------------------------------------------------------

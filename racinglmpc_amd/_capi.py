@@ -47,7 +47,7 @@ EXPORTS = [
     "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun",
     "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
-    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_solver_waves", "lmpc_plant_step_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap",
+    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_solver_waves", "lmpc_plant_step_batch", "lmpc_global_position_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap",
 ]
 
 _lib = None
@@ -294,6 +294,13 @@ class Context:
 
     def solver_waves(self, B):
         return int(self.lib.lmpc_solver_waves(self._h, C.c_int(int(B))))
+
+    def global_position_batch(self, s, ey):
+        """Map.getGlobalPosition for arrays of (s, ey): returns xy (n, 2) and status (n,)."""
+        s = _f64(np.ravel(s)); ey = _f64(np.ravel(ey)); n = s.shape[0]
+        xy = np.zeros((n, 2)); st = np.zeros(n, np.int32)
+        _chk(self.lib.lmpc_global_position_batch(self._h, C.c_int(n), _d(s), _d(ey), _d(xy), _d(st)))
+        return xy, st
 
     def selftest(self):
         _chk(self.lib.lmpc_selftest(self._h))

@@ -533,6 +533,19 @@ int lmpc_plant_step_batch(lmpc_ctx *c, int B, const double *x, const double *xg,
     return LMPC_OK;
 }
 
+int lmpc_global_position_batch(lmpc_ctx *c, int n, const double *s, const double *ey, double *xy, int *status) {
+    ARGCHK(c && s && ey && xy && status && n >= 1);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    int rc = refresh_params(c, false, false); if (rc) return rc;
+    double *d; HIPCHK(hipMalloc(&d, sizeof(double) * (size_t)n * 4)); int *ds; HIPCHK(hipMalloc(&ds, sizeof(int) * (size_t)n));
+    H2D(d, s, (size_t)n); H2D(d + n, ey, (size_t)n);
+    hipLaunchKernelGGL(lmpc_global_position_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dp, n, d, d + n, d + 2 * (size_t)n, ds);
+    HIPCHK(hipGetLastError());
+    D2H(xy, d + 2 * (size_t)n, (size_t)n * 2); D2H(status, ds, (size_t)n);
+    HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(d); (void)hipFree(ds);
+    return LMPC_OK;
+}
+
 struct lmpc_rollout_session {
     int B, T_max, t;
     std::vector<void *> keep;

@@ -162,6 +162,38 @@ __device__ __forceinline__ double frsqrt(double x) {
     return y;
 }
 
+// Map.getGlobalPosition, Track.py:135-189: curvilinear (s, ey) -> inertial (X, Y), one thread per point (batched plotting /
+// logging export of predicted trajectories and safe-set points).  Row i - 1 of the table wraps to the last
+// row for i = 0, as the reference's negative index does.
+__global__ void lmpc_global_position_kernel(lmpc_dev_params p, int n, const double *__restrict__ s_in, const double *__restrict__ ey_in,
+                                            double *__restrict__ xy, int *__restrict__ status) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const double PI = 3.141592653589793;
+    double s = s_in[e]; const double ey = ey_in[e];
+    while (s > p.TL) s = s - p.TL;
+    int i = -1;
+    for (int r = 0; r < p.track_rows; r++) { const double c0 = p.track[r * 6 + 3]; if (s >= c0 && s < c0 + p.track[r * 6 + 4]) { i = r; break; } }
+    if (i < 0) { status[e] = LMPC_ST_NO_SEGMENT; xy[2 * e] = 0.0; xy[2 * e + 1] = 0.0; return; }
+    const double *ti = p.track + i * 6, *tp = p.track + (i > 0 ? i - 1 : p.track_rows - 1) * 6;
+    double x, y;
+    if (ti[5] == 0.0) {
+        const double deltaL = ti[4], reltaL = s - ti[3], psi = ti[2];
+        x = (1 - reltaL / deltaL) * tp[0] + reltaL / deltaL * ti[0] + ey * cos(psi + PI / 2);
+        y = (1 - reltaL / deltaL) * tp[1] + reltaL / deltaL * ti[1] + ey * sin(psi + PI / 2);
+    } else {
+        const double r = 1 / ti[5], ang = tp[2], dir = r >= 0 ? 1.0 : -1.0, ar = fabs(r);
+        const double cx = tp[0] + ar * cos(ang + dir * PI / 2), cy = tp[1] + ar * sin(ang + dir * PI / 2);
+        const double span = (s - ti[3]) / (PI * ar) * PI;
+        double an = dir * PI / 2 + ang;
+        if (an < -PI) an = 2 * PI + an; else if (an > PI) an = an - 2 * PI;                 // wrap(), Track.py:367-375
+        const double angle = -(PI - fabs(an)) * (an >= 0 ? 1.0 : -1.0);
+        x = cx + (ar - dir * ey) * cos(angle + dir * span);
+        y = cy + (ar - dir * ey) * sin(angle + dir * span);
+    }
+    xy[2 * e] = x; xy[2 * e + 1] = y; status[e] = 0;
+}
+
 // =====================================================================================================
 // K1 (block form): regression + linearisation of ALL horizon steps of one problem by one work-group.
 //

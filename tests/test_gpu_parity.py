@@ -352,3 +352,18 @@ def test_lmpc_generations_improve_lap_time(g):
     assert max(times[0]) < 300 and times[1][0] <= times[0][0] and times[2][0] <= times[1][0] + 2
     assert times[2][0] < times[0][0]
     ctx.close()
+
+
+def test_global_position_batch(g):
+    """lmpc_global_position_batch vs the reference's Map.getGlobalPosition (fixture from the executed reference) and the oracle."""
+    import os
+    from oracle import lmpc_oracle as orc
+    t = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "track_xy.npz"))
+    ctx, par = common.make_lmpc_ctx(g, 4, max_batch=4)
+    xy, st = ctx.global_position_batch(t["s"], t["ey"])
+    assert np.all(st == 0)
+    assert np.abs(xy - t["xy"]).max() < 1e-12
+    xy2, st2 = ctx.global_position_batch(np.array([2 * float(t["trackLength"]), 1.0]), np.array([0.0, 0.1]))
+    assert st2[0] == 4 and st2[1] == 0                                     # LMPC_ST_NO_SEGMENT where the reference raises
+    assert np.allclose(xy2[1], orc.get_global_position(t["track"], 1.0, 0.1), atol=1e-13)
+    ctx.close()

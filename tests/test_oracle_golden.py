@@ -1,6 +1,7 @@
 """CPU: the oracle restatement reproduces what the reference's own classes produced (golden fixtures made by
 tests/golden/make_golden.py), and the restated OSQP returns certified optima."""
 import numpy as np
+import pytest
 
 from oracle import lmpc_oracle as orc
 from tests import common
@@ -91,3 +92,14 @@ def test_ipm_model_matches_certified_optimum():
         assert o["iters"] < 25
         w = np.concatenate([o["x"].ravel(), o["u"].ravel()])
         assert np.abs(w - g["rec_sol_opt"][r][:102]).max() < 1e-6
+
+
+def test_global_position_oracle_matches_reference_fixture():
+    """oracle.get_global_position vs Map.getGlobalPosition outputs recorded from the executed reference (tests/golden/track_xy.npz)."""
+    import os
+    t = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "track_xy.npz"))
+    pt = t["track"]
+    got = np.array([orc.get_global_position(pt, float(s), float(e)) for s, e in zip(t["s"], t["ey"])])
+    assert np.abs(got - t["xy"]).max() < 1e-12
+    with pytest.raises(ValueError):
+        orc.get_global_position(pt, float(2 * t["trackLength"]), 0.0)      # wraps to TrackLength exactly: on no segment
