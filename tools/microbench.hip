@@ -5,14 +5,13 @@
 template <int OP> __global__ void mb(double *out, long long *cyc, int iters) {
     const int lane = threadIdx.x, lg = lane >> 3, lc = lane & 7;
     double v = 1.0 + lane * 1e-3, acc = 0.0;
-    double g[8];
     long long t0 = __builtin_readcyclecounter();
     for (int i = 0; i < iters; i++) {
         if (OP == 0) { v = v * 1.0000001 + 1e-9; }
-        if (OP == 1) { gather_c(v, g); v = g[7] + g[3] * 1e-9; }
-        if (OP == 2) { gather_g(v, g, lg); v = g[7] + g[3] * 1e-9; }
-        if (OP == 3) { v = lane_bcast(v, (lane * 7 + 3) & 63) + 1e-9; }
-        if (OP == 4) { v = lane_read(v, 54) + lane * 1e-9; }
+        if (OP == 1) { v = dpp_blk<0x118, 0x8>(dpp_blk<0x114, 0x6>(v, v), v) + 1e-9; }
+        if (OP == 2) { v = frcp(v + 1.5); }
+        if (OP == 3) { v = lane_gather(v, 4 * ((lane * 7 + 3) & 63)) + 1e-9; }
+        if (OP == 4) { v = rdlane(v, 54) + lane * 1e-9; }
         if (OP == 5) { v = 1.0 / (v + 1.5); }
         if (OP == 6) { v = sum_over_c(v) * 0.125; }
         if (OP == 7) { v = sum_over_g(v) * 0.125; }
@@ -30,7 +29,7 @@ template <int OP> __global__ void mb(double *out, long long *cyc, int iters) {
 }
 int main() {
     double *d; long long *c; hipMalloc(&d, 64 * 8); hipMalloc(&c, 8);
-    const char *names[] = {"fma_f64", "gather_c", "gather_g", "lane_bcast(bpermute)", "lane_read(readlane)", "div_f64", "sum_over_c", "sum_over_g", "wsum", "sqrt_f64",
+    const char *names[] = {"fma_f64", "2x dpp_blk (A form copy)", "frcp (rcp + 2 Newton)", "lane_gather(bpermute)", "rdlane(readlane)", "div_f64", "sum_over_c", "sum_over_g", "wsum", "sqrt_f64",
                            "swap16+add", "swap32+add", "dpp_mov+add", "LDS write+sync+read+sync"};
     const int iters = 2000;
 #define RUN(OP) { hipLaunchKernelGGL(mb<OP>, dim3(1), dim3(64), 0, 0, d, c, iters); hipDeviceSynchronize(); hipLaunchKernelGGL(mb<OP>, dim3(1), dim3(64), 0, 0, d, c, iters); long long h; hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost); printf("%-28s %8.1f cycles/op\n", names[OP], (double)h / iters); }
