@@ -526,7 +526,7 @@ int lmpc_plant_step_batch(lmpc_ctx *c, int B, const double *x, const double *xg,
     double *d; HIPCHK(hipMalloc(&d, sizeof(double) * (size_t)B * 29)); int *ds; HIPCHK(hipMalloc(&ds, sizeof(int) * B));
     double *dx = d, *dg = d + (size_t)B * 6, *du = d + (size_t)B * 12, *dn = d + (size_t)B * 14, *dxn = d + (size_t)B * 17, *dgn = d + (size_t)B * 23;
     H2D(dx, x, (size_t)B * 6); H2D(dg, xg, (size_t)B * 6); H2D(du, u, (size_t)B * 2); H2D(dn, noise, (size_t)B * 3);
-    hipLaunchKernelGGL(lmpc_plant_kernel, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, dx, dg, du, dn, dxn, dgn, ds);
+    hipLaunchKernelGGL(lmpc_plant_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, dx, dg, du, dn, dxn, dgn, ds);
     HIPCHK(hipGetLastError());
     D2H(xn, dxn, (size_t)B * 6); D2H(xgn, dgn, (size_t)B * 6); D2H(status, ds, B);
     HIPCHK(hipStreamSynchronize(c->stream)); hipFree(d); hipFree(ds);
@@ -617,7 +617,7 @@ int lmpc_rollout_run(lmpc_ctx *c, int max_steps, int *steps_total, int *n_done) 
         io.timeStep = r->d_tstep; io.xPred = r->d_xPred; io.uPred = r->d_uPred; io.slack = r->d_slack; io.lambda = r->d_lam; io.sTerm = r->d_sT; io.ztNext = r->d_ztN;
         io.ztuNext = r->d_ztuN; io.resid = r->d_resid; io.status = r->d_status; io.iters = r->d_iters;
         rc = launch_solve(c, B, io); if (rc) return rc;
-        hipLaunchKernelGGL(lmpc_rollout_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, r->t, st);
+        hipLaunchKernelGGL(lmpc_rollout_advance_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, r->t, st);
         HIPCHK(hipGetLastError());
         r->t++;
         if ((r->t & 7) == 0 || r->t == t_end) {

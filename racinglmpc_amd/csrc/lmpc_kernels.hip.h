@@ -1333,24 +1333,33 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
 // One thread per rollout (the plant is 100 dependent Euler sub-steps of ~60 flops: no intra-rollout parallelism).
 // =====================================================================================================
 // Simulator.dynModel, SysModel.py:56-147.  x, xg: (B,6) curvilinear / global state; u: (B,2); nz: (B,3) N(0,1) draws.
-__device__ __forceinline__ void plant_step_one(const lmpc_dev_params &p, const double *x, const double *xg, const double *u, const double *nz,
-                                               double *xn, double *xgn, int *bad) {
+// TWO adjacent lanes integrate one car: the sub-step's transcendental chains come in pairs that run the same instructions
+// on different data -- front / rear slip angle and tyre force (atan2, atan, sin), heading psi / heading error epsi
+// (sin, cos) -- so lane `role` 0 takes the front tyre and psi, lane 1 the rear tyre and epsi, they swap the three results
+// with one DPP quad_perm each, and both carry the full state redundantly.  Every transcendental is still evaluated exactly
+// once per sub-step with the same argument as in the scalar form, so the result is unchanged; the 100-sub-step dependent
+// chain is ~40 % shorter (it is the latency of this chain, not throughput, that the rollout loop waits for).
+__device__ __forceinline__ void plant_step_pair(const lmpc_dev_params &p, const double *x, const double *xg, const double *u, const double *nz,
+                                                double *xn, double *xgn, int *bad, const int role) {
     const double m = 1.98, lf = 0.125, lr = 0.125, Iz = 0.024;
-    const double Df = 0.8 * m * 9.81 / 2.0, Cf = 1.25, Bf = 1.0, Dr = 0.8 * m * 9.81 / 2.0, Cr = 1.25, Br = 1.0;
+    const double Df = 0.8 * m * 9.81 / 2.0, Cf = 1.25, Bf = 1.0;                     // rear tyre: same D, C, B (SysModel.py:68-76)
     const double deltaT = 0.001;
     const double delta = u[0], a = u[1];
     double psi = xg[3], X = xg[4], Y = xg[5];
     double vx = x[0], vy = x[1], wz = x[2], epsi = x[3], s = x[4], ey = x[5];
     const double sd = sin(delta), cd = cos(delta);
     for (int i = 0; i < 100; i++) {                                  // while (i+1)*deltaT <= dt, SysModel.py:93
-        const double alpha_f = delta - atan2(vy + lf * wz, vx);
-        const double alpha_r = -atan2(vy - lf * wz, vx);
-        const double Fyf = Df * sin(Cf * atan(Bf * alpha_f));
-        const double Fyr = Dr * sin(Cr * atan(Br * alpha_r));
+        const double at = atan2(role ? vy - lf * wz : vy + lf * wz, vx);
+        const double alpha = role ? -at : delta - at;                // alpha_r = -atan2(vy - lf wz, vx), alpha_f = delta - atan2(vy + lf wz, vx)
+        const double F = Df * sin(Cf * atan(Bf * alpha));
+        const double ang = role ? epsi : psi;
+        const double sn = sin(ang), cs = cos(ang);
+        const double Fo = dpp_mov<DPP_QP_X1>(F), sno = dpp_mov<DPP_QP_X1>(sn), cso = dpp_mov<DPP_QP_X1>(cs);
+        const double Fyf = role ? Fo : F, Fyr = role ? F : Fo;
+        const double sp = role ? sno : sn, cp = role ? cso : cs, se = role ? sn : sno, ce = role ? cs : cso;
         const double nvx = vx + deltaT * (a - 1 / m * Fyf * sd + wz * vy);
         const double nvy = vy + deltaT * (1 / m * (Fyf * cd + Fyr) - wz * vx);
         const double nwz = wz + deltaT * (1 / Iz * (lf * Fyf * cd - lr * Fyr));
-        const double sp = sin(psi), cp = cos(psi), se = sin(epsi), ce = cos(epsi);
         const double npsi = psi + deltaT * (wz);
         const double nX = X + deltaT * ((vx * cp - vy * sp));
         const double nY = Y + deltaT * (vx * sp + vy * cp);
@@ -1367,13 +1376,15 @@ __device__ __forceinline__ void plant_step_one(const lmpc_dev_params &p, const d
 
 __global__ void lmpc_plant_kernel(lmpc_dev_params p, int B, const double *__restrict__ x, const double *__restrict__ xg, const double *__restrict__ u,
                                   const double *__restrict__ nz, double *__restrict__ xn, double *__restrict__ xgn, int *__restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, b = tid >> 1, role = tid & 1;
     if (b >= B) return;
     int bad = 0;
     double xo[6], go[6];
-    plant_step_one(p, x + (size_t)b * 6, xg + (size_t)b * 6, u + (size_t)b * 2, nz + (size_t)b * 3, xo, go, &bad);
-    for (int j = 0; j < 6; j++) { xn[(size_t)b * 6 + j] = xo[j]; xgn[(size_t)b * 6 + j] = go[j]; }
-    if (status) status[b] = bad ? LMPC_ST_NO_SEGMENT : 0;
+    plant_step_pair(p, x + (size_t)b * 6, xg + (size_t)b * 6, u + (size_t)b * 2, nz + (size_t)b * 3, xo, go, &bad, role);
+    if (role == 0) {
+        for (int j = 0; j < 6; j++) { xn[(size_t)b * 6 + j] = xo[j]; xgn[(size_t)b * 6 + j] = go[j]; }
+        if (status) status[b] = bad ? LMPC_ST_NO_SEGMENT : 0;
+    }
 }
 
 // One closed-loop step of every rollout after lmpc_step_batch_dev: log (x_t, u_t, xglob_t), integrate the plant with
@@ -1385,29 +1396,34 @@ struct lmpc_rollout_state {
     double *finX, *finG;                                                                       // state right after the crossing step
 };
 __global__ void lmpc_rollout_advance_kernel(lmpc_dev_params p, int B, int t, lmpc_rollout_state r) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, b = tid >> 1, role = tid & 1;    // two lanes per rollout, see plant_step_pair
     if (b >= B) return;
     const int N = p.N;
     double *x = r.x + (size_t)b * 6, *xg = r.xg + (size_t)b * 6;
     const double *uP = r.uPred + (size_t)b * N * 2, *xP = r.xPred + (size_t)b * (N + 1) * 6;
     const double u0[2] = {uP[0], uP[1]};
-    for (int j = 0; j < 6; j++) { r.logX[((size_t)t * B + b) * 6 + j] = x[j]; r.logG[((size_t)t * B + b) * 6 + j] = xg[j]; }
-    r.logU[((size_t)t * B + b) * 2] = u0[0]; r.logU[((size_t)t * B + b) * 2 + 1] = u0[1];
+    if (role == 0) {
+        for (int j = 0; j < 6; j++) { r.logX[((size_t)t * B + b) * 6 + j] = x[j]; r.logG[((size_t)t * B + b) * 6 + j] = xg[j]; }
+        r.logU[((size_t)t * B + b) * 2] = u0[0]; r.logU[((size_t)t * B + b) * 2 + 1] = u0[1];
+    }
     int bad = 0; double xo[6], go[6];
-    plant_step_one(p, x, xg, u0, r.noise + ((size_t)t * B + b) * 3, xo, go, &bad);
-    for (int j = 0; j < 6; j++) { x[j] = xo[j]; xg[j] = go[j]; }
+    plant_step_pair(p, x, xg, u0, r.noise + ((size_t)t * B + b) * 3, xo, go, &bad, role);
+    // bookkeeping shared by the two lanes (strided copies)
     double *xl = r.xLin + (size_t)b * (N + 1) * 6, *ul = r.uLin + (size_t)b * N * 2, *xpp = r.xPP + (size_t)b * (N + 1) * 6;
-    for (int i = 0; i < (N + 1) * 6; i++) xpp[i] = xP[i];
-    for (int i = 0; i < N * 6; i++) xl[i] = xP[6 + i];
-    for (int j = 0; j < 6; j++) { xl[N * 6 + j] = r.ztNext[(size_t)b * 6 + j]; r.zt[(size_t)b * 6 + j] = r.ztNext[(size_t)b * 6 + j]; }
-    for (int i = 0; i < (N - 1) * 2; i++) ul[i] = uP[2 + i];
-    ul[(N - 1) * 2] = r.ztuNext[(size_t)b * 2]; ul[(N - 1) * 2 + 1] = r.ztuNext[(size_t)b * 2 + 1];
-    r.uOld[(size_t)b * 2] = u0[0]; r.uOld[(size_t)b * 2 + 1] = u0[1];
-    r.hasPred[b] = 1; r.timeStep[b] = t + 1;
-    r.statusAcc[b] |= r.status[b] | (bad ? LMPC_ST_NO_SEGMENT : 0);
-    if (r.doneAt[b] < 0 && xo[4] > p.TL) {                                                     // lap completed, SysModel.py:45
-        r.doneAt[b] = t + 1; atomicAdd(r.nDone, 1);
-        for (int j = 0; j < 6; j++) { r.finX[(size_t)b * 6 + j] = xo[j]; r.finG[(size_t)b * 6 + j] = go[j]; }
+    for (int i = role; i < (N + 1) * 6; i += 2) xpp[i] = xP[i];
+    for (int i = role; i < N * 6; i += 2) xl[i] = xP[6 + i];
+    for (int i = role; i < (N - 1) * 2; i += 2) ul[i] = uP[2 + i];
+    if (role == 0) {
+        for (int j = 0; j < 6; j++) { x[j] = xo[j]; xg[j] = go[j]; }
+        for (int j = 0; j < 6; j++) { xl[N * 6 + j] = r.ztNext[(size_t)b * 6 + j]; r.zt[(size_t)b * 6 + j] = r.ztNext[(size_t)b * 6 + j]; }
+        ul[(N - 1) * 2] = r.ztuNext[(size_t)b * 2]; ul[(N - 1) * 2 + 1] = r.ztuNext[(size_t)b * 2 + 1];
+        r.uOld[(size_t)b * 2] = u0[0]; r.uOld[(size_t)b * 2 + 1] = u0[1];
+        r.hasPred[b] = 1; r.timeStep[b] = t + 1;
+        r.statusAcc[b] |= r.status[b] | (bad ? LMPC_ST_NO_SEGMENT : 0);
+        if (r.doneAt[b] < 0 && xo[4] > p.TL) {                                                 // lap completed, SysModel.py:45
+            r.doneAt[b] = t + 1; atomicAdd(r.nDone, 1);
+            for (int j = 0; j < 6; j++) { r.finX[(size_t)b * 6 + j] = xo[j]; r.finG[(size_t)b * 6 + j] = go[j]; }
+        }
     }
 }
 
