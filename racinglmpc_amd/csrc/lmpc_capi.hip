@@ -548,6 +548,7 @@ int lmpc_global_position_batch(lmpc_ctx *c, int n, const double *s, const double
 
 struct lmpc_rollout_session {
     int B, T_max, t;
+    hipStream_t pstream; hipEvent_t e_solved, e_plant;          // plant integration runs beside the next regression (lmpc_rollout_plant_kernel)
     std::vector<void *> keep;
     double *d_x, *d_xg, *d_xLin, *d_uLin, *d_uOld, *d_zt, *d_xPP, *d_xPred, *d_uPred, *d_slack, *d_lam, *d_sT, *d_ztN, *d_ztuN, *d_A, *d_B, *d_C, *d_resid;
     double *d_logX, *d_logU, *d_logG, *d_noise, *d_finX, *d_finG;
@@ -556,7 +557,8 @@ struct lmpc_rollout_session {
 
 static void rollout_free(lmpc_ctx *c) {
     if (!c->ro) return;
-    for (void *q : c->ro->keep) hipFree(q);
+    for (void *q : c->ro->keep) (void)hipFree(q);
+    if (c->ro->pstream) { (void)hipStreamDestroy(c->ro->pstream); (void)hipEventDestroy(c->ro->e_solved); (void)hipEventDestroy(c->ro->e_plant); }
     delete c->ro; c->ro = nullptr;
 }
 
@@ -566,7 +568,8 @@ int lmpc_rollout_begin(lmpc_ctx *c, int B, int T_max, const double *x0, const do
     ARGCHK(c && x0 && xg0 && xLin0 && uLin0 && noise && B >= 1 && T_max >= 1 && c->cfg.numSS_it > 0);
     HIPCHK(hipSetDevice(c->cfg.device));
     rollout_free(c);
-    lmpc_rollout_session *r = new lmpc_rollout_session(); c->ro = r; r->B = B; r->T_max = T_max; r->t = 0;
+    lmpc_rollout_session *r = new lmpc_rollout_session(); c->ro = r; r->B = B; r->T_max = T_max; r->t = 0; r->pstream = nullptr;
+    HIPCHK(hipStreamCreate(&r->pstream)); HIPCHK(hipEventCreateWithFlags(&r->e_solved, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&r->e_plant, hipEventDisableTiming));
     const size_t N = c->cfg.N, S = c->cfg.numSS_points, Bz = B;
     bool ok = true;
     auto dalloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) { ok = false; return nullptr; } r->keep.push_back(q); return q; };
@@ -593,7 +596,7 @@ int lmpc_rollout_begin(lmpc_ctx *c, int B, int T_max, const double *x0, const do
 }
 
 int lmpc_rollout_run(lmpc_ctx *c, int max_steps, int *steps_total, int *n_done) {
-    // advance every rollout by up to max_steps simulated steps (three launches per step, no host round trip except a
+    // advance every rollout by up to max_steps simulated steps (four launches per step on two streams, no host round trip except a
     // finished-lap poll every 8 steps); stops early once every rollout has crossed the finish line
     ARGCHK(c && c->ro && max_steps >= 1);
     lmpc_rollout_session *r = c->ro;
@@ -616,11 +619,17 @@ int lmpc_rollout_run(lmpc_ctx *c, int max_steps, int *steps_total, int *n_done) 
         io.mode = 3; io.A = r->d_A; io.Bm = r->d_B; io.C = r->d_C; io.x0 = r->d_x; io.uOld = r->d_uOld; io.zt = r->d_zt; io.xPredPrev = r->d_xPP; io.hasPred = r->d_hasPred;
         io.timeStep = r->d_tstep; io.xPred = r->d_xPred; io.uPred = r->d_uPred; io.slack = r->d_slack; io.lambda = r->d_lam; io.sTerm = r->d_sT; io.ztNext = r->d_ztN;
         io.ztuNext = r->d_ztuN; io.resid = r->d_resid; io.status = r->d_status; io.iters = r->d_iters;
+        if (r->t > 0) HIPCHK(hipStreamWaitEvent(c->stream, r->e_plant, 0));          // the solve needs the plant's new state
         rc = launch_solve(c, B, io); if (rc) return rc;
-        hipLaunchKernelGGL(lmpc_rollout_advance_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, r->t, st);
+        HIPCHK(hipEventRecord(r->e_solved, c->stream));
+        HIPCHK(hipStreamWaitEvent(r->pstream, r->e_solved, 0));
+        hipLaunchKernelGGL(lmpc_rollout_plant_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, r->pstream, c->dp, B, r->t, st);
+        HIPCHK(hipEventRecord(r->e_plant, r->pstream));
+        hipLaunchKernelGGL(lmpc_rollout_shift_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, r->t, st);   // then the next step's regression
         HIPCHK(hipGetLastError());
         r->t++;
         if ((r->t & 7) == 0 || r->t == t_end) {
+            HIPCHK(hipStreamSynchronize(r->pstream));
             HIPCHK(hipMemcpyAsync(&nd, r->d_nDone, sizeof(int), hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
             if (nd >= B) break;
         }

@@ -1395,12 +1395,31 @@ struct lmpc_rollout_state {
     double *logX, *logU, *logG; const double *noise; int *nDone, *statusAcc;                   // logs [T][B][..], noise [T][B][3]
     double *finX, *finG;                                                                       // state right after the crossing step
 };
-__global__ void lmpc_rollout_advance_kernel(lmpc_dev_params p, int B, int t, lmpc_rollout_state r) {
+// The step's bookkeeping and its plant integration are two kernels on two streams: the shift of the linearisation trajectory
+// feeds the NEXT step's regression kernel, which does not need the plant's result and runs concurrently with it; only the next
+// solve waits for the new state.
+__global__ void lmpc_rollout_shift_kernel(lmpc_dev_params p, int B, int t, lmpc_rollout_state r) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, b = tid >> 1, role = tid & 1;    // two lanes per rollout (strided copies)
+    if (b >= B) return;
+    const int N = p.N;
+    const double *uP = r.uPred + (size_t)b * N * 2, *xP = r.xPred + (size_t)b * (N + 1) * 6;
+    double *xl = r.xLin + (size_t)b * (N + 1) * 6, *ul = r.uLin + (size_t)b * N * 2, *xpp = r.xPP + (size_t)b * (N + 1) * 6;
+    for (int i = role; i < (N + 1) * 6; i += 2) xpp[i] = xP[i];
+    for (int i = role; i < N * 6; i += 2) xl[i] = xP[6 + i];
+    for (int i = role; i < (N - 1) * 2; i += 2) ul[i] = uP[2 + i];
+    if (role == 0) {
+        for (int j = 0; j < 6; j++) { xl[N * 6 + j] = r.ztNext[(size_t)b * 6 + j]; r.zt[(size_t)b * 6 + j] = r.ztNext[(size_t)b * 6 + j]; }
+        ul[(N - 1) * 2] = r.ztuNext[(size_t)b * 2]; ul[(N - 1) * 2 + 1] = r.ztuNext[(size_t)b * 2 + 1];
+        r.uOld[(size_t)b * 2] = uP[0]; r.uOld[(size_t)b * 2 + 1] = uP[1];
+        r.hasPred[b] = 1; r.timeStep[b] = t + 1;
+    }
+}
+__global__ void lmpc_rollout_plant_kernel(lmpc_dev_params p, int B, int t, lmpc_rollout_state r) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, b = tid >> 1, role = tid & 1;    // two lanes per rollout, see plant_step_pair
     if (b >= B) return;
     const int N = p.N;
     double *x = r.x + (size_t)b * 6, *xg = r.xg + (size_t)b * 6;
-    const double *uP = r.uPred + (size_t)b * N * 2, *xP = r.xPred + (size_t)b * (N + 1) * 6;
+    const double *uP = r.uPred + (size_t)b * N * 2;
     const double u0[2] = {uP[0], uP[1]};
     if (role == 0) {
         for (int j = 0; j < 6; j++) { r.logX[((size_t)t * B + b) * 6 + j] = x[j]; r.logG[((size_t)t * B + b) * 6 + j] = xg[j]; }
@@ -1408,17 +1427,8 @@ __global__ void lmpc_rollout_advance_kernel(lmpc_dev_params p, int B, int t, lmp
     }
     int bad = 0; double xo[6], go[6];
     plant_step_pair(p, x, xg, u0, r.noise + ((size_t)t * B + b) * 3, xo, go, &bad, role);
-    // bookkeeping shared by the two lanes (strided copies)
-    double *xl = r.xLin + (size_t)b * (N + 1) * 6, *ul = r.uLin + (size_t)b * N * 2, *xpp = r.xPP + (size_t)b * (N + 1) * 6;
-    for (int i = role; i < (N + 1) * 6; i += 2) xpp[i] = xP[i];
-    for (int i = role; i < N * 6; i += 2) xl[i] = xP[6 + i];
-    for (int i = role; i < (N - 1) * 2; i += 2) ul[i] = uP[2 + i];
     if (role == 0) {
         for (int j = 0; j < 6; j++) { x[j] = xo[j]; xg[j] = go[j]; }
-        for (int j = 0; j < 6; j++) { xl[N * 6 + j] = r.ztNext[(size_t)b * 6 + j]; r.zt[(size_t)b * 6 + j] = r.ztNext[(size_t)b * 6 + j]; }
-        ul[(N - 1) * 2] = r.ztuNext[(size_t)b * 2]; ul[(N - 1) * 2 + 1] = r.ztuNext[(size_t)b * 2 + 1];
-        r.uOld[(size_t)b * 2] = u0[0]; r.uOld[(size_t)b * 2 + 1] = u0[1];
-        r.hasPred[b] = 1; r.timeStep[b] = t + 1;
         r.statusAcc[b] |= r.status[b] | (bad ? LMPC_ST_NO_SEGMENT : 0);
         if (r.doneAt[b] < 0 && xo[4] > p.TL) {                                                 // lap completed, SysModel.py:45
             r.doneAt[b] = t + 1; atomicAdd(r.nDone, 1);

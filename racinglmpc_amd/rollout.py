@@ -63,7 +63,7 @@ class BatchedRollouts:
         return np.tile(a[None], (B, 1, 1)) if a.ndim == 2 else a
 
     def run_lap_device(self, x0, xLin0, uLin0, xglob0=None, max_steps=400, ext=0, on_ext=None):
-        """The whole lap (controller steps, plant, bookkeeping) stays on the GPU (lmpc_rollout_*): three kernel launches
+        """The whole lap (controller steps, plant, bookkeeping) stays on the GPU (lmpc_rollout_*): four kernel launches
         per simulated step, no host round trip.  If ext > 0 the lap pauses after `ext` steps and on_ext(X, U) is called
         with the first ext states/inputs (ext, B, .) -- the hook that plays LMPC.addPoint for the stored laps.
         Returns (laps [(x, u, x_glob, final12)], where final12 = state + global state right after the finish line)."""
