@@ -188,11 +188,13 @@ def main():
         bytes_per_solve = 8 * (18 * N + 92)                     # SURVEY 8(d) B_solve: compulsory in+out per full step
         achieved = B * bytes_per_solve / (ms_solve * 1e-3) / 1e9
         kname = "lmpc_solve_kernel_mw<%d,%d,4>" % (N, S) if ctx.solver_waves(B) == 4 else "lmpc_solve_kernel<%d,%d>" % (N, S)
-        traffic = None
+        traffic = None; counters = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("lmpc_solve_kernel_bytes_per_launch_B%d_N%d" % (B, N))
+                tj = json.load(open(tfile))
+                traffic = tj.get("lmpc_solve_kernel_bytes_per_launch_B%d_N%d" % (B, N))
+                counters = tj.get("lmpc_solve_kernel_counters_B%d_N%d" % (B, N))
             except Exception:
                 traffic = None
         out = {
@@ -207,6 +209,13 @@ def main():
             "solver_only_solves_per_s": B / (ms_solve * 1e-3), "regression_only_solves_per_s": B / (ms_reg * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": kname, "algorithmic_bytes_per_launch": B * bytes_per_solve,
+                         # the other fraction SURVEY 8(d) asks for: FP64 work per launch from the rocprofv3 instruction-mix pass
+                         # (profiles/, static) over the launch time measured live; plus VALU utilisation and the LDS bank-conflict rate
+                         "fp64": None if not counters or "fp64_flop_per_launch" not in counters else {
+                             "achieved": counters["fp64_flop_per_launch"] / (ms_solve * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                             "frac": counters["fp64_flop_per_launch"] / (ms_solve * 1e-3) / 1e12 / 78.6,
+                             "valu_utilisation": counters.get("valu_utilisation"), "lds_bank_conflict_rate": counters.get("lds_bank_conflict_rate"),
+                             "mfma_busy_cycles_per_launch": counters.get("SQ_VALU_MFMA_BUSY_CYCLES")},
                          "note": "dependent-issue-latency bound path (one Newton recursion per QP); compulsory HBM traffic is 2.46 KB per solve (SURVEY 8(d)); "
                                  "measured traffic also counts the A,B,C hand-over from the regression kernel, the L2-resident lap-store scans and the mu/ssSel outputs; see DESIGN.md"},
         }

@@ -26,6 +26,33 @@ for kname in fetch:
         continue
     out[short + "_bytes_per_launch_B256_N12"] = 2 * fetch[kname] * 1024 + write.get(kname, 0.0) * 1024
     out[short + "_raw"] = {"kernel": kname[:60], "FETCH_SIZE_KB": fetch[kname], "WRITE_SIZE_KB": write.get(kname, 0.0)}
+# instruction mix and utilisation of the solve kernel (passes 3-6), per launch
+def all_counters(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    try:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    except FileNotFoundError:
+        pass
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+
+
+cnt = collections.defaultdict(dict)
+for i in (3, 4, 5, 6):
+    for kname, d in all_counters("%s_pmc_pass%d.csv" % (tag, i)).items():
+        short = "lmpc_solve_kernel" if "lmpc_solve_kernel" in kname else ("lmpc_regress_kernel" if "lmpc_regress_kernel" in kname else None)
+        if short:
+            cnt[short].update(d)
+for short, d in cnt.items():
+    if "SQ_INSTS_VALU_FMA_F64" in d:
+        # FP64 flop per launch: 64 lanes x (2 per FMA + 1 per add / mul) + 512 per 4x4x4 (4 blocks) or 2048 per 16x16x4 MFMA -- counted as 512 (lower bound)
+        d["fp64_flop_per_launch"] = 64.0 * (2 * d["SQ_INSTS_VALU_FMA_F64"] + d.get("SQ_INSTS_VALU_ADD_F64", 0) + d.get("SQ_INSTS_VALU_MUL_F64", 0)) + 512.0 * d.get("SQ_INSTS_VALU_MFMA_F64", 0)
+    if "SQ_WAVE_CYCLES" in d and "SQ_ACTIVE_INST_VALU" in d:
+        d["valu_utilisation"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
+    if "SQ_LDS_IDX_ACTIVE" in d and d["SQ_LDS_IDX_ACTIVE"] > 0:
+        d["lds_bank_conflict_rate"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
+    out[short + "_counters_B256_N12"] = d
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, %s_pmc_pass1/2.csv), mean over the bench launches at B=256, N=12; "
                "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950; "
                "WRITE_SIZE uncalibrated; Infinity-Cache hits are included)." % tag)
