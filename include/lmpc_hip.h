@@ -40,6 +40,9 @@ extern "C" {
 #define LMPC_ST_WINDOW 8           /* safe-set window runs past the end of a stored lap (reference: IndexError, :497) */
 #define LMPC_ST_NUMERIC 16         /* NaN / non-positive pivot inside the KKT factorisation */
 #define LMPC_ST_NOT_INTERIOR 32    /* u = 0 is not strictly inside Fu u <= bu (solver start point) */
+#define LMPC_ST_INEXACT 64         /* returned iterate is optimal to working accuracy only (gap < 1e-9, dual residual < 1e-5 rel., equality
+                                      residual < 1e-7) because the factorisation broke down or the iteration limit was hit at that point;
+                                      the solution is usable (the reference's own solver tolerance is 1e-3) */
 
 typedef struct lmpc_ctx lmpc_ctx;
 

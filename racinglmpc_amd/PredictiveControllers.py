@@ -125,7 +125,7 @@ class MPC():
             A = np.tile(np.asarray(self.A, float)[None, None], (1, N, 1, 1)); B = np.tile(np.asarray(self.B, float)[None, None], (1, N, 1, 1))
             out = self._ctx.qp_solve_batch(A, B, np.zeros((1, N, 6)), x0[None], np.reshape(np.asarray(self.OldInput, float), (1, 2)))
         self._raise_on_status(out["status"][0], x0)
-        self.feasible = 1 if out["status"][0] == 0 else 0
+        self.feasible = 1 if (out["status"][0] & ~_capi.ST_INEXACT) == 0 else 0
         self._out = out
         self.unpackSolution()
         self.solverTime = datetime.datetime.now() - t0
@@ -212,7 +212,7 @@ class LMPC(MPC):
                                    zt=zt_dev[None], xPredPrev=xpp[None], hasPred=np.array([has_pred]), timeStep=np.array([self.timeStep]))
         self.linearizationTime = datetime.datetime.now() - t0
         self._raise_on_status(out["status"][0], x0)
-        self.feasible = 1 if out["status"][0] == 0 else 0
+        self.feasible = 1 if (out["status"][0] & ~_capi.ST_INEXACT) == 0 else 0
         self._out = out
         self.A, self.B, self.C = list(out["A"][0]), list(out["B"][0]), list(out["C"][0])
         self.SS_PointSelectedTot = out["ssSel"][0].T.copy()

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "liblmpc_hip.so")
 MAX_TRACK_ROWS = 16
 MAX_USED_LAPS = 8
 
-ST_MAXITER, ST_REG_SINGULAR, ST_NO_SEGMENT, ST_WINDOW, ST_NUMERIC, ST_NOT_INTERIOR = 1, 2, 4, 8, 16, 32
+ST_MAXITER, ST_REG_SINGULAR, ST_NO_SEGMENT, ST_WINDOW, ST_NUMERIC, ST_NOT_INTERIOR, ST_INEXACT = 1, 2, 4, 8, 16, 32, 64
 
 
 class LmpcConfig(C.Structure):

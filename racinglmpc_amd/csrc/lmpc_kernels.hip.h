@@ -1180,7 +1180,9 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         }
         TSTAMP(12);
         numeric_bad |= ricc_factor<N, term>(rc, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
-        if (numeric_bad) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
+        // a breakdown of the factorisation once the iterate is optimal to working accuracy (gap at its floor, residuals small: the
+        // barrier weights span > 1e26 there) is reported as INEXACT, not as a failure: the iterate whose residuals were just measured is returned
+        if (numeric_bad) { if (lane == 0) atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_NUMERIC); break; }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < N; k++) ph[k] = (k & 1) ? Phi[k * 64 + lc * 8 + lg] : Phi[k * 64 + lg * 8 + lc];
@@ -1280,7 +1282,8 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         __syncthreads();
     }
     TSTAMP(20);
-    if (!converged && lane == 0 && !(st_sh & LMPC_ST_NUMERIC)) atomicOr(&st_sh, LMPC_ST_MAXITER);
+    if (!converged && lane == 0 && !(st_sh & (LMPC_ST_NUMERIC | LMPC_ST_INEXACT)))
+        atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_MAXITER);
     __syncthreads();
 
     // ---- unpackSolution (:364-379) and feasibleStateInput (:382-384) -------------------------------------

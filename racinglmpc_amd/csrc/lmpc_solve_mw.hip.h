@@ -519,7 +519,7 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
             __builtin_amdgcn_s_barrier();                        // B_KAP (helpers): their kap / rDs / h writes are complete
         }
         __syncthreads();
-        if (bad_sh) { if (tid == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
+        if (bad_sh) { if (tid == 0) atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_NUMERIC); break; }   // see lmpc_solve_kernel
 
         TSMW(13);
         // ---- predictor (affine scaling) direction ----------------------------------------------------------
@@ -618,7 +618,8 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
         eta_m = fma(ald, deta, eta_m);
         __syncthreads();
     }
-    if (!converged && tid == 0 && !(st_sh & LMPC_ST_NUMERIC)) atomicOr(&st_sh, LMPC_ST_MAXITER);
+    if (!converged && tid == 0 && !(st_sh & (LMPC_ST_NUMERIC | LMPC_ST_INEXACT)))
+        atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_MAXITER);
     __syncthreads();
 
     TSMW(20); TSMW(21);
