@@ -700,7 +700,7 @@ template <int S> __device__ __forceinline__ void ss_times(const double *SS, cons
     if (j < 6 && part == 0) out[j] = acc - sub[j];
 }
 
-template <int N, int S>
+template <int N, int S, bool EQ = false>
 __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
     extern __shared__ double sm[];
     using LL = solve_lds<N, S>;
@@ -709,6 +709,8 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     constexpr int RPL = (M + WAVE - 1) / WAVE;              // inequality rows per lane
     const int b = blockIdx.x;
     if (b >= B) return;
+    // retry variant (EQ): only problems that hit the iteration limit run again, with equal primal / dual steps throughout
+    if constexpr (EQ) { if (!(io.status[b] & LMPC_ST_MAXITER)) return; }
     const int lane = threadIdx.x;
     const int lg = lane >> 3, lc = lane & 7;                // lane = 8 g + c  (8 x 8 tile coordinates)
     double *AB = sm + LL::oAB, *C = sm + LL::oC, *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
@@ -1077,7 +1079,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         const double re_sum = term ? wsum(lsum) - 1.0 : 0.0;
         ren = fmax(wmax(remax), fabs(re_sum));
         if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res) { converged = 1; break; }
-        if (gap_prev >= 0.0) sep = gap > 0.3 * gap_prev;
+        if (gap_prev >= 0.0) sep = !EQ && gap > 0.3 * gap_prev;
         gap_prev = gap;
         if (it == p.max_iter) break;
         if (!(gap == gap) || !(rdn == rdn)) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
