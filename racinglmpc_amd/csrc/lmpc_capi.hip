@@ -137,9 +137,9 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     HIPCHK(hipMalloc(&c->sstore, store_elems * sizeof(double)));
     HIPCHK(hipMemset(c->mstore, 0, store_elems * sizeof(double)));
     c->mq_chunks = (cfg->max_lap_len + K1_CHUNK - 1) / K1_CHUNK;
-    HIPCHK(hipMalloc(&c->mquant, (size_t)cfg->max_laps * 5 * cfg->max_lap_len * sizeof(unsigned)));
+    HIPCHK(hipMalloc(&c->mquant, (size_t)cfg->max_laps * 3 * cfg->max_lap_len * sizeof(unsigned)));
     HIPCHK(hipMalloc(&c->mqpar, (size_t)cfg->max_laps * c->mq_chunks * 6 * sizeof(double)));
-    HIPCHK(hipMemset(c->mquant, 0, (size_t)cfg->max_laps * 5 * cfg->max_lap_len * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->mquant, 0, (size_t)cfg->max_laps * 3 * cfg->max_lap_len * sizeof(unsigned)));
     HIPCHK(hipMemset(c->mqpar, 0, (size_t)cfg->max_laps * c->mq_chunks * 6 * sizeof(double)));
     HIPCHK(hipMemset(c->sstore, 0, store_elems * sizeof(double)));
     const size_t B = cfg->max_batch, N = cfg->N, S = cfg->numSS_it > 0 ? cfg->numSS_points : 0, M = 8 * N + S;
@@ -190,12 +190,12 @@ static int upload_lap(lmpc_ctx *c, double *store, int slot, const double *x, con
 }
 
 // K1 prefilter image of one model-store lap (PredictiveModel.py:180-197 scans (vx, vy, wz, delta, a) . scaling of rows 0..T-2):
-// per 1024-row chunk, every scaled feature is mapped to 28-bit fixed point over the chunk's [min, max] with one common scale
-// 2^28 / (widest range).  The regress kernel ranks rows by integer L1 distances on this image and re-evaluates the survivors
+// per 1024-row chunk, every scaled feature is mapped to 16-bit fixed point over the chunk's [min, max] with one common scale
+// 65535 / (widest range), packed as (vx | vy << 16), (wz | delta << 16), (a).  The regress kernel ranks rows by integer L1 distances on this image and re-evaluates the survivors
 // in FP64, so the image never decides anything by itself; it only has to be within a few units of the exact scaled values.
 static int quantise_lap(lmpc_ctx *c, int slot, const double *x, const double *u, int T) {
     const int ls = c->cfg.max_lap_len, nrows = T - 1;
-    std::vector<unsigned> q((size_t)5 * ls, 0u);
+    std::vector<unsigned> q((size_t)3 * ls, 0u);
     std::vector<double> par((size_t)c->mq_chunks * 6, 0.0);
     auto feat = [&](int t, int k) { return (k < 3 ? x[(size_t)t * 6 + k] : u[(size_t)t * 2 + (k - 3)]) * c->cfg.scaling[k]; };
     for (int t0 = 0, ch = 0; t0 < nrows; t0 += K1_CHUNK, ch++) {
@@ -207,17 +207,18 @@ static int quantise_lap(lmpc_ctx *c, int slot, const double *x, const double *u,
             if (!(l <= h)) { l = 0.0; h = 0.0; }
             lo[k] = l; rmax = std::max(rmax, std::max(h - l, 1e-9 * std::max(std::fabs(l), std::fabs(h))));
         }
-        const double sc = 268435456.0 / std::max(rmax, 1e-300);
+        const double sc = 65535.0 / std::max(rmax, 1e-300);
         for (int k = 0; k < 5; k++) {
             par[(size_t)ch * 6 + k] = lo[k];
             for (int t = t0; t < t1; t++) {
                 const double v = (feat(t, k) - lo[k]) * sc;
-                q[(size_t)k * ls + t] = std::isfinite(v) ? (unsigned)std::min(std::max(v, 0.0), 268435456.0) : 0u;
+                const unsigned qq = std::isfinite(v) ? (unsigned)std::min(std::max(v, 0.0), 65535.0) : 0u;
+                q[(size_t)(k >> 1) * ls + t] |= (k & 1) ? qq << 16 : qq;
             }
         }
         par[(size_t)ch * 6 + 5] = sc;
     }
-    HIPCHK(hipMemcpy(c->mquant + (size_t)slot * 5 * ls, q.data(), q.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->mquant + (size_t)slot * 3 * ls, q.data(), q.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->mqpar + (size_t)slot * c->mq_chunks * 6, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice));
     return LMPC_OK;
 }
@@ -347,7 +348,8 @@ static int launch_regress(lmpc_ctx *c, int B, const double *d_xLin, int xstride,
     int rc = refresh_params(c, true, false); if (rc) return rc;
     ev_begin(c, 0);
     int qg, nblk; k1_grid(c, B, &qg, &nblk);
-    hipLaunchKernelGGL(lmpc_regress_kernel, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, d_xLin, xstride, d_uLin, dA, dB, dC, dst);
+    if (nblk > c->n_cu) hipLaunchKernelGGL(lmpc_regress_kernel<true>, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, d_xLin, xstride, d_uLin, dA, dB, dC, dst);
+    else hipLaunchKernelGGL(lmpc_regress_kernel<false>, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, d_xLin, xstride, d_uLin, dA, dB, dC, dst);
     ev_end(c);
     HIPCHK(hipGetLastError());
     c->stats.n_regress++;
@@ -628,8 +630,10 @@ int lmpc_rollout_run(lmpc_ctx *c, int max_steps, int *steps_total, int *n_done) 
         rc = refresh_params(c, true, true); if (rc) return rc;
         ev_begin(c, 0);
         { int qg, nblk; k1_grid(c, B, &qg, &nblk);
-          hipLaunchKernelGGL(lmpc_regress_kernel, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, (const double *)r->d_xLin, (int)(N + 1) * 6, (const double *)r->d_uLin,
-                             r->d_A, r->d_B, r->d_C, r->d_rst); }
+          if (nblk > c->n_cu) hipLaunchKernelGGL(lmpc_regress_kernel<true>, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, (const double *)r->d_xLin, (int)(N + 1) * 6, (const double *)r->d_uLin,
+                                                 r->d_A, r->d_B, r->d_C, r->d_rst);
+          else hipLaunchKernelGGL(lmpc_regress_kernel<false>, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, (const double *)r->d_xLin, (int)(N + 1) * 6, (const double *)r->d_uLin,
+                                  r->d_A, r->d_B, r->d_C, r->d_rst); }
         ev_end(c); c->stats.n_regress++;
         lmpc_solve_io io; memset(&io, 0, sizeof(io));
         io.mode = 3; io.A = r->d_A; io.Bm = r->d_B; io.C = r->d_C; io.x0 = r->d_x; io.uOld = r->d_uOld; io.zt = r->d_zt; io.xPredPrev = r->d_xPP; io.hasPred = r->d_hasPred;

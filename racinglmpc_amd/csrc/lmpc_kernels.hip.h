@@ -29,7 +29,7 @@ struct lmpc_dev_params {
     double tol_gap, tol_res, reg; int max_iter;
     int lap_stride;                 // rows per column (max_lap_len)
     const double *mstore; int mslot[LMPC_MAX_USED_LAPS]; int mlen[LMPC_MAX_USED_LAPS];
-    const unsigned *mquant; const double *mqpar; int mq_chunks;   // K1 prefilter image of the model store (28-bit fixed point) and its per-chunk (lo[5], scale)
+    const unsigned *mquant; const double *mqpar; int mq_chunks;   // K1 prefilter image of the model store (16-bit fixed point, three packed words per row) and its per-chunk (lo[5], scale)
     const double *sstore; int sslot[LMPC_MAX_USED_LAPS]; int sslen[LMPC_MAX_USED_LAPS]; int sslapid[LMPC_MAX_USED_LAPS];
     int cur_it;                     // LMPC.it (number of laps in the safe set)
 };
@@ -239,8 +239,8 @@ template <int ROT> __device__ __forceinline__ void k1_row_rank(double d, int i, 
         k1_row_rank<ROT + 1>(d, i, rank);
     }
 }
-__device__ __forceinline__ unsigned sad_u32(unsigned a, unsigned b, unsigned c) {   // |a - b| + c
-    unsigned r; asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+__device__ __forceinline__ unsigned sad_u16(unsigned a, unsigned b, unsigned c) {   // |a.lo16 - b.lo16| + |a.hi16 - b.hi16| + c
+    unsigned r; asm("v_sad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
 }
 __device__ __forceinline__ float wminf(float v) {                           // wave-wide float minimum, all lanes
 #pragma unroll
@@ -256,7 +256,10 @@ __host__ __device__ inline int k1_queries_per_block(int qg, int trToUse, int max
     return q < 1 ? 1 : q;
 }
 
-__global__ __launch_bounds__(K1_NT) void lmpc_regress_kernel(lmpc_dev_params p, int B, int qg, const double *__restrict__ xLin, int xstride,
+// OCC: compile for four waves per SIMD (two work-groups per CU; <= 128 VGPRs, a few spills) -- pays when the grid exceeds one work-group
+// per CU (1.47x at batch 4096); the other variant (<= 256 VGPRs, no spills) has the shorter latency when each CU runs a single group.
+template <bool OCC>
+__global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_dev_params p, int B, int qg, const double *__restrict__ xLin, int xstride,
                                                              const double *__restrict__ uLin, double *__restrict__ Aout,
                                                              double *__restrict__ Bout, double *__restrict__ Cout, int *__restrict__ status) {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
@@ -298,39 +301,42 @@ __global__ __launch_bounds__(K1_NT) void lmpc_regress_kernel(lmpc_dev_params p, 
             const int ls = p.lap_stride;
             const int nrows = p.mlen[c] - 1;
             for (int t0 = 0; t0 < nrows; t0 += K1_CHUNK) {
-                // Prefilter image of this lane's rows: the scaled features in 28-bit fixed point, quantised by the host when the lap was
-                // stored (lmpc_capi.hip: quantise_lap), per 1024-row chunk over the chunk's own [min, max] with ONE scale for the five
-                // features (the L1 norm weighs them equally).  One v_sad_u32 per feature gives the L1 distance; every decision is
-                // re-made in FP64 below.  A query outside [min, max] is clamped: that shifts all of a feature's |differences| by the
-                // same amount, so the order of the rows is untouched.
+                // Prefilter image of this lane's rows: the scaled features in 16-bit fixed point, packed (vx, vy | wz, delta | a, flag),
+                // quantised by the host when the lap was stored (lmpc_capi.hip: quantise_lap), per 1024-row chunk over the chunk's own
+                // [min, max] with ONE scale for the five features (the L1 norm weighs them equally).  Three v_sad_u16 per row give the
+                // integer L1 distance; every decision is re-made in FP64 below.  A query outside [min, max] is clamped: that shifts all
+                // of a feature's |differences| by the same amount, so the order of the rows is untouched.  Rows beyond the lap carry
+                // 0xffff in the unused half-word (the query has 0 there): farther than a full range from everything.
                 const double *qp = p.mqpar + ((size_t)p.mslot[c] * p.mq_chunks + t0 / K1_CHUNK) * 6;
                 const double qlo[5] = {qp[0], qp[1], qp[2], qp[3], qp[4]}, qsc = qp[5];
-                const unsigned *qb = p.mquant + (size_t)p.mslot[c] * 5 * ls;
-                unsigned qv[5][K1_RPL];
+                const unsigned *qb = p.mquant + (size_t)p.mslot[c] * 3 * ls;
+                unsigned qv[3][K1_RPL];
 #pragma unroll
-                for (int k = 0; k < 5; k++)
+                for (int k = 0; k < 3; k++)
 #pragma unroll
                     for (int j = 0; j < K1_RPL; j++) { const int t = t0 + lane + WAVE * j; qv[k][j] = qb[(size_t)k * ls + (t < nrows ? t : 0)]; }
 #pragma unroll
-                for (int j = 0; j < K1_RPL; j++) if (t0 + lane + WAVE * j >= nrows) qv[0][j] = 0x70000000u;   // beyond the lap: farther than any row
+                for (int j = 0; j < K1_RPL; j++) if (t0 + lane + WAVE * j >= nrows) qv[2][j] |= 0xffff0000u;
                 // ---- step A: integer prefilter, one query at a time; survivors (row indices) go to the query's 16-slot LDS segment ----
                 const int nqw = nq > sgi ? (nq - sgi + nsub - 1) / nsub : 0;                  // queries of this wave: qi = sgi + s nsub
                 // (two queries per trip: their reduction chains are independent and interleave)
                 for (int s = 0; s < nqw; s += 2) {
                     const bool two = s + 1 < nqw;
                     const int qa = sgi + s * nsub, qb2 = two ? qa + nsub : qa;
-                    unsigned ya[5], yb[5];
+                    unsigned ta5[5], tb5[5];
 #pragma unroll
                     for (int k = 0; k < 5; k++) {
-                        ya[k] = (unsigned)fmin(fmax((qf[qa][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 268435456.0);
-                        yb[k] = (unsigned)fmin(fmax((qf[qb2][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 268435456.0);
+                        ta5[k] = (unsigned)fmin(fmax((qf[qa][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 65535.0);
+                        tb5[k] = (unsigned)fmin(fmax((qf[qb2][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 65535.0);
                     }
+                    const unsigned ya[3] = {ta5[0] | (ta5[1] << 16), ta5[2] | (ta5[3] << 16), ta5[4]};
+                    const unsigned yb[3] = {tb5[0] | (tb5[1] << 16), tb5[2] | (tb5[3] << 16), tb5[4]};
                     unsigned ea[K1_RPL], eb[K1_RPL], ma = 0xffffffffu, mb = 0xffffffffu;
 #pragma unroll
                     for (int j = 0; j < K1_RPL; j++) {
                         unsigned a_ = 0, b_ = 0;
 #pragma unroll
-                        for (int k = 0; k < 5; k++) { a_ = sad_u32(qv[k][j], ya[k], a_); b_ = sad_u32(qv[k][j], yb[k], b_); }
+                        for (int k = 0; k < 3; k++) { a_ = sad_u16(qv[k][j], ya[k], a_); b_ = sad_u16(qv[k][j], yb[k], b_); }
                         ea[j] = a_; eb[j] = b_; ma = a_ < ma ? a_ : ma; mb = b_ < mb ? b_ : mb;
                     }
                     // MAXP-th smallest distinct lane minimum: at least MAXP rows lie at or below it (one-instruction DPP integer minima)
@@ -339,8 +345,9 @@ __global__ __launch_bounds__(K1_NT) void lmpc_regress_kernel(lmpc_dev_params p, 
                         ba = wminu((r == 0 || ma > ba) ? ma : 0xffffffffu);
                         bb = wminu((r == 0 || mb > bb) ? mb : 0xffffffffu);
                     }
-                    // quantisation error of a row: < 2 units per feature; the prefilter keeps everything that could be in the top MAXP
-                    const unsigned ta = ba > 0xffffff00u ? 0xffffffffu : ba + 12u, tb = bb > 0xffffff00u ? 0xffffffffu : bb + 12u;
+                    // quantisation error of a row: < 1 unit per feature (floors of the row and of the query); the prefilter keeps everything
+                    // that could be in the top MAXP
+                    const unsigned ta = ba > 0xffffff00u ? 0xffffffffu : ba + 8u, tb = bb > 0xffffff00u ? 0xffffffffu : bb + 8u;
                     int na = 0, nb = 0;
 #pragma unroll
                     for (int j = 0; j < K1_RPL; j++) {
