@@ -20,8 +20,14 @@ def mean_counter(path, name):
 fetch = mean_counter(tag + "_pmc_pass1.csv", "FETCH_SIZE")
 write = mean_counter(tag + "_pmc_pass2.csv", "WRITE_SIZE")
 out = {}
+def short_name(kname):
+    if "true>" in kname:                      # the retry variant lmpc_solve_kernel<N, S, true>: every work-group exits at once
+        return None
+    return "lmpc_solve_kernel" if "lmpc_solve_kernel" in kname else ("lmpc_regress_kernel" if "lmpc_regress_kernel" in kname else None)
+
+
 for kname in fetch:
-    short = "lmpc_solve_kernel" if "lmpc_solve_kernel" in kname else ("lmpc_regress_kernel" if "lmpc_regress_kernel" in kname else None)
+    short = short_name(kname)
     if short is None:
         continue
     out[short + "_bytes_per_launch_B256_N12"] = 2 * fetch[kname] * 1024 + write.get(kname, 0.0) * 1024
@@ -41,7 +47,7 @@ def all_counters(path):
 cnt = collections.defaultdict(dict)
 for i in (3, 4, 5, 6):
     for kname, d in all_counters("%s_pmc_pass%d.csv" % (tag, i)).items():
-        short = "lmpc_solve_kernel" if "lmpc_solve_kernel" in kname else ("lmpc_regress_kernel" if "lmpc_regress_kernel" in kname else None)
+        short = short_name(kname)
         if short:
             cnt[short].update(d)
 for short, d in cnt.items():
