@@ -187,7 +187,8 @@ def main():
         ms_solve = st.ms_solve / max(st.n_solve, 1); ms_reg = st.ms_regress / max(st.n_regress, 1)
         bytes_per_solve = 8 * (18 * N + 92)                     # SURVEY 8(d) B_solve: compulsory in+out per full step
         achieved = B * bytes_per_solve / (ms_solve * 1e-3) / 1e9
-        kname = "lmpc_solve_kernel_mw<%d,%d,4>" % (N, S) if ctx.solver_waves(B) == 4 else "lmpc_solve_kernel<%d,%d>" % (N, S)
+        nw = ctx.solver_waves(B)
+        kname = "lmpc_solve_kernel_mw<%d,%d,%d>" % (N, S, nw) if nw > 1 else "lmpc_solve_kernel<%d,%d>" % (N, S)
         traffic = None; counters = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):

@@ -36,6 +36,7 @@ struct lmpc_ctx {
     size_t lds_bytes;
     int (*solve_launch)(lmpc_ctx *, int, const lmpc_solve_io &);
     int (*solve_launch_mw)(lmpc_ctx *, int, const lmpc_solve_io &);
+    int (*solve_launch_mw2)(lmpc_ctx *, int, const lmpc_solve_io &);  // 2 waves per QP, batches between one and two QPs per CU
     int (*solve_launch_retry)(lmpc_ctx *, int, const lmpc_solve_io &);   // equal-step re-run of the problems that hit the iteration limit   // 4 waves per QP, used for small batches
     int mw_max_batch, n_cu;
     int profiling; std::vector<evpair> events; lmpc_stats stats;
@@ -50,6 +51,10 @@ template <int N, int S> static int solve_launch_retry_t(lmpc_ctx *c, int B, cons
     hipLaunchKernelGGL((lmpc_solve_kernel<N, S, true>), dim3(B), dim3(WAVE), c->lds_bytes, c->stream, c->dp, B, io);
     return LMPC_OK;
 }
+template <int N, int S> static int solve_launch_mw2_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
+    hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 2>), dim3(B), dim3(WAVE * 2), c->lds_bytes, c->stream, c->dp, B, io);
+    return LMPC_OK;
+}
 template <int N, int S> static int solve_launch_mw_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
     hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 4>), dim3(B), dim3(WAVE * 4), c->lds_bytes, c->stream, c->dp, B, io);
     return LMPC_OK;
@@ -61,6 +66,8 @@ template <int N, int S> static bool try_pick(lmpc_ctx *c, int n, int s) {
     if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
     c->solve_launch = &solve_launch_t<N, S>;
     c->solve_launch_mw = &solve_launch_mw_t<N, S>;
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
+    c->solve_launch_mw2 = &solve_launch_mw2_t<N, S>;
     if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
     c->solve_launch_retry = &solve_launch_retry_t<N, S>;
     return true;
@@ -359,7 +366,9 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
     const bool term = c->cfg.numSS_it > 0;
     int rc = refresh_params(c, false, term && (io.mode & 1)); if (rc) return rc;
     ev_begin(c, 1);
-    rc = (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->solve_launch_mw(c, B, io) : c->solve_launch(c, B, io);
+    // waves per QP so that every SIMD has a wave: 4 up to one QP per CU, 2 up to two QPs per CU, 1 beyond
+    rc = (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->solve_launch_mw(c, B, io)
+       : (B <= 2 * c->n_cu && c->mw_max_batch == c->n_cu && !io.tbuf) ? c->solve_launch_mw2(c, B, io) : c->solve_launch(c, B, io);
     ev_end(c);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -705,7 +714,7 @@ int lmpc_selftest(lmpc_ctx *c) {
     return LMPC_OK;
 }
 
-int lmpc_solver_waves(lmpc_ctx *c, int B) { if (!c) return LMPC_E_ARG; return B <= c->mw_max_batch ? 4 : 1; }
+int lmpc_solver_waves(lmpc_ctx *c, int B) { if (!c) return LMPC_E_ARG; return B <= c->mw_max_batch ? 4 : (B <= 2 * c->n_cu && c->mw_max_batch == c->n_cu) ? 2 : 1; }
 
 int lmpc_set_profiling(lmpc_ctx *c, int on) { ARGCHK(c); c->profiling = on ? 1 : 0; return LMPC_OK; }
 static int drain_events(lmpc_ctx *c) {
