@@ -95,6 +95,12 @@ def test_batch4096_safe_set_from_30_laps(built):
     assert np.all(out3["status"] == 0)
     assert np.abs(out3["xPred"] - out["xPred"][sub]).max() < 1e-7 and np.abs(out3["uPred"] - out["uPred"][sub]).max() < 1e-7
     assert np.array_equal(out3["ssSel"], out["ssSel"][sub])
+    # batches between one and two QPs per CU run it with two waves per QP
+    sub = perm[:400]
+    out4 = ctx.step_batch(inp["x0"][sub], inp["xLin"][sub], inp["uLin"][sub], inp["uOld"][sub], zt=inp["zt"][sub], timeStep=inp["timeStep"][sub])
+    assert np.all(out4["status"] == 0) and ctx.solver_waves(400) in (2, 1)
+    assert np.abs(out4["xPred"] - out["xPred"][sub]).max() < 1e-7 and np.abs(out4["uPred"] - out["uPred"][sub]).max() < 1e-7
+    assert np.array_equal(out4["ssSel"], out["ssSel"][sub])
     # sampled comparison with the oracle (stores in the library's order: model sorted ascending, safe set = argsort(LapTime))
     model_sorted = [laps[i] for i in order]
     ss_sel = [laps[i] for i in order]
