@@ -163,6 +163,8 @@ int lmpc_rollout_end(lmpc_ctx *);
 int lmpc_ss_extend_lap(lmpc_ctx *, int lap, const double *x /*n x 6*/, const double *u /*n x 2*/, int n);
         /* LMPC.addPoint (:466-474) applied to any stored lap: n points appended with s + TrackLength, Qfun counting down */
 int lmpc_selftest(lmpc_ctx *);                   /* device self test of the cross-lane reduction primitives */
+/* Developer switch (environment, read at lmpc_create): LMPC_MW_MAX_BATCH=<n> overrides the largest batch that runs four waves per
+ * QP (default: the number of CUs; 0 forces the one-wave kernel everywhere).  Results do not depend on it beyond summation order. */
 int lmpc_solver_waves(lmpc_ctx *, int B);         /* wavefronts per QP the solve kernel uses for a batch of B (4 or 2: lmpc_solve_kernel_mw, 1: lmpc_solve_kernel) */
 int lmpc_set_profiling(lmpc_ctx *, int on);       /* HIP events around each kernel launch */
 int lmpc_get_stats(lmpc_ctx *, lmpc_stats *out);  /* drains pending events */
