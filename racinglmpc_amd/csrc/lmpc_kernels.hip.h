@@ -1241,6 +1241,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
                 const double dtt = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dmm = -h[r] - th[r] * dtt;
                 dm[r] = dmm;
+                if constexpr (EQ) dt_r[j] = dtt;
                 if (dtt < 0.0) apx = fmin(apx, -t_r[j] * frcp(dtt));
                 if (dmm < 0.0) adx = fmin(adx, -mr * frcp(dmm));
             }
@@ -1248,6 +1249,22 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         apx = wmin(apx); adx = wmin(adx);
         double al = fmin(1.0, 0.995 * apx), ald = fmin(1.0, 0.995 * adx);
         if (!sep) { al = fmin(al, ald); ald = al; }
+        if constexpr (EQ) {
+            // retry variant only: stay in a wide neighbourhood of the central path -- shorten the step until every complementarity
+            // product keeps at least 1 % of the mean.  It costs the well-behaved problems half an iteration (so the first pass does not
+            // do it) and is what gets the remaining stalled ones through (NumPy model: 11-12 iterations instead of a stall).
+            for (int trial = 0; trial < 8; trial++) {
+                double pmin = INFINITY, psum = 0.0;
+#pragma unroll
+                for (int j = 0; j < RPL; j++) {
+                    const int r = lane + WAVE * j;
+                    if (r < M) { const double pr = (t_r[j] + al * dt_r[j]) * (m[r] + ald * dm[r]); pmin = fmin(pmin, pr); psum += pr; }
+                }
+                pmin = wmin(pmin); psum = wsum(psum);
+                if (pmin >= 1e-2 * psum / (double)M) break;
+                al *= 0.7; ald *= 0.7;
+            }
+        }
         TSTAMP(17);
         // ---- multipliers of the equality rows (costates): nu_k = -(Pi_k xi_k + p_k)_x, all stages at once ----
         if constexpr (term) {
