@@ -716,8 +716,9 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     constexpr int RPL = (M + WAVE - 1) / WAVE;              // inequality rows per lane
     const int b = blockIdx.x;
     if (b >= B) return;
-    // retry variant (EQ): only problems that hit the iteration limit run again, with equal primal / dual steps throughout
-    if constexpr (EQ) { if (!(io.status[b] & LMPC_ST_MAXITER)) return; }
+    // retry variant (EQ): only problems that hit the iteration limit (or broke down numerically far from the optimum) run again,
+    // with equal primal / dual steps throughout and a neighbourhood safeguard on the step length
+    if constexpr (EQ) { if (!(io.status[b] & (LMPC_ST_MAXITER | LMPC_ST_NUMERIC))) return; }
     const int lane = threadIdx.x;
     const int lg = lane >> 3, lc = lane & 7;                // lane = 8 g + c  (8 x 8 tile coordinates)
     double *AB = sm + LL::oAB, *C = sm + LL::oC, *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
