@@ -71,7 +71,7 @@ typedef struct {
     double ms_regress, ms_solve;      /* accumulated HIP-event time of the two kernels (profiling on) */
     long long n_regress, n_solve;     /* launches accumulated */
     long long qp_solved;              /* problems passed through the solve kernel */
-    long long ipm_iters;              /* interior-point iterations accumulated (last D2H of iters) */
+    long long ipm_iters;              /* interior-point iterations accumulated by the host-buffer entry points (lmpc_step_batch, lmpc_qp_solve_batch) */
 } lmpc_stats;
 
 int lmpc_config_default(lmpc_config *cfg);                       /* reference defaults, N = 12 */
@@ -122,9 +122,11 @@ int lmpc_step_batch(lmpc_ctx *, int B, const double *x0, const double *xLin /*B 
                     const double *uOld, const double *zt, const double *xPredPrev, const int *hasPred, const int *timeStep,
                     double *xPred, double *uPred, double *slack, double *lambda, double *sTerm,
                     double *ztNext /*B x 6*/, double *ztuNext /*B x 2*/, double *ssSel /*B x S x 6*/,
+                    double *qSel /*B x S: Qfun_SelectedTot, :404-412, or NULL*/, double *mu /*B x (8N+S) inequality duals, reference row order, or NULL*/,
                     double *Aout /*B x N x 36 or NULL*/, double *Bout, double *Cout,
                     int *status, int *iters, double *resid);
-        /* one full MPC.solve(x0) per problem, :110-137 (a3 -> a19 of SURVEY section 8) */
+        /* one full MPC.solve(x0) per problem, :110-137 (a3 -> a19 of SURVEY section 8).  status[b] carries the solver bits and the
+         * OR of the regression kernel's per-point bits (LMPC_ST_REG_SINGULAR, LMPC_ST_NO_SEGMENT) of the problem's N points. */
 
 int lmpc_assemble_batch(lmpc_ctx *, int B, const double *A, const double *Bm, const double *C, const double *x0, const double *uOld,
                         const double *ssSel, const double *qSel,
@@ -142,8 +144,9 @@ typedef struct {          /* all device pointers, layouts as in lmpc_step_batch 
     const double *x0, *xLin, *uLin, *uOld, *zt, *xPredPrev; const int *hasPred, *timeStep;
     double *xPred, *uPred, *slack, *lambda, *sTerm, *ztNext, *ztuNext, *ssSel, *A, *Bm, *C, *mu, *resid;
     int *status, *iters;
+    double *qSel;          /* B x S or NULL */
 } lmpc_step_dev_args;
-int lmpc_step_batch_dev(lmpc_ctx *, int B, const lmpc_step_dev_args *args);   /* async on the ctx stream */
+int lmpc_step_batch_dev(lmpc_ctx *, int B, const lmpc_step_dev_args *args);   /* async on the ctx stream; status as in lmpc_step_batch */
 
 /* ---- caller side of the path, next row of SURVEY 8(f): plant integrator + device-resident closed-loop laps ---- */
 /* Map.getGlobalPosition (Track.py:135-189), batched: curvilinear (s, ey) -> inertial (X, Y) for n points on the track given

@@ -38,7 +38,7 @@ class LmpcStats(C.Structure):
 class StepDevArgs(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("x0", "xLin", "uLin", "uOld", "zt", "xPredPrev", "hasPred", "timeStep",
                                           "xPred", "uPred", "slack", "lambda_", "sTerm", "ztNext", "ztuNext", "ssSel",
-                                          "A", "Bm", "C", "mu", "resid", "status", "iters")]
+                                          "A", "Bm", "C", "mu", "resid", "status", "iters", "qSel")]
 
 
 EXPORTS = [
@@ -207,11 +207,13 @@ class Context:
         ts = None if timeStep is None else _i32(timeStep)
         out = dict(xPred=np.zeros((B, N + 1, 6)), uPred=np.zeros((B, N, 2)), slack=np.zeros((B, 2 * N)), lambd=np.zeros((B, S)),
                    sTerm=np.zeros((B, 6)), ztNext=np.zeros((B, 6)), ztuNext=np.zeros((B, 2)), ssSel=np.zeros((B, S, 6)),
+                   qSel=np.zeros((B, S)), mu=np.zeros((B, self.M)),
                    A=np.zeros((B, N, 6, 6)), B=np.zeros((B, N, 6, 2)), C=np.zeros((B, N, 6)),
                    status=np.zeros(B, np.int32), iters=np.zeros(B, np.int32), resid=np.zeros((B, 3)))
         _chk(self.lib.lmpc_step_batch(self._h, C.c_int(B), _d(x0), _d(xLin), _d(uLin), _d(uOld), _d(ztc), _d(xpp), _d(hp), _d(ts),
                                       _d(out["xPred"]), _d(out["uPred"]), _d(out["slack"]), _d(out["lambd"]), _d(out["sTerm"]),
-                                      _d(out["ztNext"]), _d(out["ztuNext"]), _d(out["ssSel"]), _d(out["A"]), _d(out["B"]), _d(out["C"]),
+                                      _d(out["ztNext"]), _d(out["ztuNext"]), _d(out["ssSel"]), _d(out["qSel"]), _d(out["mu"]),
+                                      _d(out["A"]), _d(out["B"]), _d(out["C"]),
                                       _d(out["status"]), _d(out["iters"]), _d(out["resid"])))
         return out
 
@@ -259,6 +261,44 @@ class Context:
 
     def step_batch_dev(self, B, args):
         _chk(self.lib.lmpc_step_batch_dev(self._h, C.c_int(B), C.byref(args)))
+
+    def step_dev_buffers(self, inp):
+        """HBM-resident inputs/outputs of lmpc_step_batch_dev for a batch given as host arrays (keys x0, xLin, uLin, uOld, zt,
+        xPredPrev, hasPred, timeStep).  Returns (StepDevArgs, device pointers to free with dev_free)."""
+        N, S, M = self.N, self.S, self.M
+        B = np.asarray(inp["x0"]).shape[0]
+        a = StepDevArgs(); keep = []
+
+        def up(arr, dt):
+            p = self.dev_array(np.ascontiguousarray(arr, dtype=dt)); keep.append(p); return p
+
+        def alloc(nbytes):
+            p = self.dev_alloc(max(int(nbytes), 8)); keep.append(p); return p
+        a.x0, a.xLin, a.uLin, a.uOld = up(inp["x0"], np.float64), up(inp["xLin"], np.float64), up(inp["uLin"], np.float64), up(inp["uOld"], np.float64)
+        a.zt = up(inp["zt"] if inp.get("zt") is not None else np.zeros((B, 6)), np.float64)
+        a.xPredPrev = up(inp["xPredPrev"] if inp.get("xPredPrev") is not None else np.zeros((B, N + 1, 6)), np.float64)
+        a.hasPred = up(inp["hasPred"] if inp.get("hasPred") is not None else np.zeros(B), np.int32)
+        a.timeStep = up(inp["timeStep"] if inp.get("timeStep") is not None else np.zeros(B), np.int32)
+        a.xPred, a.uPred, a.slack = alloc(B * (N + 1) * 6 * 8), alloc(B * N * 2 * 8), alloc(B * N * 2 * 8)
+        a.lambda_, a.sTerm, a.ztNext, a.ztuNext = alloc(B * S * 8), alloc(B * 6 * 8), alloc(B * 6 * 8), alloc(B * 2 * 8)
+        a.ssSel, a.qSel, a.A, a.Bm, a.C = alloc(B * S * 6 * 8), alloc(B * S * 8), alloc(B * N * 36 * 8), alloc(B * N * 12 * 8), alloc(B * N * 6 * 8)
+        a.mu, a.resid, a.status, a.iters = alloc(B * M * 8), alloc(B * 3 * 8), alloc(B * 4), alloc(B * 4)
+        return a, keep
+
+    def step_dev_fetch(self, a, B):
+        """Download every output of a finished lmpc_step_batch_dev call (same keys as step_batch)."""
+        N, S, M = self.N, self.S, self.M
+        self.sync()
+        out = dict(xPred=np.zeros((B, N + 1, 6)), uPred=np.zeros((B, N, 2)), slack=np.zeros((B, 2 * N)), lambd=np.zeros((B, S)),
+                   sTerm=np.zeros((B, 6)), ztNext=np.zeros((B, 6)), ztuNext=np.zeros((B, 2)), ssSel=np.zeros((B, S, 6)), qSel=np.zeros((B, S)),
+                   mu=np.zeros((B, M)), A=np.zeros((B, N, 6, 6)), B=np.zeros((B, N, 6, 2)), C=np.zeros((B, N, 6)),
+                   status=np.zeros(B, np.int32), iters=np.zeros(B, np.int32), resid=np.zeros((B, 3)))
+        src = dict(xPred=a.xPred, uPred=a.uPred, slack=a.slack, lambd=a.lambda_, sTerm=a.sTerm, ztNext=a.ztNext, ztuNext=a.ztuNext, ssSel=a.ssSel,
+                   qSel=a.qSel, mu=a.mu, A=a.A, B=a.Bm, C=a.C, status=a.status, iters=a.iters, resid=a.resid)
+        for k, arr in out.items():
+            if arr.nbytes:
+                self.dev_download(src[k], arr)
+        return out
 
     def plant_step_batch(self, x, x_glob, u, noise):
         x = _f64(x); xg = _f64(x_glob); u = _f64(u); nz = _f64(noise); B = x.shape[0]

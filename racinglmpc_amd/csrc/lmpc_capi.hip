@@ -117,27 +117,22 @@ static void fill_params(lmpc_ctx *c) {
     p.mquant = c->mquant; p.mqpar = c->mqpar; p.mq_chunks = c->mq_chunks;
 }
 
-int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
-    ARGCHK(cfg && out);
-    ARGCHK(cfg->N >= 2 && cfg->N <= LMPC_MAX_N);
-    ARGCHK(cfg->numSS_it >= 0 && cfg->numSS_it <= LMPC_MAX_USED_LAPS && cfg->trToUse >= 0 && cfg->trToUse <= LMPC_MAX_USED_LAPS);
-    ARGCHK(cfg->maxNumPoint >= 1 && cfg->maxNumPoint <= 8);
-    if (cfg->numSS_it > 0) {
-        ARGCHK(cfg->numSS_points % cfg->numSS_it == 0 && cfg->numSS_points + 6 <= WAVE && cfg->numSS_points / cfg->numSS_it + 1 <= WAVE);
-        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) if (i != j) ARGCHK(cfg->QtermSlack[i * 6 + j] == 0.0);   // diagonal terminal-slack weight
-        for (int i = 0; i < 6; i++) ARGCHK(cfg->QtermSlack[i * 7] > 0.0);
-    }
-    ARGCHK(cfg->track_rows >= 0 && cfg->track_rows <= LMPC_MAX_TRACK_ROWS);
-    ARGCHK(cfg->max_batch >= 1 && cfg->max_laps >= 1 && cfg->max_lap_len >= 8);
-    lmpc_ctx *c = new lmpc_ctx();
-    c->cfg = *cfg; c->profiling = 0; c->ro = nullptr;
+}  // extern "C" (helpers)
+
+// everything of lmpc_create that can fail; the caller destroys the context on any error (one failure path, no leaks)
+static int create_body(lmpc_ctx *c) {
+    const lmpc_config *cfg = &c->cfg;
+    HIPCHK(hipSetDevice(cfg->device));
+    // an unsupported (N, numSS_points) pair is an ordinary user error: find that out before anything is allocated
+    if (!pick_solver(c)) return set_err(LMPC_E_ARG, "unsupported (N, numSS_points): built variants are N in {8,12,14,20,40} x numSS_points in {0,48}", "");
     {   // batches that leave SIMDs idle (B <= number of CUs) run the 4-waves-per-QP kernel
         const char *e = getenv("LMPC_MW_MAX_BATCH"); hipDeviceProp_t prop; int cus = 256;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         c->mw_max_batch = e ? atoi(e) : cus; c->n_cu = cus;
-    } memset(&c->stats, 0, sizeof(c->stats));
-    hipError_t e = hipSetDevice(cfg->device);
-    if (e != hipSuccess) { delete c; return set_err(LMPC_E_HIP, "hipSetDevice", hipGetErrorString(e)); }
+    }
+    // a variant whose LDS footprint leaves room for one QP per CU (N = 40) keeps three SIMDs idle in the 1-wave kernel at any
+    // batch size: always run it with four waves per QP (measured at N=40, B=1024: 2.80 vs 3.52 ms; N=20 and N=14 prefer 1 wave)
+    if (!getenv("LMPC_MW_MAX_BATCH") && 2 * c->lds_bytes > 160 * 1024) c->mw_max_batch = 1 << 30;
     HIPCHK(hipStreamCreate(&c->stream));
     const size_t store_elems = (size_t)cfg->max_laps * LMPC_COLS * cfg->max_lap_len;
     HIPCHK(hipMalloc(&c->mstore, store_elems * sizeof(double)));
@@ -158,10 +153,28 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     DALLOC(w_mu, B * M); DALLOC(w_ztN, B * 6); DALLOC(w_ztuN, B * 2); DALLOC(w_resid, B * 3);
     DALLOC(w_hasPred, B); DALLOC(w_tstep, B); DALLOC(w_status, B); DALLOC(w_iters, B); DALLOC(w_rstatus, B * N);
 #undef DALLOC
-    if (!pick_solver(c)) { delete c; return set_err(LMPC_E_ARG, "unsupported (N, numSS_points): built variants are N in {8,12,14,20,40} x numSS_points in {0,48}", ""); }
-    // a variant whose LDS footprint leaves room for one QP per CU (N = 40) keeps three SIMDs idle in the 1-wave kernel at any
-    // batch size: always run it with four waves per QP (measured at N=40, B=1024: 2.80 vs 3.52 ms; N=20 and N=14 prefer 1 wave)
-    if (!getenv("LMPC_MW_MAX_BATCH") && 2 * c->lds_bytes > 160 * 1024) c->mw_max_batch = 1 << 30;
+    return LMPC_OK;
+}
+
+extern "C" {
+int lmpc_destroy(lmpc_ctx *c);
+int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
+    ARGCHK(cfg && out);
+    ARGCHK(cfg->N >= 2 && cfg->N <= LMPC_MAX_N);
+    ARGCHK(cfg->numSS_it >= 0 && cfg->numSS_it <= LMPC_MAX_USED_LAPS && cfg->trToUse >= 0 && cfg->trToUse <= LMPC_MAX_USED_LAPS);
+    ARGCHK(cfg->maxNumPoint >= 1 && cfg->maxNumPoint <= 8);
+    if (cfg->numSS_it > 0) {
+        ARGCHK(cfg->numSS_points % cfg->numSS_it == 0 && cfg->numSS_points + 6 <= WAVE && cfg->numSS_points / cfg->numSS_it + 1 <= WAVE);
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) if (i != j) ARGCHK(cfg->QtermSlack[i * 6 + j] == 0.0);   // diagonal terminal-slack weight
+        for (int i = 0; i < 6; i++) ARGCHK(cfg->QtermSlack[i * 7] > 0.0);
+    }
+    ARGCHK(cfg->track_rows >= 0 && cfg->track_rows <= LMPC_MAX_TRACK_ROWS);
+    ARGCHK(cfg->max_batch >= 1 && cfg->max_laps >= 1 && cfg->max_lap_len >= 8);
+    lmpc_ctx *c = new lmpc_ctx();                      // value-initialised: every pointer starts as nullptr, so lmpc_destroy is safe at any point
+    c->cfg = *cfg; c->profiling = 0; c->ro = nullptr;
+    memset(&c->stats, 0, sizeof(c->stats));
+    int rc = create_body(c);
+    if (rc != LMPC_OK) { const std::string keep = g_err; lmpc_destroy(c); g_err = keep; return rc; }
     fill_params(c);
     *out = c;
     return LMPC_OK;
@@ -170,15 +183,15 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
 static void rollout_free(lmpc_ctx *c);
 int lmpc_destroy(lmpc_ctx *c) {
     if (!c) return LMPC_OK;
-    hipSetDevice(c->cfg.device);
-    hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     rollout_free(c);
-    for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     void *ptrs[] = {c->mstore, c->sstore, c->mquant, c->mqpar, c->w_x0, c->w_xLin, c->w_uLin, c->w_uOld, c->w_zt, c->w_xPP, c->w_A, c->w_B, c->w_C, c->w_ssSel, c->w_qSel,
                     c->w_succ, c->w_succU, c->w_ztUsed, c->w_xPred, c->w_uPred, c->w_slack, c->w_lam, c->w_sT, c->w_mu, c->w_ztN, c->w_ztuN, c->w_resid,
                     c->w_hasPred, c->w_tstep, c->w_status, c->w_iters, c->w_rstatus};
-    for (void *q : ptrs) if (q) hipFree(q);
-    hipStreamDestroy(c->stream);
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LMPC_OK;
 }
@@ -299,8 +312,8 @@ int lmpc_ss_replace_lap(lmpc_ctx *c, int lap, const double *x, const double *u, 
     return LMPC_OK;
 }
 int lmpc_ss_set_selected(lmpc_ctx *c, const int *laps, int n) {
-    ARGCHK(c && n >= 0 && n <= LMPC_MAX_USED_LAPS);
-    c->s_override.assign(laps, laps + n);
+    ARGCHK(c && n >= 0 && n <= LMPC_MAX_USED_LAPS && (n == 0 || laps));
+    if (n == 0) c->s_override.clear(); else c->s_override.assign(laps, laps + n);
     return LMPC_OK;
 }
 int lmpc_ss_num_laps(lmpc_ctx *c, int *n) { ARGCHK(c && n); *n = (int)c->s_len.size(); return LMPC_OK; }
@@ -388,6 +401,17 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
 #define H2D(dst, src, n) HIPCHK(hipMemcpyAsync(dst, src, sizeof(*(dst)) * (size_t)(n), hipMemcpyHostToDevice, c->stream))
 #define D2H(dst, src, n) do { if (dst) HIPCHK(hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(n), hipMemcpyDeviceToHost, c->stream)); } while (0)
 
+// iteration counts of the batch just solved into the work buffers: copied to the caller (if asked) and added to lmpc_stats.ipm_iters
+// (host-buffer entry points only: the device-resident path leaves the counts in the caller's device buffer)
+static int fetch_iters(lmpc_ctx *c, int B, int *iters) {
+    std::vector<int> tmp; int *dst = iters;
+    if (!dst) { tmp.resize((size_t)B); dst = tmp.data(); }
+    HIPCHK(hipMemcpyAsync(dst, c->w_iters, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < B; b++) c->stats.ipm_iters += dst[b];
+    return LMPC_OK;
+}
+
 int lmpc_regress_batch(lmpc_ctx *c, int B, const double *xLin, int xLinRowStride, const double *uLin, double *A, double *Bm, double *C, int *status) {
     ARGCHK(c && xLin && uLin && A && Bm && C && B >= 1 && B <= c->cfg.max_batch);
     const int N = c->cfg.N;
@@ -436,9 +460,8 @@ int lmpc_qp_solve_batch(lmpc_ctx *c, int B, const double *A, const double *Bm, c
     int rc = launch_solve(c, B, io); if (rc) return rc;
     D2H(xPred, c->w_xPred, (size_t)B * (N + 1) * 6); D2H(uPred, c->w_uPred, (size_t)B * N * 2); D2H(slack, c->w_slack, (size_t)B * N * 2);
     if (S > 0) { D2H(lambda, c->w_lam, (size_t)B * S); D2H(sTerm, c->w_sT, (size_t)B * 6); }
-    D2H(mu, c->w_mu, (size_t)B * M); D2H(status, c->w_status, B); D2H(iters, c->w_iters, B); D2H(resid, c->w_resid, (size_t)B * 3);
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return LMPC_OK;
+    D2H(mu, c->w_mu, (size_t)B * M); D2H(status, c->w_status, B); D2H(resid, c->w_resid, (size_t)B * 3);
+    return fetch_iters(c, B, iters);                     // synchronises the stream
 }
 
 int lmpc_step_batch_dev(lmpc_ctx *c, int B, const lmpc_step_dev_args *a) {
@@ -453,13 +476,15 @@ int lmpc_step_batch_dev(lmpc_ctx *c, int B, const lmpc_step_dev_args *a) {
     io.mode = term ? 3 : 2; io.A = a->A; io.Bm = a->Bm; io.C = a->C; io.x0 = a->x0; io.uOld = a->uOld;
     io.zt = a->zt; io.xPredPrev = a->xPredPrev; io.hasPred = a->hasPred; io.timeStep = a->timeStep;
     io.xPred = a->xPred; io.uPred = a->uPred; io.slack = a->slack; io.lambda = a->lambda; io.sTerm = a->sTerm; io.mu = a->mu;
-    io.ztNext = a->ztNext; io.ztuNext = a->ztuNext; io.ssSelOut = a->ssSel; io.resid = a->resid; io.status = a->status; io.iters = a->iters;
+    io.ztNext = a->ztNext; io.ztuNext = a->ztuNext; io.ssSelOut = a->ssSel; io.qSelOut = a->qSel; io.resid = a->resid; io.status = a->status; io.iters = a->iters;
+    io.rstatus = c->w_rstatus;                          // a singular regression / off-track linearisation point marks status[b] (the reference raises)
     return launch_solve(c, B, io);
 }
 
 int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, const double *uLin, const double *uOld, const double *zt,
                     const double *xPredPrev, const int *hasPred, const int *timeStep, double *xPred, double *uPred, double *slack, double *lambda,
-                    double *sTerm, double *ztNext, double *ztuNext, double *ssSel, double *Aout, double *Bout, double *Cout, int *status, int *iters, double *resid) {
+                    double *sTerm, double *ztNext, double *ztuNext, double *ssSel, double *qSel, double *mu, double *Aout, double *Bout, double *Cout,
+                    int *status, int *iters, double *resid) {
     ARGCHK(c && x0 && xLin && uLin && uOld && xPred && uPred && B >= 1 && B <= c->cfg.max_batch);
     const int N = c->cfg.N; const bool term = c->cfg.numSS_it > 0; const int S = term ? c->cfg.numSS_points : 0;
     if (term) ARGCHK(zt != nullptr);
@@ -474,19 +499,15 @@ int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, co
     lmpc_step_dev_args a; memset(&a, 0, sizeof(a));
     a.x0 = c->w_x0; a.xLin = c->w_xLin; a.uLin = c->w_uLin; a.uOld = c->w_uOld; a.zt = c->w_zt; a.xPredPrev = c->w_xPP; a.hasPred = c->w_hasPred; a.timeStep = c->w_tstep;
     a.xPred = c->w_xPred; a.uPred = c->w_uPred; a.slack = c->w_slack; a.lambda = c->w_lam; a.sTerm = c->w_sT; a.ztNext = c->w_ztN; a.ztuNext = c->w_ztuN;
-    a.ssSel = c->w_ssSel; a.A = c->w_A; a.Bm = c->w_B; a.C = c->w_C; a.mu = c->w_mu; a.resid = c->w_resid; a.status = c->w_status; a.iters = c->w_iters;
+    a.ssSel = c->w_ssSel; a.qSel = c->w_qSel; a.A = c->w_A; a.Bm = c->w_B; a.C = c->w_C; a.mu = c->w_mu; a.resid = c->w_resid; a.status = c->w_status; a.iters = c->w_iters;
     int rc = lmpc_step_batch_dev(c, B, &a); if (rc) return rc;
     D2H(xPred, c->w_xPred, (size_t)B * (N + 1) * 6); D2H(uPred, c->w_uPred, (size_t)B * N * 2); D2H(slack, c->w_slack, (size_t)B * N * 2);
-    if (term) { D2H(lambda, c->w_lam, (size_t)B * S); D2H(sTerm, c->w_sT, (size_t)B * 6); D2H(ssSel, c->w_ssSel, (size_t)B * S * 6); }
+    if (term) { D2H(lambda, c->w_lam, (size_t)B * S); D2H(sTerm, c->w_sT, (size_t)B * 6); D2H(ssSel, c->w_ssSel, (size_t)B * S * 6); D2H(qSel, c->w_qSel, (size_t)B * S); }
+    D2H(mu, c->w_mu, (size_t)B * (8 * N + S));
     D2H(ztNext, c->w_ztN, (size_t)B * 6); D2H(ztuNext, c->w_ztuN, (size_t)B * 2);
     D2H(Aout, c->w_A, (size_t)B * N * 36); D2H(Bout, c->w_B, (size_t)B * N * 12); D2H(Cout, c->w_C, (size_t)B * N * 6);
-    D2H(status, c->w_status, B); D2H(iters, c->w_iters, B); D2H(resid, c->w_resid, (size_t)B * 3);
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (status) {   // fold the regression status bits of the N horizon steps into the per-problem status
-        std::vector<int> rs((size_t)B * N);
-        HIPCHK(hipMemcpy(rs.data(), c->w_rstatus, sizeof(int) * (size_t)B * N, hipMemcpyDeviceToHost));
-        for (int b = 0; b < B; b++) for (int i = 0; i < N; i++) status[b] |= rs[(size_t)b * N + i];
-    }
+    D2H(status, c->w_status, B); D2H(resid, c->w_resid, (size_t)B * 3);
+    rc = fetch_iters(c, B, iters); if (rc) return rc;    // synchronises the stream
     return LMPC_OK;
 }
 
@@ -647,7 +668,7 @@ int lmpc_rollout_run(lmpc_ctx *c, int max_steps, int *steps_total, int *n_done) 
         lmpc_solve_io io; memset(&io, 0, sizeof(io));
         io.mode = 3; io.A = r->d_A; io.Bm = r->d_B; io.C = r->d_C; io.x0 = r->d_x; io.uOld = r->d_uOld; io.zt = r->d_zt; io.xPredPrev = r->d_xPP; io.hasPred = r->d_hasPred;
         io.timeStep = r->d_tstep; io.xPred = r->d_xPred; io.uPred = r->d_uPred; io.slack = r->d_slack; io.lambda = r->d_lam; io.sTerm = r->d_sT; io.ztNext = r->d_ztN;
-        io.ztuNext = r->d_ztuN; io.resid = r->d_resid; io.status = r->d_status; io.iters = r->d_iters;
+        io.ztuNext = r->d_ztuN; io.resid = r->d_resid; io.status = r->d_status; io.iters = r->d_iters; io.rstatus = r->d_rst;
         if (r->t > 0) HIPCHK(hipStreamWaitEvent(c->stream, r->e_plant, 0));          // the solve needs the plant's new state
         rc = launch_solve(c, B, io); if (rc) return rc;
         HIPCHK(hipEventRecord(r->e_solved, c->stream));
@@ -682,20 +703,37 @@ int lmpc_rollout_fetch(lmpc_ctx *c, int t0, int t1, double *X, double *U, double
 
 int lmpc_rollout_end(lmpc_ctx *c) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream)); rollout_free(c); return LMPC_OK; }
 
+__global__ void lmpc_store_rows_kernel(double *base, int stride, int row0, int n, const double *rows /* n x 9: x (6, s already shifted) | u (2) | Qfun */) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * LMPC_COLS) { const int i = e / LMPC_COLS, col = e % LMPC_COLS; base[(size_t)col * stride + row0 + i] = rows[e]; }
+}
+
 int lmpc_ss_extend_lap(lmpc_ctx *c, int lap, const double *x, const double *u, int n) {
     // batched-mode form of LMPC.addPoint (:466-474) for ANY stored lap: append n points shifted by TrackLength in s,
-    // Q-function continuing to count down.  (In the reference the points of lap j extend lap j-1 one by one.)
-    ARGCHK(c && x && u && n >= 0 && lap >= 0 && lap < (int)c->s_len.size());
+    // Q-function continuing to count down.  (In the reference the points of lap j extend lap j-1 one by one.)  One upload, one launch.
+    ARGCHK(c && lap >= 0 && lap < (int)c->s_len.size() && n >= 0 && (n == 0 || (x && u)));
+    if (n == 0) return LMPC_OK;
     HIPCHK(hipSetDevice(c->cfg.device));
     if (c->s_len[lap] + n > c->cfg.max_lap_len) return set_err(LMPC_E_CAPACITY, "lap longer than max_lap_len", "");
-    double *base = c->sstore + (size_t)lap * LMPC_COLS * c->cfg.max_lap_len;
+    std::vector<double> rows((size_t)n * LMPC_COLS);
+    double q = c->s_qlast[lap];
     for (int i = 0; i < n; i++) {
-        const double q = c->s_qlast[lap] - 1.0; const int row = c->s_len[lap];
-        hipLaunchKernelGGL(lmpc_store_row_kernel, dim3(1), dim3(64), 0, c->stream, base, c->cfg.max_lap_len, row,
-                           x[i * 6 + 0], x[i * 6 + 1], x[i * 6 + 2], x[i * 6 + 3], x[i * 6 + 4] + c->cfg.trackLength, x[i * 6 + 5], u[i * 2], u[i * 2 + 1], q);
-        c->s_len[lap] = row + 1; c->s_qlast[lap] = q;
+        q -= 1.0;
+        double *r = &rows[(size_t)i * LMPC_COLS];
+        for (int j = 0; j < 6; j++) r[j] = x[(size_t)i * 6 + j];
+        r[4] += c->cfg.trackLength; r[6] = u[(size_t)i * 2]; r[7] = u[(size_t)i * 2 + 1]; r[8] = q;
     }
-    HIPCHK(hipGetLastError());
+    double *d_rows; HIPCHK(hipMalloc(&d_rows, rows.size() * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        double *base = c->sstore + (size_t)lap * LMPC_COLS * c->cfg.max_lap_len;
+        hipLaunchKernelGGL(lmpc_store_rows_kernel, dim3((n * LMPC_COLS + 255) / 256), dim3(256), 0, c->stream, base, c->cfg.max_lap_len, c->s_len[lap], n, (const double *)d_rows);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // rows (host) and d_rows are released below
+    (void)hipFree(d_rows);
+    if (e != hipSuccess) return set_err(LMPC_E_HIP, "lmpc_ss_extend_lap", hipGetErrorString(e));
+    c->s_len[lap] += n; c->s_qlast[lap] = q;
     return LMPC_OK;
 }
 

@@ -82,6 +82,7 @@ struct lmpc_solve_io {
     int mode;
     const double *A, *Bm, *C, *x0, *uOld, *ssSelIn, *qSelIn;
     const double *zt, *xPredPrev; const int *hasPred, *timeStep;
+    const int *rstatus;       // optional per-point status of the regression kernel (B x N): OR-ed into status[b] (the reference raises there)
     double *xPred, *uPred, *slack, *lambda, *sTerm, *mu, *ztNext, *ztuNext;
     double *ssSelOut, *qSelOut, *succOut, *succUOut, *ztUsed, *resid;
     int *status, *iters;
@@ -345,9 +346,12 @@ __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_d
                         ba = wminu((r == 0 || ma > ba) ? ma : 0xffffffffu);
                         bb = wminu((r == 0 || mb > bb) ? mb : 0xffffffffu);
                     }
-                    // quantisation error of a row: < 1 unit per feature (floors of the row and of the query); the prefilter keeps everything
-                    // that could be in the top MAXP
-                    const unsigned ta = ba > 0xffffff00u ? 0xffffffffu : ba + 8u, tb = bb > 0xffffff00u ? 0xffffffffu : bb + 8u;
+                    // Two-sided bound.  Per feature |floor(a) - floor(b)| differs from |a - b| by < 1, so over the five features the
+                    // integer distance e of a row and its exact scaled distance d satisfy |e - d| < 5.  (i) At least MAXP rows have
+                    // e <= T (T = ba / bb), hence d < T + 5: the MAXP-th smallest exact distance is < T + 5.  (ii) A row of the exact
+                    // top MAXP therefore has d < T + 5 and e < d + 5 < T + 10, i.e. e <= T + 9.  Everything up to T + 10 survives
+                    // (one unit of margin for the rounding of the host's fixed-point conversion); the survivors are re-ranked in FP64.
+                    const unsigned ta = ba > 0xffffff00u ? 0xffffffffu : ba + 10u, tb = bb > 0xffffff00u ? 0xffffffffu : bb + 10u;
                     int na = 0, nb = 0;
 #pragma unroll
                     for (int j = 0; j < K1_RPL; j++) {
@@ -707,6 +711,81 @@ template <int S> __device__ __forceinline__ void ss_times(const double *SS, cons
     if (j < 6 && part == 0) out[j] = acc - sub[j];
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2: safe-set selection.  LMPC.addTerminalComponents :392-412 and selectPoints :478-514.  Shared by the one-wave and the
+// multi-wave solve kernels: wave `wave` of NW handles laps wave, wave + NW, ...; results go to SS (6 x S, row-major), Qsel (S),
+// sel_start (window start per lap, kept for the successor rows of feasibleStateInput) and the optional global outputs.
+// ------------------------------------------------------------------------------------------------
+template <int N, int S, int NW>
+__device__ __forceinline__ void k2_select(const lmpc_dev_params &p, const lmpc_solve_io &io, int b, int lane, int wave, double *SS, double *Qsel,
+                                          int *sel_start, int *st_sh) {
+    if (io.mode & 1) {
+        double ztv[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) ztv[j] = io.zt[(size_t)b * 6 + j];
+        const double x04 = io.x0[(size_t)b * 6 + 4];
+        if (ztv[4] - x04 > p.TL / 2) ztv[4] = fmax(ztv[4] - p.TL, 0.0);        // :392-393
+        if (io.ztUsed && wave == 0 && lane < 6) { double v = ztv[0];
+#pragma unroll
+            for (int j = 1; j < 6; j++) if (lane == j) v = ztv[j];
+            io.ztUsed[(size_t)b * 6 + lane] = v; }
+        const int hasPred = io.hasPred ? io.hasPred[b] : 0;                     // Q-function shift bookkeeping (:502-512)
+        int crossed = 0;
+        if (hasPred) {
+            int c_ = 0;
+            if (lane <= N) c_ = (io.xPredPrev[((size_t)b * (N + 1) + lane) * 6 + 4] > p.TL) ? 1 : 0;
+            crossed = (int)__popcll(__ballot(c_));
+        }
+        const int tstep = io.timeStep ? io.timeStep[b] : 0;
+        const int ppl = p.ppl, npw = ppl + 1;                                   // numSS_Points/numSS_it + 1 (=13)
+        for (int l = wave; l < p.L; l += NW) {
+            const double *base = p.sstore + (size_t)p.sslot[l] * LMPC_COLS * p.lap_stride;
+            const int T = p.sslen[l], ls = p.lap_stride;
+            double best = INFINITY; int bi = 0x7fffffff;
+            for (int r = lane; r < T; r += WAVE) {
+                double nrm = fabs(base[r] - ztv[0]);                            // la.norm(x - zt, 1, axis=1)
+                nrm = nrm + fabs(base[ls + r] - ztv[1]);
+                nrm = nrm + fabs(base[2 * ls + r] - ztv[2]);
+                nrm = nrm + fabs(base[3 * ls + r] - ztv[3]);
+                nrm = nrm + fabs(base[4 * ls + r] - ztv[4]);
+                nrm = nrm + fabs(base[5 * ls + r] - ztv[5]);
+                if (nrm < best) { best = nrm; bi = r; }
+            }
+            wave_argmin(best, bi);                                              // np.argmin: first minimum
+            const int MinNorm = bi;
+            const int start = ((double)MinNorm - (double)npw / 2.0 >= 0.0) ? MinNorm - npw / 2 : MinNorm;   // :492-495
+            if (lane == 0) { sel_start[l] = start; if (start + npw > T) atomicOr(st_sh, LMPC_ST_WINDOW); }
+            double shift = 0.0;                                                 // :502-512
+            if (hasPred && crossed > 0) {
+                if (p.sslapid[l] < p.cur_it - 1) shift = base[8 * ls];
+                else shift = (double)tstep + (double)(N - crossed);
+            }
+            if (lane < ppl) {
+                int r0 = start + lane; r0 = r0 > T - 1 ? T - 1 : r0;
+                int r1 = start + lane + 1; r1 = r1 > T - 1 ? T - 1 : r1;
+                const int col = l * ppl + lane;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const double v = base[j * ls + r0];
+                    SS[j * S + col] = v;
+                    if (io.ssSelOut) io.ssSelOut[((size_t)b * S + col) * 6 + j] = v;
+                    if (io.succOut) io.succOut[((size_t)b * S + col) * 6 + j] = base[j * ls + r1];
+                }
+                if (io.succUOut) { io.succUOut[((size_t)b * S + col) * 2] = base[6 * ls + r1]; io.succUOut[((size_t)b * S + col) * 2 + 1] = base[7 * ls + r1]; }
+                const double qv = base[8 * ls + r0] + shift;
+                Qsel[col] = qv;
+                if (io.qSelOut) io.qSelOut[(size_t)b * S + col] = qv;
+            }
+        }
+    } else {
+        for (int c = wave * WAVE + lane; c < S; c += NW * WAVE) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) SS[j * S + c] = io.ssSelIn[((size_t)b * S + c) * 6 + j];
+            Qsel[c] = io.qSelIn[(size_t)b * S + c];
+        }
+    }
+}
+
 template <int N, int S, bool EQ = false>
 __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
     extern __shared__ double sm[];
@@ -749,77 +828,9 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     __syncthreads();
     const double a_s = par[PAR_AS], c_s = par[PAR_CS];
 
-    // ------------------------------------------------------------------------------------------------
-    // K2: safe-set selection.  LMPC.addTerminalComponents :392-412 and selectPoints :478-514.
-    // ------------------------------------------------------------------------------------------------
-    if constexpr (term) {
-        if (io.mode & 1) {
-            double ztv[6];
-#pragma unroll
-            for (int j = 0; j < 6; j++) ztv[j] = io.zt[(size_t)b * 6 + j];
-            const double x04 = io.x0[(size_t)b * 6 + 4];
-            if (ztv[4] - x04 > p.TL / 2) ztv[4] = fmax(ztv[4] - p.TL, 0.0);        // :392-393
-            if (io.ztUsed && lane < 6) { double v = ztv[0];
-#pragma unroll
-                for (int j = 1; j < 6; j++) if (lane == j) v = ztv[j];
-                io.ztUsed[(size_t)b * 6 + lane] = v; }
-            const int hasPred = io.hasPred ? io.hasPred[b] : 0;                     // Q-function shift bookkeeping (:502-512)
-            int crossed = 0;
-            if (hasPred) {
-                int c_ = 0;
-                if (lane <= N) c_ = (io.xPredPrev[((size_t)b * (N + 1) + lane) * 6 + 4] > p.TL) ? 1 : 0;
-                crossed = (int)__popcll(__ballot(c_));
-            }
-            const int tstep = io.timeStep ? io.timeStep[b] : 0;
-            const int ppl = p.ppl, npw = ppl + 1;                                   // numSS_Points/numSS_it + 1 (=13)
-            for (int l = 0; l < p.L; l++) {
-                const double *base = p.sstore + (size_t)p.sslot[l] * LMPC_COLS * p.lap_stride;
-                const int T = p.sslen[l], ls = p.lap_stride;
-                double best = INFINITY; int bi = 0x7fffffff;
-                for (int r = lane; r < T; r += WAVE) {
-                    double nrm = fabs(base[r] - ztv[0]);                            // la.norm(x - zt, 1, axis=1)
-                    nrm = nrm + fabs(base[ls + r] - ztv[1]);
-                    nrm = nrm + fabs(base[2 * ls + r] - ztv[2]);
-                    nrm = nrm + fabs(base[3 * ls + r] - ztv[3]);
-                    nrm = nrm + fabs(base[4 * ls + r] - ztv[4]);
-                    nrm = nrm + fabs(base[5 * ls + r] - ztv[5]);
-                    if (nrm < best) { best = nrm; bi = r; }
-                }
-                wave_argmin(best, bi);                                              // np.argmin: first minimum
-                const int MinNorm = bi;
-                const int start = ((double)MinNorm - (double)npw / 2.0 >= 0.0) ? MinNorm - npw / 2 : MinNorm;   // :492-495
-                if (lane == 0) { sel_start[l] = start; if (start + npw > T) atomicOr(&st_sh, LMPC_ST_WINDOW); }
-                double shift = 0.0;                                                 // :502-512
-                if (hasPred && crossed > 0) {
-                    if (p.sslapid[l] < p.cur_it - 1) shift = base[8 * ls];
-                    else shift = (double)tstep + (double)(N - crossed);
-                }
-                if (lane < ppl) {
-                    int r0 = start + lane; r0 = r0 > T - 1 ? T - 1 : r0;
-                    int r1 = start + lane + 1; r1 = r1 > T - 1 ? T - 1 : r1;
-                    const int col = l * ppl + lane;
-#pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        const double v = base[j * ls + r0];
-                        SS[j * S + col] = v;
-                        if (io.ssSelOut) io.ssSelOut[((size_t)b * S + col) * 6 + j] = v;
-                        if (io.succOut) io.succOut[((size_t)b * S + col) * 6 + j] = base[j * ls + r1];
-                    }
-                    if (io.succUOut) { io.succUOut[((size_t)b * S + col) * 2] = base[6 * ls + r1]; io.succUOut[((size_t)b * S + col) * 2 + 1] = base[7 * ls + r1]; }
-                    const double qv = base[8 * ls + r0] + shift;
-                    Qsel[col] = qv;
-                    if (io.qSelOut) io.qSelOut[(size_t)b * S + col] = qv;
-                }
-            }
-        } else {
-            FOR_LANES(c, S) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) SS[j * S + c] = io.ssSelIn[((size_t)b * S + c) * 6 + j];
-                Qsel[c] = io.qSelIn[(size_t)b * S + c];
-            }
-        }
-        __syncthreads();
-    }
+    // K2: safe-set selection (k2_select), then the regression status bits of this problem's N points
+    if constexpr (term) { k2_select<N, S, 1>(p, io, b, lane, 0, SS, Qsel, sel_start, &st_sh); __syncthreads(); }
+    if (io.rstatus && lane < N) { const int rs_ = io.rstatus[(size_t)b * N + lane]; if (rs_) atomicOr(&st_sh, rs_); }
     TSTAMP(1);
     if (!(io.mode & 2)) { if (lane == 0) io.status[b] = st_sh; return; }
 
@@ -1459,7 +1470,9 @@ __global__ void lmpc_rollout_plant_kernel(lmpc_dev_params p, int B, int t, lmpc_
     plant_step_pair(p, x, xg, u0, r.noise + ((size_t)t * B + b) * 3, xo, go, &bad, role);
     if (role == 0) {
         for (int j = 0; j < 6; j++) { x[j] = xo[j]; xg[j] = go[j]; }
-        r.statusAcc[b] |= r.status[b] | (bad ? LMPC_ST_NO_SEGMENT : 0);
+        // status bits count only up to and including the step that crosses the line: a finished car keeps being simulated until
+        // the slowest rollout ends, and whatever happens to it there (window past the lap end, ...) does not belong to its lap
+        if (r.doneAt[b] < 0) r.statusAcc[b] |= r.status[b] | (bad ? LMPC_ST_NO_SEGMENT : 0);
         if (r.doneAt[b] < 0 && xo[4] > p.TL) {                                                 // lap completed, SysModel.py:45
             r.doneAt[b] = t + 1; atomicAdd(r.nDone, 1);
             for (int j = 0; j < 6; j++) { r.finX[(size_t)b * 6 + j] = xo[j]; r.finG[(size_t)b * 6 + j] = go[j]; }

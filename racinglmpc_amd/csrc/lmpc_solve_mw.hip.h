@@ -65,77 +65,9 @@ __global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params
     auto red_max = [&](int slot) { double r = red[slot * 4]; for (int w = 1; w < NW; w++) r = fmax(r, red[slot * 4 + w]); return r; };
     auto red_min = [&](int slot) { double r = red[slot * 4]; for (int w = 1; w < NW; w++) r = fmin(r, red[slot * 4 + w]); return r; };
 
-    // ------------------------------------------------------------------------------------------------
-    // K2: safe-set selection, one lap per wave.  LMPC.addTerminalComponents :392-412 and selectPoints :478-514.
-    // ------------------------------------------------------------------------------------------------
-    if constexpr (term) {
-        if (io.mode & 1) {
-            double ztv[6];
-#pragma unroll
-            for (int j = 0; j < 6; j++) ztv[j] = io.zt[(size_t)b * 6 + j];
-            const double x04 = io.x0[(size_t)b * 6 + 4];
-            if (ztv[4] - x04 > p.TL / 2) ztv[4] = fmax(ztv[4] - p.TL, 0.0);        // :392-393
-            if (io.ztUsed && tid < 6) { double v = ztv[0];
-#pragma unroll
-                for (int j = 1; j < 6; j++) if (tid == j) v = ztv[j];
-                io.ztUsed[(size_t)b * 6 + tid] = v; }
-            const int hasPred = io.hasPred ? io.hasPred[b] : 0;                     // Q-function shift bookkeeping (:502-512)
-            int crossed = 0;
-            if (hasPred) {
-                int c_ = 0;
-                if (lane <= N) c_ = (io.xPredPrev[((size_t)b * (N + 1) + lane) * 6 + 4] > p.TL) ? 1 : 0;
-                crossed = (int)__popcll(__ballot(c_));
-            }
-            const int tstep = io.timeStep ? io.timeStep[b] : 0;
-            const int ppl = p.ppl, npw = ppl + 1;                                   // numSS_Points/numSS_it + 1 (=13)
-            for (int l = wave; l < p.L; l += NW) {
-                const double *base = p.sstore + (size_t)p.sslot[l] * LMPC_COLS * p.lap_stride;
-                const int T = p.sslen[l], ls = p.lap_stride;
-                double best = INFINITY; int bi = 0x7fffffff;
-                for (int r = lane; r < T; r += WAVE) {
-                    double nrm = fabs(base[r] - ztv[0]);                            // la.norm(x - zt, 1, axis=1)
-                    nrm = nrm + fabs(base[ls + r] - ztv[1]);
-                    nrm = nrm + fabs(base[2 * ls + r] - ztv[2]);
-                    nrm = nrm + fabs(base[3 * ls + r] - ztv[3]);
-                    nrm = nrm + fabs(base[4 * ls + r] - ztv[4]);
-                    nrm = nrm + fabs(base[5 * ls + r] - ztv[5]);
-                    if (nrm < best) { best = nrm; bi = r; }
-                }
-                wave_argmin(best, bi);                                              // np.argmin: first minimum
-                const int MinNorm = bi;
-                const int start = ((double)MinNorm - (double)npw / 2.0 >= 0.0) ? MinNorm - npw / 2 : MinNorm;   // :492-495
-                if (lane == 0) { sel_start[l] = start; if (start + npw > T) atomicOr(&st_sh, LMPC_ST_WINDOW); }
-                double shift = 0.0;                                                 // :502-512
-                if (hasPred && crossed > 0) {
-                    if (p.sslapid[l] < p.cur_it - 1) shift = base[8 * ls];
-                    else shift = (double)tstep + (double)(N - crossed);
-                }
-                if (lane < ppl) {
-                    int r0 = start + lane; r0 = r0 > T - 1 ? T - 1 : r0;
-                    int r1 = start + lane + 1; r1 = r1 > T - 1 ? T - 1 : r1;
-                    const int col = l * ppl + lane;
-#pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        const double v = base[j * ls + r0];
-                        SS[j * S + col] = v;
-                        if (io.ssSelOut) io.ssSelOut[((size_t)b * S + col) * 6 + j] = v;
-                        if (io.succOut) io.succOut[((size_t)b * S + col) * 6 + j] = base[j * ls + r1];
-                    }
-                    if (io.succUOut) { io.succUOut[((size_t)b * S + col) * 2] = base[6 * ls + r1]; io.succUOut[((size_t)b * S + col) * 2 + 1] = base[7 * ls + r1]; }
-                    const double qv = base[8 * ls + r0] + shift;
-                    Qsel[col] = qv;
-                    if (io.qSelOut) io.qSelOut[(size_t)b * S + col] = qv;
-                }
-            }
-        } else {
-            for (int c = tid; c < S; c += NT) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) SS[j * S + c] = io.ssSelIn[((size_t)b * S + c) * 6 + j];
-                Qsel[c] = io.qSelIn[(size_t)b * S + c];
-            }
-        }
-        __syncthreads();
-    }
+    // K2: safe-set selection, one lap per wave (k2_select, lmpc_kernels.hip.h), then the regression status bits of this problem
+    if constexpr (term) { k2_select<N, S, NW>(p, io, b, lane, wave, SS, Qsel, sel_start, &st_sh); __syncthreads(); }
+    if (io.rstatus && tid < N) { const int rs_ = io.rstatus[(size_t)b * N + tid]; if (rs_) atomicOr(&st_sh, rs_); }
     if (!(io.mode & 2)) { if (tid == 0) io.status[b] = st_sh; return; }
 
     // ------------------------------------------------------------------------------------------------

@@ -232,6 +232,10 @@ def main():
     out["all_status"] = np.array([r["status"] for r in records]); out["all_iters"] = np.array([r["iters"] for r in records])
     out["all_polish"] = np.array([r["polish"] for r in records])
     out["all_xPred"] = np.array([r["xPred"] for r in records]); out["all_uPred"] = np.array([r["uPred"] for r in records])
+    # controller inputs of EVERY step (the rec_* records are a sample): lets a test re-run all closed-loop steps through the
+    # HIP path and compare with the answer the reference flow produced at its own solver settings
+    for k in ("t", "xLin", "uLin", "OldInput", "zt", "hasPred", "xPredPrev", "ztNext", "ztuNext", "Qsel", "sol", "y"):
+        out["all_" + k] = np.array([r[k] for r in records])
     kept = [r for r in records if r["keep"]]
     for k in kept[0].keys():
         if k == "keep":

@@ -1,0 +1,236 @@
+"""-m gpu: solver-independent checks on EVERY problem of the batches that carry the headline numbers.
+
+* full-batch KKT certificate (tests/kkt_batch.py) for the bench batch and for batch sizes that route to each of the three solve
+  kernels (4 waves per QP, 2 waves per QP, 1 wave per QP), for the 30-lap / N = 40 / N = 14 configurations;
+* the "reference-solver ball": all 444 closed-loop steps the reference flow took in the fixture are re-run through the HIP path
+  and compared with the answer that flow produced at the reference's own OSQP settings (restated OSQP, parity with the real
+  osqp binary unpinned -- see oracle/README.md);
+* K1 prefilter slack: a lap constructed so that a row of the exact top-7 sits at integer distance T + 9;
+* regression status bits on the device-resident paths.
+"""
+import numpy as np
+import pytest
+
+from tests import common, kkt_batch, k1_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx_pid(g, N, B, **kw):
+    from racinglmpc_amd import _capi
+    from oracle import lmpc_oracle as orc
+    cfg, _ = common.lmpc_config(g, N, max_batch=B, **kw)
+    ctx = _capi.Context(cfg)
+    for _ in range(4):
+        ctx.model_add_trajectory(g["xPID"], g["uPID"]); ctx.ss_add_trajectory(g["xPID"], g["uPID"])
+    return ctx, orc.QPParams.lmpc_default(N)
+
+
+def _certify(par, out, inp, tol=common.TOL_KKT, what=""):
+    ok = (out["status"] & ~64) == 0                      # LMPC_ST_INEXACT solutions are certified too
+    assert np.all(ok), np.unique(out["status"], return_counts=True)
+    c = kkt_batch.certificate(par, out["A"], out["B"], out["C"], inp["x0"], inp["uOld"], out["xPred"], out["uPred"], out["slack"], out["mu"],
+                              ssSel=out["ssSel"], qSel=out["qSel"], lambd=out["lambd"], sTerm=out["sTerm"])
+    worst = kkt_batch.assert_certified(c, tol, what)
+    print("%s: KKT certificate over all %d problems: worst %.2e (stat %.1e prim %.1e comp %.1e)" % (
+        what, c["worst"].size, worst, (c["stat"] / c["scale"]).max(), max(c["prim_eq"].max(), c["prim_ineq"].max()), (c["comp"] / c["scale"]).max()))
+    return c
+
+
+@pytest.mark.parametrize("B", [1, 256, 512, 2048, 8192])
+def test_bench_batch_certificate_all_kernels(built, B):
+    """bench.synth_batch (the driver-timed inputs at B = 256, seed 1234) and the sweep's larger batches: every problem certified.
+    B <= 256 runs lmpc_solve_kernel_mw<.,.,4>, 512 the two-wave variant, >= 1024 the one-wave kernel lmpc_solve_kernel."""
+    import bench
+    g = common.load_lmpc_golden()
+    ctx, par = _ctx_pid(g, 12, B)
+    inp = bench.synth_batch(g, B, 12, seed=1234)
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    assert np.all(out["status"] == 0), np.unique(out["status"], return_counts=True)
+    _certify(par, out, inp, what="bench batch B=%d (%d wave(s) per QP)" % (B, ctx.solver_waves(B)))
+    if B == 256:                                         # and the oracle's optimum on a sample of the exact bench inputs
+        from tests.test_gpu_configs import oracle_step
+        worst = 0.0
+        for b in (0, 17, 101, 255):
+            A, Bm, C, SSsel, opt, cert, _ = oracle_step(par, np.array(g["track"]), float(g["trackLength"]), [(g["xPID"], g["uPID"])] * 4,
+                                                        [(g["xPID"], g["uPID"])] * 4, 12, inp["x0"][b], inp["xLin"][b], inp["uLin"][b], inp["uOld"][b],
+                                                        inp["zt"][b], int(inp["timeStep"][b]))
+            assert np.array_equal(out["ssSel"][b], SSsel.T)
+            worst = max(worst, np.abs(np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()]) - opt[:102]).max())
+        print("bench batch: worst |xu - oracle optimum| on the sample %.2e" % worst)
+        assert worst < common.TOL_XU
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,B", [(40, 1024), (14, 256), (14, 2048), (20, 300), (8, 64), (8, 1500)])
+def test_other_horizons_certificate(built, N, B):
+    """BASELINE config 'N=40, batch=1024' and the other built horizons, every problem certified (N = 40 always runs four waves per QP,
+    the others the kernel their batch size selects)."""
+    g = common.load_lmpc_golden()
+    ctx, par = _ctx_pid(g, N, B)
+    xP, uP = g["xPID"], g["uPID"]
+    tb = (37 * np.arange(B)) % 900
+    rng = np.random.default_rng(1234)
+    inp = dict(x0=xP[tb] + rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02]),
+               xLin=np.stack([xP[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uP[t + 1:t + N + 1] for t in tb]),
+               uOld=uP[tb].copy(), zt=xP[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    _certify(par, out, inp, what="N=%d B=%d (%d wave(s) per QP)" % (N, B, ctx.solver_waves(B)))
+    ctx.close()
+
+
+def test_batch4096_30_laps_certificate(built):
+    """BASELINE config 'batch=4096, safe set from 30 laps': all 4096 problems certified (the sampled oracle comparison lives in
+    test_gpu_configs.py)."""
+    from racinglmpc_amd import _capi
+    from tests.test_gpu_configs import pid_laps_batched
+    g = common.load_lmpc_golden()
+    N, B = 12, 4096
+    laps = pid_laps_batched(np.array(g["track"]), 30)
+    cfg, par = common.lmpc_config(g, N, max_batch=B, max_laps=40, max_lap_len=1024)
+    ctx = _capi.Context(cfg)
+    for x, u in laps:
+        ctx.model_add_trajectory(x, u); ctx.ss_add_trajectory(x, u)
+    xq, uq = laps[29]
+    tb = (37 * np.arange(B)) % (xq.shape[0] - 40 - N - 2)
+    rng = np.random.default_rng(1234)
+    inp = dict(x0=xq[tb] + rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02]),
+               xLin=np.stack([xq[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uq[t + 1:t + N + 1] for t in tb]),
+               uOld=uq[tb].copy(), zt=xq[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    assert np.all(out["status"] == 0)
+    _certify(par, out, inp, what="B=4096 / 30 laps")
+    ctx.close()
+
+
+def test_inexact_and_perturbed_batches_certificate(built):
+    """5x the bench's state noise (the regime that produces LMPC_ST_INEXACT): every returned solution, flagged or not, carries
+    a certificate <= 1e-7."""
+    g = common.load_lmpc_golden()
+    N, B = 12, 8192
+    ctx, par = _ctx_pid(g, N, B)
+    xP, uP = g["xPID"], g["uPID"]
+    rng = np.random.default_rng(3)
+    tb = rng.integers(0, 900, size=B)
+    inp = dict(x0=xP[tb] + rng.normal(size=(B, 6)) * np.array([.1, .05, .1, .05, 0.0, .08]) * 2.5,
+               xLin=np.stack([xP[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uP[t + 1:t + N + 1] for t in tb]),
+               uOld=uP[tb].copy(), zt=xP[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    print("perturbed batch: status histogram", dict(zip(*[a.tolist() for a in np.unique(out["status"], return_counts=True)])))
+    _certify(par, out, inp, what="perturbed B=8192")
+    ctx.close()
+
+
+def test_reference_solver_ball_all_444_steps(built):
+    """Every closed-loop step of the two LMPC laps the reference flow drove in the fixture (make_golden.py), inputs exactly as
+    that flow had them (all_* fields), re-run through lmpc_step_batch with the store replayed step by step; the flow's own answer
+    (all_sol / all_y: primal and dual of the solver it ran at the reference's settings, eps = 1e-3 + polish) is classified by ITS
+    solver-independent KKT certificate on the GPU-side problem data:
+      * certified answers (<= 1e-7; the polish found the optimum): |GPU - recorded| <= 1e-6 on x and u;
+      * the rest (the polish failed, or 'succeeded' on a wrong active set): the recorded point is OSQP's eps-accurate iterate --
+        its certificate must sit at OSQP's termination level (<= 2e-2), it must respect dynamics, initial state and the input
+        box within eps_abs + eps_rel * scale, and the GPU optimum must lie in a bounded neighbourhood; the distribution is printed.
+    The recorded answers come from the RESTATED OSQP (oracle/osqp_restated.c; the real osqp binary cannot be installed here), so
+    this pins the HIP path to the reference flow at its stated solver settings, not to the osqp binary itself."""
+    from oracle import lmpc_oracle as orc
+    g = common.load_lmpc_golden()
+    par = orc.QPParams.lmpc_default(12)
+    tot = 0; d_cert, d_ball, c_ball, pol_cert = [], [], [], []
+    for lap in (4, 5):
+        ctx, _ = common.make_lmpc_ctx(g, lap, max_batch=4)
+        steps = np.where(g["all_lap"] == lap)[0]
+        for gi in steps:
+            out = ctx.step_batch(g["all_x0"][gi][None], g["all_xLin"][gi][None], g["all_uLin"][gi][None], g["all_OldInput"][gi][None],
+                                 zt=g["all_zt"][gi][None], xPredPrev=g["all_xPredPrev"][gi][None], hasPred=np.array([g["all_hasPred"][gi]]),
+                                 timeStep=np.array([g["all_t"][gi]]))
+            assert (out["status"][0] & ~64) == 0, (gi, out["status"][0])
+            assert np.array_equal(out["qSel"][0], g["all_Qsel"][gi])                 # same selection as the reference at every step
+            z, y = g["all_sol"][gi], g["all_y"][gi]
+            xr, ur = z[:78].reshape(1, 13, 6), z[78:102].reshape(1, 12, 2)
+            assert np.array_equal(xr[0], g["all_xPred"][gi]) and np.array_equal(ur[0], g["all_uPred"][gi])
+            crec = kkt_batch.certificate(par, out["A"], out["B"], out["C"], g["all_x0"][gi][None], g["all_OldInput"][gi][None], xr, ur, z[None, 102:126],
+                                         np.maximum(y[None, :144], 0.0), ssSel=out["ssSel"], qSel=out["qSel"], lambd=z[None, 126:174], sTerm=z[None, 174:180])["worst"][0]
+            d = max(np.abs(out["xPred"][0] - xr[0]).max(), np.abs(out["uPred"][0] - ur[0]).max())
+            if crec <= 1e-7:
+                d_cert.append(d); pol_cert.append(int(g["all_polish"][gi]))
+                assert d <= common.TOL_XU, (gi, d, crec)
+            else:
+                d_ball.append(d); c_ball.append(crec)
+                eps = 1e-3 + 1e-3 * max(np.abs(xr).max(), 1.0)                       # eps_abs + eps_rel * ||.||_inf, OSQP defaults
+                dyn = np.einsum("kij,kj->ki", out["A"][0], xr[0, :-1]) + np.einsum("kij,kj->ki", out["B"][0], ur[0]) + out["C"][0] - xr[0, 1:]
+                assert max(np.abs(dyn).max(), np.abs(xr[0, 0] - g["all_x0"][gi]).max()) <= eps, gi
+                assert np.abs(ur[0, :, 0]).max() <= 0.5 + eps and np.abs(ur[0, :, 1]).max() <= 10 + eps
+            ctx.ss_add_point(g["all_x0"][gi], g["all_u0"][gi])
+            tot += 1
+        ctx.close()
+    d_cert, d_ball, c_ball = np.array(d_cert), np.array(d_ball), np.array(c_ball)
+    print("reference-solver ball over %d steps: recorded answer certified (<= 1e-7) on %d steps (all with polish status 1: %s): |GPU - recorded| "
+          "max %.2e median %.2e; uncertified %d steps (recorded certificate median %.1e max %.1e): distance to the GPU optimum max %.3f / p90 %.3f / "
+          "median %.3f" % (tot, d_cert.size, all(p == 1 for p in pol_cert), d_cert.max(), np.median(d_cert), d_ball.size, np.median(c_ball), c_ball.max(),
+                           d_ball.max(), np.quantile(d_ball, 0.9), np.median(d_ball)))
+    assert tot == 444 and d_cert.size >= 100 and d_cert.size + d_ball.size == 444
+    assert c_ball.max() <= 2e-2 and d_ball.max() <= 0.5        # eps_abs + eps_rel * (norms of a few units)
+
+
+def test_k1_prefilter_keeps_row_at_T_plus_9(built, monkeypatch):
+    """K1's integer prefilter: a lap constructed (tests/k1_cases.py) so that a row of the exact 7 nearest has integer distance
+    T + 9 (T = the prefilter's 7th smallest distinct lane minimum) -- the extreme the two-sided quantisation bound allows.  With a
+    slack below 9 the row is dropped and another one is selected; the regression output then differs from the oracle's."""
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    g = common.load_lmpc_golden()
+    case = k1_cases.slack_case()
+    emu = k1_cases.emulate_prefilter(case)
+    assert emu["e"][case["victim"]] == emu["T"] + 9 and case["victim"] in emu["exact_top"] and case["decoys"][6] not in emu["exact_top"]
+    N, B = 12, 2
+    cfg, par = common.lmpc_config(g, N, max_batch=B, max_lap_len=2048)
+    cfg.trToUse = 1; cfg.h = case["h"]; cfg.lamb = 0.0; cfg.maxNumPoint = 7
+    for i in range(5):
+        cfg.scaling[i] = 1.0
+    monkeypatch.setattr(orc, "H_BAND", case["h"]); monkeypatch.setattr(orc, "SCALING", np.ones(5))
+    ctx = _capi.Context(cfg)
+    ctx.model_add_trajectory(case["x"], case["u"])
+    xLin = np.tile(case["xq"][None, None], (B, N + 1, 1)); uLin = np.tile(case["uq"][None, None], (B, N, 1))
+    A, Bm, C, st = ctx.regress_batch(xLin, uLin)
+    assert np.all(st == 0), st
+    Ai, Bi, Ci = orc.regression_and_linearization([case["x"]], [case["u"]], [0], np.array(g["track"]), case["xq"], case["uq"])
+    worst = 0.0
+    for got, ref in ((A[0, 0], Ai), (Bm[0, 0], Bi), (C[0, 0], Ci)):
+        worst = max(worst, (np.abs(got - ref) / (1.0 + np.abs(ref))).max())
+    # what dropping the T + 9 row would give (selection = decoys 0..6): far away from the oracle
+    alt = k1_cases.fit_with_rows(case, case["decoys"])
+    print("K1 T+9 row: worst rel err vs oracle %.2e; the wrong selection would differ by %.2e" % (worst, np.abs(alt - Ai[0:3, 0:3]).max()))
+    assert np.abs(alt - Ai[0:3, 0:3]).max() > 1e-3
+    assert worst < 1e-5                      # 7 points, 5 unknowns, cond(M'KM) ~ 1e9: rounding alone reaches 1e-7
+    ctx.close()
+
+
+def test_regression_status_reaches_device_paths(built):
+    """An off-track linearisation point (the reference raises in Map.curvature, Track.py:307) must mark status[b] on the
+    device-resident step and in a device-resident rollout, not only in lmpc_step_batch."""
+    from racinglmpc_amd import _capi
+    import bench
+    g = common.load_lmpc_golden()
+    N, B = 12, 64
+    ctx, par = _ctx_pid(g, N, B)
+    inp = bench.synth_batch(g, B, N, seed=5)
+    inp["xLin"][7, 3, 4] = -1.0                                    # s < 0 at horizon point 3 of problem 7
+    a, keep = ctx.step_dev_buffers(inp)
+    ctx.step_batch_dev(B, a)
+    out = ctx.step_dev_fetch(a, B)
+    assert out["status"][7] & _capi.ST_NO_SEGMENT
+    assert np.all(np.delete(out["status"], 7) == 0)
+    host = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    assert np.array_equal(host["status"], out["status"])
+    for p in keep:
+        ctx.dev_free(p)
+    # rollout: rollout 3 starts with an off-track linearisation trajectory; its lap carries the bit, the others do not
+    R = 16
+    x0 = np.tile(g["xPID"][0], (R, 1)); xl = np.tile(g["xPID"][1:N + 2][None], (R, 1, 1)); ul = np.tile(g["uPID"][1:N + 1][None], (R, 1, 1))
+    xl[3, 5, 4] = -2.0
+    ctx.rollout_begin(x0, x0, xl, ul, np.zeros((4, R, 3)))
+    t, nd = ctx.rollout_run(2)
+    X, U, G, done, st, fx, fg = ctx.rollout_fetch(0, t)
+    ctx.rollout_end()
+    assert st[3] & _capi.ST_NO_SEGMENT and np.all(np.delete(st, 3) == 0), st
+    ctx.close()

@@ -1,0 +1,58 @@
+"""CPU checks of the test infrastructure itself: the vectorised KKT certificate against the dense oracle certificate on the
+reference-produced fixture, and the construction of the K1 prefilter edge case."""
+import numpy as np
+
+from tests import common, k1_cases, kkt_batch
+
+
+def _split(z, N=12, S=48):
+    x = z[:, :6 * (N + 1)].reshape(-1, N + 1, 6); o = 6 * (N + 1)
+    u = z[:, o:o + 2 * N].reshape(-1, N, 2); o += 2 * N
+    s = z[:, o:o + 2 * N]; o += 2 * N
+    return x, u, s, z[:, o:o + S], z[:, o + S:o + S + 6]
+
+
+def test_batch_certificate_agrees_with_dense_oracle_certificate():
+    """On the 60 recorded QPs: the certified optimum passes the banded certificate at the level of the dense one, and a
+    1e-5 perturbation of one input is caught."""
+    from oracle import lmpc_oracle as orc
+    g = common.load_lmpc_golden()
+    par = orc.QPParams.lmpc_default(12)
+    x, u, s, lam, sT = _split(g["rec_sol_opt"])
+    mu = g["rec_y_opt"][:, :144]
+    ss = np.transpose(g["rec_SSsel"], (0, 2, 1))
+    c = kkt_batch.certificate(par, g["rec_A"], g["rec_B"], g["rec_C"], g["rec_x0"], g["rec_OldInput"], x, u, s, mu, ssSel=ss, qSel=g["rec_Qsel"], lambd=lam, sTerm=sT)
+    assert c["worst"].max() < 1e-8 and c["worst"].max() <= 10 * max(g["rec_cert_opt"].max(), 1e-10)
+    u2 = u.copy(); u2[:, 3, 0] += 1e-5
+    c2 = kkt_batch.certificate(par, g["rec_A"], g["rec_B"], g["rec_C"], g["rec_x0"], g["rec_OldInput"], x, u2, s, mu, ssSel=ss, qSel=g["rec_Qsel"], lambd=lam, sTerm=sT)
+    assert c2["worst"].min() > 1e-6
+    # the reference flow's eps = 1e-3 answers (polish failed) do not pass, its polished answers do
+    xr, ur, sr, lr, tr = _split(g["rec_sol"])
+    c3 = kkt_batch.certificate(par, g["rec_A"], g["rec_B"], g["rec_C"], g["rec_x0"], g["rec_OldInput"], xr, ur, sr, np.maximum(g["rec_y"][:, :144], 0.0),
+                               ssSel=ss, qSel=g["rec_Qsel"], lambd=lr, sTerm=tr)
+    ok = g["rec_polish"] == 1
+    assert c3["worst"][ok].max() < 1e-6 and c3["worst"][~ok].min() > 1e-6
+
+
+def test_batch_certificate_plain_mpc():
+    from oracle import lmpc_oracle as orc
+    gl = common.load_ltv_golden()
+    par = orc.QPParams.mpc_default(12, 0.8)
+    z, y = gl["sol_opt"], gl["y_opt"]
+    x = z[:, :78].reshape(-1, 13, 6); u = z[:, 78:102].reshape(-1, 12, 2); s = z[:, 102:126]
+    c = kkt_batch.certificate(par, gl["A"], gl["B"], gl["C"], gl["x0"], gl["OldInput"], x, u, s, y[:, :96])
+    assert c["worst"].max() < 1e-8
+
+
+def test_k1_slack_case_construction(monkeypatch):
+    """The constructed lap really puts a row of the exact top 7 at integer distance T + 9 (so a prefilter slack of 8 drops it)."""
+    from oracle import lmpc_oracle as orc
+    case = k1_cases.slack_case()
+    emu = k1_cases.emulate_prefilter(case)
+    assert emu["T"] == case["E0"] + 6
+    assert emu["e"][case["victim"]] == emu["T"] + 9
+    assert [int(emu["e"][r]) for r in case["decoys"]] == [case["E0"] + i for i in range(7)]
+    monkeypatch.setattr(orc, "H_BAND", case["h"]); monkeypatch.setattr(orc, "SCALING", np.ones(5))
+    idx, K = orc.compute_indices(case["x"], case["u"], np.hstack([case["xq"][:3], case["uq"]]))
+    assert sorted(idx) == sorted(case["decoys"][:6] + [case["victim"]])
+    assert sorted(idx) == sorted(emu["exact_top"])
