@@ -165,6 +165,25 @@ int lmpc_rollout_end(lmpc_ctx *);
         /* Simulator.sim with one LMPC controller per rollout, SysModel.py:22-54, state resident on the device */
 int lmpc_ss_extend_lap(lmpc_ctx *, int lap, const double *x /*n x 6*/, const double *u /*n x 2*/, int n);
         /* LMPC.addPoint (:466-474) applied to any stored lap: n points appended with s + TrackLength, Qfun counting down */
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI.  The QPs / rollouts of a batch are independent given the
+ * read-only safe set, so the data path has no collective; the ONE exchange is per lap.  The reference has no counterpart (single
+ * process); what is exchanged are the arguments of LMPC.addTrajectory / PredictiveModel.addTrajectory (:418-445, PredictiveModel.py:35-46).
+ * The 128-byte id is created on rank 0 and handed to the other processes by the caller (racinglmpc_amd/parallel.py). */
+#define LMPC_COMM_ID_BYTES 128
+int lmpc_comm_unique_id(unsigned char *id /*LMPC_COMM_ID_BYTES*/);                       /* ncclGetUniqueId */
+int lmpc_comm_init(lmpc_ctx *, const unsigned char *id, int rank, int world);            /* ncclCommInitRank on the ctx's device */
+int lmpc_comm_destroy(lmpc_ctx *);
+int lmpc_comm_info(lmpc_ctx *, int *rank, int *world, int *is_rccl);
+int lmpc_comm_allgather_dev(lmpc_ctx *, const void *send_dev, void *recv_dev /*world x bytes*/, long long bytes);   /* ncclAllGather, async on the ctx stream */
+int lmpc_comm_allgather(lmpc_ctx *, const void *send_host, void *recv_host /*world x bytes*/, long long bytes);     /* same for small host-side control data */
+int lmpc_comm_allreduce_max(lmpc_ctx *, double *v /*n, in/out, host*/, int n);
+int lmpc_comm_barrier(lmpc_ctx *);                                                       /* stream drained on every rank */
+int lmpc_rollout_exchange(lmpc_ctx *, int K, int T_max, double *records /*world x K x (T_max+1) x 14*/, long long *lens /*world x K, -1 = empty*/,
+                          int *n_valid_local);
+        /* per-lap exchange of the current rollout session: the rank's K fastest valid laps (finished, <= T_max steps, status clean) are
+         * packed on the device from the session logs -- rows t < T: x_t | u_t | x_glob_t, row T_max: state and global state right after the
+         * finish line, rollout index -- and all-gathered; every rank receives the same world x K records */
+
 int lmpc_selftest(lmpc_ctx *);                   /* device self test of the cross-lane reduction primitives */
 /* Developer switch (environment, read at lmpc_create): LMPC_MW_MAX_BATCH=<n> overrides the largest batch that runs four waves per
  * QP (default: the number of CUs; 0 forces the one-wave kernel everywhere).  Results do not depend on it beyond summation order. */

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "liblmpc_hip.so")
 
 MAX_TRACK_ROWS = 16
 MAX_USED_LAPS = 8
+COMM_ID_BYTES = 128
 
 ST_MAXITER, ST_REG_SINGULAR, ST_NO_SEGMENT, ST_WINDOW, ST_NUMERIC, ST_NOT_INTERIOR, ST_INEXACT = 1, 2, 4, 8, 16, 32, 64
 
@@ -47,6 +48,8 @@ EXPORTS = [
     "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun",
     "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
+    "lmpc_comm_unique_id", "lmpc_comm_init", "lmpc_comm_destroy", "lmpc_comm_info", "lmpc_comm_allgather_dev", "lmpc_comm_allgather",
+    "lmpc_comm_allreduce_max", "lmpc_comm_barrier", "lmpc_rollout_exchange",
     "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_solver_waves", "lmpc_plant_step_batch", "lmpc_global_position_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap",
 ]
 
@@ -70,6 +73,13 @@ def load():
         lib.lmpc_last_error.restype = C.c_char_p
         _lib = lib
     return _lib
+
+
+def comm_unique_id():
+    """ncclGetUniqueId (call on rank 0, hand the bytes to the other ranks)."""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    _chk(load().lmpc_comm_unique_id(buf))
+    return bytes(buf)
 
 
 def _chk(rc):
@@ -310,12 +320,13 @@ class Context:
         x0 = _f64(x0); xg = _f64(xglob0); xl = _f64(xLin0); ul = _f64(uLin0); nz = _f64(noise)
         B = x0.shape[0]
         assert xl.shape == (B, self.N + 1, 6) and ul.shape == (B, self.N, 2) and nz.shape[1:] == (B, 3)
-        self._ro = (B, nz.shape[0])
+        self._ro = (B, nz.shape[0]); self._ro_t = 0
         _chk(self.lib.lmpc_rollout_begin(self._h, C.c_int(B), C.c_int(nz.shape[0]), _d(x0), _d(xg), _d(xl), _d(ul), _d(nz)))
 
     def rollout_run(self, max_steps):
         t = C.c_int(); nd = C.c_int()
         _chk(self.lib.lmpc_rollout_run(self._h, C.c_int(int(max_steps)), C.byref(t), C.byref(nd)))
+        self._ro_t = t.value                      # simulated steps so far (upper bound for rollout_fetch)
         return t.value, nd.value
 
     def rollout_fetch(self, t0, t1):
@@ -331,6 +342,43 @@ class Context:
     def ss_extend_lap(self, lap, x, u):
         x = _f64(x); u = _f64(u)
         _chk(self.lib.lmpc_ss_extend_lap(self._h, C.c_int(int(lap)), _d(x), _d(u), C.c_int(x.shape[0])))
+
+    # ---- multi-GPU exchange (RCCL behind the C ABI; see parallel.py for the rendezvous)
+    def comm_init(self, id_bytes, rank, world):
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        _chk(self.lib.lmpc_comm_init(self._h, buf, C.c_int(int(rank)), C.c_int(int(world))))
+
+    def comm_destroy(self):
+        _chk(self.lib.lmpc_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, w, f = C.c_int(), C.c_int(), C.c_int()
+        _chk(self.lib.lmpc_comm_info(self._h, C.byref(r), C.byref(w), C.byref(f)))
+        return r.value, w.value, bool(f.value)
+
+    def comm_allgather(self, arr):
+        """Every rank's `arr` (same shape / dtype everywhere), stacked along a new leading axis of length world."""
+        arr = np.ascontiguousarray(arr)
+        world = self.comm_info()[1]
+        out = np.empty((world,) + arr.shape, dtype=arr.dtype)
+        _chk(self.lib.lmpc_comm_allgather(self._h, _d(arr), _d(out), C.c_longlong(arr.nbytes)))
+        return out
+
+    def comm_allreduce_max(self, values):
+        v = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64)))
+        _chk(self.lib.lmpc_comm_allreduce_max(self._h, _d(v), C.c_int(v.shape[0])))
+        return v
+
+    def comm_barrier(self):
+        _chk(self.lib.lmpc_comm_barrier(self._h))
+
+    def rollout_exchange(self, K, T_max):
+        """Per-lap exchange of the current rollout session (device-packed records, one ncclAllGather).
+        Returns (records (world, K, T_max + 1, 14), lens (world, K), number of valid laps on this rank)."""
+        world = self.comm_info()[1]
+        rec = np.zeros((world, K, T_max + 1, 14)); ln = np.zeros((world, K), dtype=np.int64); nv = C.c_int()
+        _chk(self.lib.lmpc_rollout_exchange(self._h, C.c_int(int(K)), C.c_int(int(T_max)), _d(rec), _d(ln), C.byref(nv)))
+        return rec, ln, nv.value
 
     def solver_waves(self, B):
         return int(self.lib.lmpc_solver_waves(self._h, C.c_int(int(B))))

@@ -4,7 +4,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "lmpc_capi.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "lmpc_kernels.hip.h"), os.path.join(_HERE, "csrc", "lmpc_solve_mw.hip.h"), os.path.join(os.path.dirname(_HERE), "include", "lmpc_hip.h")]
+DEPS = [SRC, os.path.join(_HERE, "csrc", "lmpc_kernels.hip.h"), os.path.join(_HERE, "csrc", "lmpc_solve_mw.hip.h"), os.path.join(_HERE, "csrc", "lmpc_comm.hip.h"), os.path.join(os.path.dirname(_HERE), "include", "lmpc_hip.h")]
 OUT = os.path.join(_HERE, "liblmpc_hip.so")
 
 
@@ -12,7 +12,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-unused-value", "-fPIC", "-shared", "-o", OUT, SRC]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-unused-value", "-fPIC", "-shared", "-o", OUT, SRC, "-L/opt/rocm/lib", "-lrccl"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

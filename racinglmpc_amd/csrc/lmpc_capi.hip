@@ -3,6 +3,7 @@
 // lmpc_kernels.hip.h.  No CPU compute path exists here: if HIP fails, the call fails.
 #include "lmpc_kernels.hip.h"
 #include "lmpc_solve_mw.hip.h"
+#include <rccl/rccl.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -41,6 +42,7 @@ struct lmpc_ctx {
     int mw_max_batch, n_cu;
     int profiling; std::vector<evpair> events; lmpc_stats stats;
     struct lmpc_rollout_session *ro;
+    void *comm; int comm_rank, comm_world;   // RCCL communicator of this rank (lmpc_comm.hip.h); null = single process
 };
 
 template <int N, int S> static int solve_launch_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
@@ -171,7 +173,7 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     ARGCHK(cfg->track_rows >= 0 && cfg->track_rows <= LMPC_MAX_TRACK_ROWS);
     ARGCHK(cfg->max_batch >= 1 && cfg->max_laps >= 1 && cfg->max_lap_len >= 8);
     lmpc_ctx *c = new lmpc_ctx();                      // value-initialised: every pointer starts as nullptr, so lmpc_destroy is safe at any point
-    c->cfg = *cfg; c->profiling = 0; c->ro = nullptr;
+    c->cfg = *cfg; c->profiling = 0; c->ro = nullptr; c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
     memset(&c->stats, 0, sizeof(c->stats));
     int rc = create_body(c);
     if (rc != LMPC_OK) { const std::string keep = g_err; lmpc_destroy(c); g_err = keep; return rc; }
@@ -186,6 +188,7 @@ int lmpc_destroy(lmpc_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rollout_free(c);
+    if (c->comm) { (void)ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     void *ptrs[] = {c->mstore, c->sstore, c->mquant, c->mqpar, c->w_x0, c->w_xLin, c->w_uLin, c->w_uOld, c->w_zt, c->w_xPP, c->w_A, c->w_B, c->w_C, c->w_ssSel, c->w_qSel,
                     c->w_succ, c->w_succU, c->w_ztUsed, c->w_xPred, c->w_uPred, c->w_slack, c->w_lam, c->w_sT, c->w_mu, c->w_ztN, c->w_ztuN, c->w_resid,
@@ -769,3 +772,5 @@ int lmpc_get_stats(lmpc_ctx *c, lmpc_stats *out) { ARGCHK(c && out); int rc = dr
 int lmpc_reset_stats(lmpc_ctx *c) { ARGCHK(c); int rc = drain_events(c); if (rc) return rc; memset(&c->stats, 0, sizeof(c->stats)); return LMPC_OK; }
 
 }  // extern "C"
+
+#include "lmpc_comm.hip.h"

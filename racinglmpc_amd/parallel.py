@@ -2,10 +2,20 @@
 
 The QPs / rollouts of a batch are independent given a read-only safe set, so the data path needs no
 collective; the only exchange is after a lap: every rank contributes its K fastest finished rollouts as fixed-stride
-padded records, an all-gather (RCCL over xGMI when the process group's backend is "nccl", gloo on CPU) makes the
-union visible everywhere, and every rank runs the same deterministic top-K selection and the same addTrajectory
-inserts, which leaves identical lap stores on all ranks.  torch.distributed is used for the process group only.
+padded records, one all-gather makes the union visible everywhere, and every rank runs the same deterministic top-K
+selection and the same addTrajectory inserts, which leaves identical lap stores on all ranks.
+
+The collective is RCCL (ncclAllGather over xGMI) called from liblmpc_hip.so (include/lmpc_hip.h: lmpc_comm_*,
+lmpc_rollout_exchange): the records are packed on the device from the rollout session's logs and never staged through the
+host.  This module holds what surrounds it: the rendezvous (rank 0 creates the 128-byte RCCL id and hands it to the other
+processes over TCP on the launcher's MASTER_ADDR), the sharding rule and the deterministic top-K.  A communicator is any
+object with rank / world / allgather / allreduce_max / barrier: `RcclComm` (GPUs), `LocalComm` (one process); the CPU tests
+supply a gloo-backed one of their own.
 """
+import os
+import socket
+import time
+
 import numpy as np
 
 REC_COLS = 14            # x (6) | u (2) | x_glob (6)
@@ -18,18 +28,102 @@ def shard(total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def _dist():
-    try:
-        import torch.distributed as dist
-    except Exception:
-        return None
-    return dist if (dist.is_available() and dist.is_initialized()) else None
+# ---------------------------------------------------------------------------------------------- communicators
+class LocalComm:
+    """Single process."""
+    rank, world, backend = 0, 1, "local"
+
+    def allgather(self, arr):
+        return np.array(arr)[None]
+
+    def allreduce_max(self, values):
+        return np.atleast_1d(np.asarray(values, dtype=np.float64)).copy()
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
 
 
+def _rendezvous_id(rank, world, addr, port, make_id, timeout=120.0):
+    """Rank 0 creates the RCCL unique id and serves it to the world - 1 other ranks over TCP (addr, port)."""
+    if rank == 0:
+        uid = make_id()
+        if world > 1:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port)); srv.listen(world); srv.settimeout(timeout)
+            try:
+                for _ in range(world - 1):
+                    conn, _peer = srv.accept()
+                    conn.sendall(uid); conn.close()
+            finally:
+                srv.close()
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            s = socket.create_connection((addr, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() - t0 > timeout:
+                raise
+            time.sleep(0.05)
+    buf = b""
+    while len(buf) < 128:
+        chunk = s.recv(128 - len(buf))
+        if not chunk:
+            raise ConnectionError("rendezvous: rank 0 closed the connection early")
+        buf += chunk
+    s.close()
+    return buf
+
+
+class RcclComm:
+    """RCCL communicator owned by an lmpc context (one per process / GPU)."""
+    backend = "rccl"
+
+    def __init__(self, ctx, rank, world, addr="127.0.0.1", port=29617):
+        from . import _capi
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        uid = _rendezvous_id(self.rank, self.world, addr, int(port), _capi.comm_unique_id)
+        ctx.comm_init(uid, self.rank, self.world)
+
+    def allgather(self, arr):
+        return self.ctx.comm_allgather(arr)
+
+    def allreduce_max(self, values):
+        return self.ctx.comm_allreduce_max(values)
+
+    def barrier(self):
+        self.ctx.comm_barrier()
+
+    def close(self):
+        self.ctx.comm_destroy()
+
+
+def env_world():
+    """(rank, world, local_rank, addr, rendezvous port) from the launcher's environment (torch.distributed.run / bench.py --gpus)."""
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("LMPC_RDZV_PORT", str(int(os.environ.get("MASTER_PORT", "29500")) + 117)))   # MASTER_PORT itself belongs to the launcher's store
+    return rank, world, local, addr, port
+
+
+def comm_from_env(ctx, force_rccl=False):
+    rank, world, _local, addr, port = env_world()
+    if world > 1 or force_rccl:
+        return RcclComm(ctx, rank, world, addr, port)
+    return LocalComm()
+
+
+# ---------------------------------------------------------------------------------------------- lap records
 def pack_laps(laps, K, T_max):
-    """laps: list of (x (T,6), u (T,2), x_glob (T,6)[, extra (<=14,)]).  Keeps the K shortest (ties: lower local index),
-    pads to T_max rows + 1 row for `extra` (e.g. the state right after the finish line).
-    Returns (records float64 [K, T_max + 1, 14], lengths int64 [K]); unused slots have length -1."""
+    """laps: list of (x (T,6), u (T,2), x_glob (T,6)[, extra (<=12,)]).  Keeps the K shortest (ties: lower local index),
+    pads to T_max rows + 1 row for `extra` (the state right after the finish line) and the local index.
+    Returns (records float64 [K, T_max + 1, 14], lengths int64 [K]); unused slots have length -1.
+    Same layout as the device-side packing of lmpc_rollout_exchange (lmpc_comm.hip.h)."""
     order = sorted(range(len(laps)), key=lambda i: (laps[i][0].shape[0], i))[:K]
     rec = np.zeros((K, T_max + 1, REC_COLS)); ln = -np.ones(K, dtype=np.int64)
     for j, i in enumerate(order):
@@ -41,28 +135,14 @@ def pack_laps(laps, K, T_max):
         if len(laps[i]) > 3:
             e = np.asarray(laps[i][3], float).reshape(-1)
             rec[j, T_max, :e.shape[0]] = e
+        rec[j, T_max, 12] = i
     return rec, ln
 
 
-def exchange_laps(laps, K, T_max):
-    """All-gather every rank's K fastest laps and return the global K fastest as [(x, u, x_glob, src_rank, T, extra)],
-    ordered by (T, src_rank, local order) -- identical on every rank."""
-    rec, ln = pack_laps(laps, K, T_max)
-    dist = _dist()
-    if dist is None:
-        recs, lens = rec[None], ln[None]
-    else:
-        import torch
-        world = dist.get_world_size()
-        on_gpu = dist.get_backend() == "nccl"                   # "nccl" is RCCL on ROCm
-        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-        t_rec = torch.from_numpy(rec).to(dev); t_len = torch.from_numpy(ln).to(dev)
-        g_rec = [torch.empty_like(t_rec) for _ in range(world)]
-        g_len = [torch.empty_like(t_len) for _ in range(world)]
-        dist.all_gather(g_rec, t_rec)                           # ncclAllGather (RCCL) / gloo allgather
-        dist.all_gather(g_len, t_len)
-        recs = np.stack([t.cpu().numpy() for t in g_rec]); lens = np.stack([t.cpu().numpy() for t in g_len])
-    cand = [(int(lens[r, j]), r, j) for r in range(recs.shape[0]) for j in range(K) if lens[r, j] >= 0]
+def top_k(recs, lens, K, T_max):
+    """Deterministic global selection from gathered records (world, K, T_max + 1, 14) / lengths (world, K): the K shortest laps,
+    ordered by (T, source rank, slot) -- identical on every rank.  Returns [(x, u, x_glob, src_rank, T, extra14)]."""
+    cand = [(int(lens[r, j]), r, j) for r in range(recs.shape[0]) for j in range(recs.shape[1]) if lens[r, j] >= 0]
     cand.sort()
     out = []
     for T, r, j in cand[:K]:
@@ -70,25 +150,22 @@ def exchange_laps(laps, K, T_max):
     return out
 
 
-def broadcast_array(arr, src=0):
-    """Every rank receives rank `src`'s array (same shape/dtype everywhere)."""
-    dist = _dist()
-    if dist is None:
-        return np.array(arr)
-    import torch
-    on_gpu = dist.get_backend() == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
-    dist.broadcast(t, src=src)
-    return t.cpu().numpy()
+def exchange_laps(laps, K, T_max, comm=None):
+    """All-gather every rank's K fastest laps (host-side lists) and return the global K fastest, identical on every rank."""
+    comm = comm or LocalComm()
+    rec, ln = pack_laps(laps, K, T_max)
+    recs = comm.allgather(rec); lens = comm.allgather(ln)
+    return top_k(recs, lens, K, T_max)
 
 
-def allreduce_max(value):
-    dist = _dist()
-    if dist is None:
-        return float(value)
-    import torch
-    on_gpu = dist.get_backend() == "nccl"
-    t = torch.tensor([float(value)], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+def gather_owned_rows(buf, mask, comm=None):
+    """buf (K, ...) holds this rank's rows where mask[k] is set; every rank receives the union (each row taken from the rank that
+    owns it; a row nobody owns stays zero and is reported in the returned `owned` mask)."""
+    comm = comm or LocalComm()
+    allb = comm.allgather(np.ascontiguousarray(buf, dtype=np.float64)); allm = comm.allgather(np.ascontiguousarray(mask, dtype=np.int64))
+    out = np.zeros_like(allb[0]); owned = np.zeros(allm.shape[1], dtype=bool)
+    for r in range(allb.shape[0]):
+        for k in np.nonzero(allm[r])[0]:
+            if not owned[k]:
+                out[k] = allb[r, k]; owned[k] = True
+    return out, owned

@@ -10,8 +10,8 @@ pytestmark = pytest.mark.gpu
 
 def pid_laps_batched(track, n_laps, max_steps=600):
     """30 single-lap PID trajectories, lap i at target speed 0.6 + 0.02 i, integrated with the vectorised plant
-    (racinglmpc_amd.rollout.plant_step restates SysModel.dynModel); control law = Utilities.PID.solve."""
-    from racinglmpc_amd import rollout
+    (tests/host_rollout.plant_step restates SysModel.dynModel); control law = Utilities.PID.solve."""
+    from tests import host_rollout as rollout
     TL = float(track[-1, 3] + track[-1, 4])
     rng = np.random.default_rng(77)
     vt = 0.6 + 0.02 * np.arange(n_laps)

@@ -10,23 +10,31 @@ from tests import common
 WORKER = r'''
 import os, sys, numpy as np
 sys.path.insert(0, sys.argv[1])
-import torch.distributed as dist
 from racinglmpc_amd import parallel
-dist.init_process_group(backend="gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
+from tests.gloo_comm import GlooComm
+comm = GlooComm()
+rank, world = comm.rank, comm.world
 lo, hi = parallel.shard(11, rank, world)
 rng = np.random.default_rng(100 + rank)
 laps = []
 for i in range(lo, hi):
     T = 120 + (7 * i) % 23                       # deterministic lap lengths, some ties across ranks
-    laps.append((rng.normal(size=(T, 6)) + i, rng.normal(size=(T, 2)), rng.normal(size=(T, 6))))
-best = parallel.exchange_laps(laps, K=4, T_max=160)
-bc = parallel.broadcast_array(np.arange(6.0) + 10 * rank, src=0)
-assert np.array_equal(bc, np.arange(6.0))
-mx = parallel.allreduce_max(float(rank + 1))
+    laps.append((rng.normal(size=(T, 6)) + i, rng.normal(size=(T, 2)), rng.normal(size=(T, 6)), np.arange(12.0) + i))
+best = parallel.exchange_laps(laps, K=4, T_max=160, comm=comm)
+rec, ln = parallel.pack_laps(laps, 4, 160)
+recs = comm.allgather(rec)
+# rows owned by different ranks (K = 4 parent laps continued by global rollouts 0..3: all on rank 0 here; 7..10 on rank 1)
+buf = np.zeros((4, 3, 8)); mask = np.zeros(4, dtype=np.int64)
+for k in range(4):
+    gidx = 2 + 3 * k                              # global rollout index that owns row k: 2, 5 on rank 0; 8 on rank 1; 11 nobody
+    if lo <= gidx < hi:
+        buf[k] = gidx; mask[k] = 1
+rows, owned = parallel.gather_owned_rows(buf, mask, comm)
+mx = comm.allreduce_max(float(rank + 1))[0]
 np.savez(os.path.join(sys.argv[2], "rank%d.npz" % rank), lens=np.array([b[4] for b in best]), src=np.array([b[3] for b in best]),
-         x0=np.array([b[0][0, 0] for b in best]), chk=np.array([b[0].sum() + b[1].sum() + b[2].sum() for b in best]), mx=mx, lo=lo, hi=hi)
-dist.barrier(); dist.destroy_process_group()
+         x0=np.array([b[0][0, 0] for b in best]), chk=np.array([b[0].sum() + b[1].sum() + b[2].sum() for b in best]), mx=mx, lo=lo, hi=hi,
+         extra=np.array([b[5] for b in best]), recs=recs, rows=rows, owned=owned)
+comm.close()
 '''
 
 
@@ -43,6 +51,7 @@ def test_shard_covers_everything():
 
 def test_exchange_single_process():
     from racinglmpc_amd import parallel
+    assert parallel.LocalComm().allgather(np.arange(3.0)).shape == (1, 3)
     rng = np.random.default_rng(0)
     laps = [(rng.normal(size=(T, 6)), rng.normal(size=(T, 2)), rng.normal(size=(T, 6))) for T in (50, 40, 45, 40)]
     best = parallel.exchange_laps(laps, K=3, T_max=64)
@@ -58,9 +67,36 @@ def test_exchange_two_ranks_gloo(tmp_path):
            "--master-port", "29571", str(script), common.ROOT, str(tmp_path)]
     subprocess.run(cmd, check=True, env=env, timeout=600, capture_output=True)
     r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
-    for k in ("lens", "src", "x0", "chk", "mx"):
+    for k in ("lens", "src", "x0", "chk", "mx", "extra", "recs", "rows", "owned"):
         assert np.array_equal(r0[k], r1[k]), k
     assert float(r0["mx"]) == 2.0
     assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 6, 6, 11)
     lens_all = sorted(120 + (7 * i) % 23 for i in range(11))
     assert list(r0["lens"]) == lens_all[:4]
+    # record layout: (world, K, T_max + 1, 14); the extra row carries the 12 finish-line values and the local index
+    assert r0["recs"].shape == (2, 4, 161, 14)
+    assert np.all(r0["extra"][:, 12] == np.round(r0["extra"][:, 12])) and np.all(r0["extra"][:, 13] == 0)
+    # owner gather: rows 0, 1 from rank 0, row 2 from rank 1, row 3 owned by nobody
+    assert list(r0["owned"]) == [True, True, True, False]
+    assert np.all(r0["rows"][0] == 2) and np.all(r0["rows"][1] == 5) and np.all(r0["rows"][2] == 8) and np.all(r0["rows"][3] == 0)
+
+
+RDZV_WORKER = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+from racinglmpc_amd import parallel
+rank, world, port = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+uid = parallel._rendezvous_id(rank, world, "127.0.0.1", port, lambda: bytes(range(128)))
+assert uid == bytes(range(128)), uid
+print("ok", rank)
+'''
+
+
+def test_unique_id_rendezvous_three_processes(tmp_path):
+    """The TCP hand-off of the RCCL unique id (rank 0 creates, the others fetch), without a GPU: three processes, any start order."""
+    script = tmp_path / "rdzv.py"
+    script.write_text(RDZV_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), common.ROOT, str(r), "3", "29689"], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in (2, 1, 0)]
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0 and out.decode().startswith("ok"), err.decode()
