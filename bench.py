@@ -5,15 +5,22 @@ One "step" = one pass of the full hot path (LTV regression for N horizon points,
 QP assembly-in-structure + solve to the certified optimum, unpack) over one batch of synthetic QPs whose
 inputs are already resident in HBM.  Workload at N_gpus=1: BASELINE.json configs[1]
 ("batch=256 LMPC QPs, N=12, fixed safe-set, 1xMI355X"), generated as SURVEY.md section 8(d) prescribes.
-With --gpus G (launched by torch.distributed.run, one rank per GPU) every rank runs the same batch size on
-its own GPU (weak scaling, no data-path collective: the QPs are independent); value = all ranks' solves /
-max-over-ranks time.
 
-Prints ONE JSON line on rank 0.
+Multi-GPU: one process per GPU.  Either the driver launches the ranks (torch.distributed.run sets RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_*), or `python bench.py --gpus N` on its own spawns N ranks of itself with that environment.  Every rank
+runs the same batch size on its own GPU (weak scaling, no data-path collective: the QPs are independent); the barrier and the
+max-over-ranks time go through RCCL behind the library's C ABI (racinglmpc_amd/parallel.py); value = all ranks' solves /
+max-over-ranks time.  No PyTorch anywhere in the measured path.
+
+Besides the contract's keys the line carries (cheap, a few seconds together): the batch sweep 1..8192, BASELINE configs[2]
+(batch 4096, safe set from 30 laps), configs[4] (N = 40, batch 1024) and configs[3] (closed-loop rollouts sharded over the ranks
+with one all-gather per lap).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,53 +31,119 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP64_VEC_PEAK_TFLOPS = 78.6      # MI355X FP64 vector peak (spec)
+SEED_LAP = os.path.join(ROOT, "tests", "golden", "lmpc_n12.npz")     # PID seed lap + track table recorded from the executed reference (data only)
 
 
-def synth_batch(g, B, N, seed=1234):
-    """SURVEY 8(d) 'cfg batch=256, fixed safe-set': problem b starts at row t_b = 37 b mod 900 of the PID seed lap."""
-    xPID, uPID = g["xPID"], g["uPID"]
+def load_seed():
+    g = np.load(SEED_LAP)
+    return dict(xPID=np.array(g["xPID"]), uPID=np.array(g["uPID"]), track=np.array(g["track"]), trackLength=float(g["trackLength"]))
+
+
+def synth_batch(g, B, N, seed=1234, lap=None):
+    """SURVEY 8(d) 'cfg batch=256, fixed safe-set': problem b starts at row t_b = 37 b mod 900 of the PID seed lap
+    (of `lap` = (x, u) if given: the 30-lap configuration queries lap 29)."""
+    xq, uq = (g["xPID"], g["uPID"]) if lap is None else lap
     rng = np.random.default_rng(seed)
-    tb = (37 * np.arange(B)) % 900
+    span = 900 if lap is None else xq.shape[0] - 40 - N - 2
+    tb = (37 * np.arange(B)) % span
     eps = rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02])
-    x0 = xPID[tb] + eps
-    xLin = np.stack([xPID[t + 1:t + N + 2] for t in tb])
-    uLin = np.stack([uPID[t + 1:t + N + 1] for t in tb])
-    uOld = uPID[tb].copy()
-    zt = xPID[tb + N + 1].copy()
-    tstep = (tb % 300).astype(np.int32)
-    return dict(x0=x0, xLin=xLin, uLin=uLin, uOld=uOld, zt=zt, timeStep=tstep, hasPred=np.zeros(B, np.int32),
+    return dict(x0=xq[tb] + eps, xLin=np.stack([xq[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uq[t + 1:t + N + 1] for t in tb]),
+                uOld=uq[tb].copy(), zt=xq[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32), hasPred=np.zeros(B, np.int32),
                 xPredPrev=np.zeros((B, N + 1, 6)))
 
 
-def make_ctx(g, N, B, device):
+def make_ctx(g, N, B, device, laps=None, **kw):
+    """Context with the reference's LMPC tuning (lmpc_config_default: initControllerParameters.py:28-59) on the recorded track;
+    stores: 4 x PID lap (main.py:102-110) unless `laps` is given."""
     from racinglmpc_amd import _capi
-    from tests import common
-    cfg, par = common.lmpc_config(g, N, max_batch=max(B, 1), device=device)
+    cfg = _capi.default_config()
+    cfg.N = N; cfg.max_batch = max(B, 1); cfg.device = device
+    for i, v in enumerate(g["track"].reshape(-1)):
+        cfg.track[i] = float(v)
+    cfg.track_rows = g["track"].shape[0]; cfg.trackLength = g["trackLength"]
+    for k, v in kw.items():
+        setattr(cfg, k, v)
     ctx = _capi.Context(cfg)
-    for _ in range(4):                                  # main.py:102-110: model store = safe set = 4 x PID lap
-        ctx.model_add_trajectory(g["xPID"], g["uPID"])
-        ctx.ss_add_trajectory(g["xPID"], g["uPID"])
-    return ctx, par
+    for x, u in (laps if laps is not None else [(g["xPID"], g["uPID"])] * 4):
+        ctx.model_add_trajectory(x, u)
+        ctx.ss_add_trajectory(x, u)
+    return ctx
 
 
-def device_args(ctx, inp, B, N, S):
-    from racinglmpc_amd import _capi
-    a = _capi.StepDevArgs()
-    keep = []
+def pid_laps(ctx, g, n_laps, max_steps=600):
+    """SURVEY 8(d) 'safe-set from 30 laps': n single-lap PID trajectories, lap i at target speed 0.6 + 0.02 i (Utilities.PID.solve
+    control law, noise seeded), integrated by the plant kernel (lmpc_plant_step_batch = Simulator.dynModel)."""
+    TL = g["trackLength"]
+    rng = np.random.default_rng(77)
+    vt = 0.6 + 0.02 * np.arange(n_laps)
+    x = np.tile(np.array([0.5, 0, 0, 0, 0, 0.0]), (n_laps, 1)); xg = x.copy()
+    X, U = [], []
+    done = -np.ones(n_laps, int)
+    for t in range(max_steps):
+        u = np.stack([-0.6 * x[:, 5] - 0.9 * x[:, 3] + np.clip(rng.standard_normal(n_laps) * 0.25, -0.9, 0.9),
+                      1.5 * (vt - x[:, 0]) + np.clip(rng.standard_normal(n_laps) * 0.10, -0.2, 0.2)], axis=1)
+        X.append(x.copy()); U.append(u)
+        x, xg, _st = ctx.plant_step_batch(x, xg, u, rng.standard_normal((n_laps, 3)))
+        done[(done < 0) & (x[:, 4] > TL)] = t + 1
+        if np.all(done > 0):
+            break
+    X = np.stack(X, 1); U = np.stack(U, 1)
+    return [(X[i, :min(done[i] + 20, X.shape[1])], U[i, :min(done[i] + 20, X.shape[1])]) for i in range(n_laps)]
 
-    def up(arr):
-        p = ctx.dev_array(arr); keep.append(p); return p
 
-    def alloc(nbytes):
-        p = ctx.dev_alloc(max(nbytes, 8)); keep.append(p); return p
-    a.x0, a.xLin, a.uLin, a.uOld, a.zt = up(inp["x0"]), up(inp["xLin"]), up(inp["uLin"]), up(inp["uOld"]), up(inp["zt"])
-    a.xPredPrev, a.hasPred, a.timeStep = up(inp["xPredPrev"]), up(inp["hasPred"]), up(inp["timeStep"])
-    M = 8 * N + S
-    a.xPred, a.uPred, a.slack = alloc(B * (N + 1) * 6 * 8), alloc(B * N * 2 * 8), alloc(B * N * 2 * 8)
-    a.lambda_, a.sTerm, a.ztNext, a.ztuNext = alloc(B * S * 8), alloc(B * 6 * 8), alloc(B * 6 * 8), alloc(B * 2 * 8)
-    a.ssSel, a.A, a.Bm, a.C = alloc(B * S * 6 * 8), alloc(B * N * 36 * 8), alloc(B * N * 12 * 8), alloc(B * N * 6 * 8)
-    a.mu, a.resid, a.status, a.iters = alloc(B * M * 8), alloc(B * 3 * 8), alloc(B * 4), alloc(B * 4)
-    return a, keep
+def time_steps(ctx, B, a, steps, warmup, sync=None):
+    """W untimed + K timed full steps on device-resident buffers; returns (seconds, stats of the timed launches)."""
+    for _ in range(warmup):
+        ctx.step_batch_dev(B, a)
+    (sync or ctx.sync)()
+    ctx.reset_stats(); ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.step_batch_dev(B, a)
+    (sync or ctx.sync)()
+    dt = time.perf_counter() - t0
+    st = ctx.stats(); ctx.set_profiling(False)
+    return dt, st
+
+
+def run_config(g, N, B, device, steps, warmup, laps=None, query_lap=None, **kw):
+    """One extra configuration: build, time, check the status of every problem, free."""
+    ctx = make_ctx(g, N, B, device, laps=laps, **kw)
+    inp = synth_batch(g, B, N, lap=query_lap)
+    a, keep = ctx.step_dev_buffers(inp)
+    dt, st = time_steps(ctx, B, a, steps, warmup)
+    status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32)
+    ctx.dev_download(a.status, status); ctx.dev_download(a.iters, iters)
+    out = dict(batch=B, N=N, solves_per_s=B * steps / dt, ms_per_step=dt / steps * 1e3, solved_ok=int(np.sum(status == 0)),
+               ipm_iters_mean=float(iters.mean()), ipm_iters_max=int(iters.max()), waves_per_qp=ctx.solver_waves(B),
+               kernel_ms={"lmpc_solve_kernel": st.ms_solve / max(st.n_solve, 1), "lmpc_regress_kernel": st.ms_regress / max(st.n_regress, 1)})
+    for p in keep:
+        ctx.dev_free(p)
+    ctx.close()
+    return out
+
+
+def rollout_leg(g, comm, ctx, rollouts_per_gpu, generations=2, K=4, T_max=400):
+    """BASELINE configs[3]: closed-loop LMPC laps, device resident, sharded over the ranks, one all-gather of the fastest laps per lap.
+    Runs last on the main context (its stores grow by K laps per generation on every rank, identically)."""
+    from racinglmpc_amd import rollout
+    world, rank = comm.world, comm.rank
+    total = rollouts_per_gpu * world
+    ro = rollout.BatchedRollouts(ctx, g["track"], seed=100 + rank)
+    x0 = np.tile(np.array([0.5, 0, 0, 0, 0, 0.0]), (total, 1)); x0[:, 5] = np.linspace(-0.1, 0.1, total); x0[:, 0] += np.linspace(0.0, 0.1, total)
+    gen = rollout.LmpcGeneration(ro, total, K=K, T_max=T_max, ext=40, comm=comm)
+    laps = []
+    for it in range(generations):
+        comm.barrier(); t0 = time.perf_counter()
+        best = gen.run(x0, g["xPID"][1:14], g["uPID"][1:13])
+        dt = float(comm.allreduce_max(time.perf_counter() - t0)[0])
+        steps = int(ctx._ro_t)
+        laps.append(dict(generation=it, seconds=dt, simulated_steps=steps, best_lap_steps=[b[4] for b in best], src_ranks=[int(b[3]) for b in best],
+                         closed_loop_solves_per_s=total * steps / dt, allgather_bytes_per_rank=int(gen.last_exchange[0]),
+                         exchange_seconds=float(comm.allreduce_max(gen.last_exchange[1])[0])))
+    info = ctx.comm_info()
+    return dict(rollouts_total=total, rollouts_per_gpu=rollouts_per_gpu, K=K, collective="ncclAllGather (RCCL)" if info[2] else "none (single process)",
+                rccl_ranks=info[1] if info[2] else 1, generations=laps)
 
 
 def _cpu_worker(args):
@@ -82,11 +155,10 @@ def _cpu_worker(args):
     except Exception:
         pass
     from oracle import lmpc_oracle as orc
-    from tests import common
-    g = common.load_lmpc_golden()
+    g = load_seed()
     inp = synth_batch(g, B, N, seed=1234)
     par = orc.QPParams.lmpc_default(N)
-    pt, TL = g["track"], float(g["trackLength"])
+    pt, TL = g["track"], g["trackLength"]
     xS = [g["xPID"]] * 4; uS = [g["uPID"]] * 4
     Qf = [orc.compute_cost(g["xPID"], TL)] * 4
     done = 0
@@ -116,10 +188,40 @@ def cpu_baseline(N, B, seconds=6.0, max_procs=64):
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(i * 7, seconds, N, B) for i in range(cores)])
     done = sum(r[0] for r in res); busy = max(r[1] for r in res)
-    return dict(value=done / busy, unit="solves/s", cores=cores, kind="port",
-                sample="%d full steps (a3-a19, restated OSQP eps=1e-3 + polish) of the bench batch in %.1f s on %d single-threaded processes "
-                       "(host has %d cores)" % (done, busy, cores, os.cpu_count() or 1),
-                single_core={"value": one, "unit": "solves/s", "cores": 1, "sample": "%d steps in %.1f s" % (n1, t1)})
+    out = dict(value=done / busy, unit="solves/s", cores=cores, kind="port",
+               sample="%d full steps (a3-a19, restated OSQP eps=1e-3 + polish) of the bench batch in %.1f s on %d single-threaded processes "
+                      "(host has %d cores)" % (done, busy, cores, os.cpu_count() or 1),
+               single_core={"value": one, "unit": "solves/s", "cores": 1, "sample": "%d steps in %.1f s" % (n1, t1)})
+    ref = os.path.join(ROOT, "profiles", "cpu_reference.json")
+    if os.path.exists(ref):
+        try:   # the reference's OWN classes timed in the build container (different box: /root/reference does not exist here)
+            out["reference_classes_other_box"] = json.load(open(ref))
+        except Exception:
+            pass
+    return out
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU, with the launcher's environment."""
+    import __graft_entry__ as ge
+    if "--dry-run" not in argv:
+        ge.build()                                  # once, before the ranks need the library
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LMPC_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        sys.exit("bench.py: rank exit codes %s" % rcs)
 
 
 def main():
@@ -130,57 +232,46 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="QPs per GPU per step (BASELINE configs[1]: 256)")
     ap.add_argument("--horizon", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sweep", action="store_true", help="also report solves/s for batch 1..8192 (extra key 'sweep')")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sweep / extra configurations / rollout leg")
+    ap.add_argument("--rollouts-per-gpu", type=int, default=1024)
+    ap.add_argument("--dry-run", action="store_true", help="start the ranks and the rendezvous only (no GPU needed): proves the N-rank launch path")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1 or os.environ.get("LMPC_BENCH_FORCE_DIST") == "1":      # the env switch exercises the RCCL code path on one GPU
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus, sys.argv[1:])
+    from racinglmpc_amd import parallel
+    rank, world, local, addr, port = parallel.env_world()
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+
+    if args.dry_run:
+        uid = parallel._rendezvous_id(rank, world, addr, port, lambda: bytes(range(128)))
+        assert uid == bytes(range(128))
+        if rank == 0:   # rank 0 has served the id to world - 1 peers: every rank started and reached the rendezvous
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_at_rendezvous": world}))
+        return
+
     import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
-    if dist is not None:
-        dist.barrier()
-
-    from tests import common
-    g = common.load_lmpc_golden()
+    ge.build()                                       # no-op when the library is current (file-locked against concurrent ranks)
+    g = load_seed()
     N, B = args.horizon, args.batch
-    ctx, par = make_ctx(g, N, B, local)
+    ctx = make_ctx(g, N, max(B, 1 if args.no_extras else args.rollouts_per_gpu), local)
     S = ctx.S
+    comm = parallel.comm_from_env(ctx, force_rccl=os.environ.get("LMPC_BENCH_FORCE_DIST") == "1")
     inp = synth_batch(g, B, N, seed=1234 + rank)
-    a, keep = device_args(ctx, inp, B, N, S)
+    a, keep = ctx.step_dev_buffers(inp)
 
-    def sync_all():
+    def sync_all():                                  # device drained on this rank, then on every rank
         ctx.sync()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        comm.barrier()
 
-    for _ in range(args.warmup):
-        ctx.step_batch_dev(B, a)
-    sync_all()
-    ctx.reset_stats(); ctx.set_profiling(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.step_batch_dev(B, a)
-    sync_all()
-    dt = time.perf_counter() - t0
-    st = ctx.stats(); ctx.set_profiling(False)
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, st = time_steps(ctx, B, a, args.steps, args.warmup, sync=sync_all)
+    dt = float(comm.allreduce_max(dt)[0])
 
     status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); resid = np.zeros((B, 3))
     ctx.dev_download(a.status, status); ctx.dev_download(a.iters, iters); ctx.dev_download(a.resid, resid)
-    n_ok = int(np.sum(status == 0))
+    n_ok = int(comm.allgather(np.array([np.sum(status == 0)], dtype=np.int64)).sum())
+    comm_info = ctx.comm_info()
 
     out = None
     if rank == 0:
@@ -204,8 +295,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "batch=%d LMPC QPs per GPU, N=%d, fixed safe-set (4x PID seed lap, 48 points from 4 laps), full step a3-a19" % (B, N),
                        "batch_per_gpu": B, "N": N, "numSS_points": S, "laps_scanned": 4, "rows_per_lap": 1000,
-                       "solver": "Riccati-structured primal-dual interior point to certified optimum (gap<1e-11, res<1e-9)"},
-            "solved_ok": n_ok, "ipm_iters_mean": float(iters.mean()), "ipm_iters_max": int(iters.max()),
+                       "solver": "Riccati-structured primal-dual interior point to certified optimum (gap<1e-11, res<1e-9)",
+                       "ranks": world, "collective_backend": "rccl" if comm_info[2] else "none", "rccl_ranks": comm_info[1] if comm_info[2] else 0},
+            "solved_ok": n_ok, "solved_of": world * B, "ipm_iters_mean": float(iters.mean()), "ipm_iters_max": int(iters.max()),
             "kernel_ms": {"lmpc_solve_kernel": ms_solve, "lmpc_regress_kernel": ms_reg},
             "solver_only_solves_per_s": B / (ms_solve * 1e-3), "regression_only_solves_per_s": B / (ms_reg * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -213,39 +305,36 @@ def main():
                          # the other fraction SURVEY 8(d) asks for: FP64 work per launch from the rocprofv3 instruction-mix pass
                          # (profiles/, static) over the launch time measured live; plus VALU utilisation and the LDS bank-conflict rate
                          "fp64": None if not counters or "fp64_flop_per_launch" not in counters else {
-                             "achieved": counters["fp64_flop_per_launch"] / (ms_solve * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                             "frac": counters["fp64_flop_per_launch"] / (ms_solve * 1e-3) / 1e12 / 78.6,
+                             "achieved": counters["fp64_flop_per_launch"] / (ms_solve * 1e-3) / 1e12, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": counters["fp64_flop_per_launch"] / (ms_solve * 1e-3) / 1e12 / FP64_VEC_PEAK_TFLOPS,
                              "valu_utilisation": counters.get("valu_utilisation"), "lds_bank_conflict_rate": counters.get("lds_bank_conflict_rate"),
                              "mfma_busy_cycles_per_launch": counters.get("SQ_VALU_MFMA_BUSY_CYCLES")},
                          "note": "dependent-issue-latency bound path (one Newton recursion per QP); compulsory HBM traffic is 2.46 KB per solve (SURVEY 8(d)); "
-                                 "measured traffic also counts the A,B,C hand-over from the regression kernel, the L2-resident lap-store scans and the mu/ssSel outputs; see DESIGN.md"},
+                                 "measured traffic also counts the L2-resident lap-store scans and the mu/ssSel outputs; see DESIGN.md"},
         }
-        if args.sweep:
-            sweep = {}
-            for bb in (1, 8, 64, 256, 512, 1024, 2048, 4096, 8192):
-                c2, _ = make_ctx(g, N, bb, local)
-                i2 = synth_batch(g, bb, N)
-                a2, k2 = device_args(c2, i2, bb, N, S)
-                for _ in range(2):
-                    c2.step_batch_dev(bb, a2)
-                c2.sync(); t1 = time.perf_counter(); reps = 20 if bb <= 1024 else 5
-                for _ in range(reps):
-                    c2.step_batch_dev(bb, a2)
-                c2.sync(); sweep[str(bb)] = bb * reps / (time.perf_counter() - t1)
-                for p in k2:
-                    c2.dev_free(p)
-                c2.close()
-            out["sweep_solves_per_s"] = sweep
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(N, B)
-        elif not args.no_cpu_baseline:
-            out["cpu_baseline"] = None
     for p in keep:
         ctx.dev_free(p)
+
+    # ---- extra configurations (rank 0's GPU; the other ranks wait at the rollout leg's first barrier) ------------------------------
+    if not args.no_extras:
+        if rank == 0:
+            sweep = {}
+            for bb in (1, 8, 64, 256, 512, 1024, 2048, 4096, 8192):
+                r = run_config(g, N, bb, local, steps=20 if bb <= 1024 else 8, warmup=3)
+                sweep[str(bb)] = {k: r[k] for k in ("solves_per_s", "solved_ok", "ipm_iters_max", "waves_per_qp")}
+            out["sweep"] = sweep
+            laps30 = pid_laps(ctx, g, 30)
+            out["config_batch4096_30laps"] = dict(run_config(g, N, 4096, local, steps=8, warmup=2, laps=laps30, query_lap=laps30[29], max_laps=40, max_lap_len=1024),
+                                                  note="BASELINE configs[2]: 30 PID laps (vt = 0.6 + 0.02 i) in both stores, reference semantics = the 4 fastest are used")
+            out["config_N40_batch1024"] = dict(run_config(g, 40, 1024, local, steps=5, warmup=2), note="BASELINE configs[4]")
+        leg = rollout_leg(g, comm, ctx, args.rollouts_per_gpu)
+        if rank == 0:
+            out["config_rollouts"] = dict(leg, note="BASELINE configs[3]: closed-loop LMPC laps sharded over the ranks, lap stores replicated, one all-gather per lap")
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, B) if world == 1 else None
+    comm.barrier()
+    comm.close()
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
 

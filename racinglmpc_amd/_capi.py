@@ -1,4 +1,4 @@
-"""ctypes binding of liblmpc_hip.so (C ABI: include/lmpc_hip.h).  NumPy in, NumPy out; no torch.
+"""ctypes binding of liblmpc_hip.so (C ABI: include/lmpc_hip.h).  NumPy in, NumPy out.
 
 The library is the only compute path: importing this module without a built .so, or calling into it
 without a working HIP device, raises -- there is no CPU fallback.

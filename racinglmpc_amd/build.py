@@ -8,14 +8,25 @@ DEPS = [SRC, os.path.join(_HERE, "csrc", "lmpc_kernels.hip.h"), os.path.join(_HE
 OUT = os.path.join(_HERE, "liblmpc_hip.so")
 
 
+def _current():
+    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+
+
 def build(force=False, verbose=False):
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+    if not force and _current():
         return OUT
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-unused-value", "-fPIC", "-shared", "-o", OUT, SRC, "-L/opt/rocm/lib", "-lrccl"]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+    import fcntl
+    with open(OUT + ".lock", "w") as lock:             # several ranks may call build() at once: one compiles, the others wait
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not _current():
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            tmp = OUT + ".tmp%d" % os.getpid()
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-unused-value", "-fPIC", "-shared", "-o", tmp, SRC,
+                   "-L/opt/rocm/lib", "-lrccl"]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            subprocess.check_call(cmd)
+            os.replace(tmp, OUT)
     return OUT
 
 

@@ -104,7 +104,7 @@ class RcclComm:
 
 
 def env_world():
-    """(rank, world, local_rank, addr, rendezvous port) from the launcher's environment (torch.distributed.run / bench.py --gpus)."""
+    """(rank, world, local_rank, addr, rendezvous port) from the launcher's environment (the driver's distributed launcher or bench.py --gpus)."""
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", str(rank)))
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(os.environ.get("LMPC_RDZV_PORT", str(int(os.environ.get("MASTER_PORT", "29500")) + 117)))   # MASTER_PORT itself belongs to the launcher's store

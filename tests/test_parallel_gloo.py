@@ -100,3 +100,16 @@ def test_unique_id_rendezvous_three_processes(tmp_path):
     for p in procs:
         out, err = p.communicate(timeout=120)
         assert p.returncode == 0 and out.decode().startswith("ok"), err.decode()
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set),
+    both reach the rendezvous, and the line says n_gpus = 2 (--dry-run: launch path only, no GPU); a WORLD_SIZE that contradicts
+    --gpus is an error."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--dry-run"], check=True, capture_output=True, timeout=300)
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line == {"dry_run": True, "n_gpus": 2, "ranks_at_rendezvous": 2}
+    bad = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, timeout=300,
+                         env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
+    assert bad.returncode != 0 and b"WORLD_SIZE=1" in bad.stderr
