@@ -107,7 +107,7 @@ int lmpc_regress_batch(lmpc_ctx *, int B, const double *xLin /*B x N x 6 (first 
 int lmpc_select_batch(lmpc_ctx *, int B, const double *x0 /*B x 6*/, const double *zt /*B x 6*/,
                       const double *xPredPrev /*B x (N+1) x 6*/, const int *hasPred /*B*/, const int *timeStep /*B*/,
                       double *ssSel /*B x S x 6*/, double *qSel /*B x S*/, double *succ /*B x S x 6*/, double *succU /*B x S x 2*/,
-                      double *ztUsed /*B x 6*/, int *status /*B*/);
+                      double *ztUsed /*B x 6*/, int *selStart /*B x numSS_it: first row of each lap's window, or NULL*/, int *status /*B*/);
         /* LMPC.addTerminalComponents (selection part) + selectPoints, :386-412, :478-514 */
 
 int lmpc_qp_solve_batch(lmpc_ctx *, int B, const double *A, const double *Bm, const double *C,
@@ -165,6 +165,10 @@ int lmpc_rollout_end(lmpc_ctx *);
         /* Simulator.sim with one LMPC controller per rollout, SysModel.py:22-54, state resident on the device */
 int lmpc_ss_extend_lap(lmpc_ctx *, int lap, const double *x /*n x 6*/, const double *u /*n x 2*/, int n);
         /* LMPC.addPoint (:466-474) applied to any stored lap: n points appended with s + TrackLength, Qfun counting down */
+int lmpc_lti_regression(int device, const double *x /*T x 6*/, const double *u /*T x 2*/, int T, double lamb,
+                        double *A /*6 x 6*/, double *B /*6 x 2*/, double *Error /*2 x 6: max; min of the fit residual*/, int *status /*or NULL*/);
+        /* Utilities.Regression, fnc/Utilities.py:5-28 (main.py:74-77: the LTI model of the path-following MPC); ridge least squares over one lap */
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI.  The QPs / rollouts of a batch are independent given the
  * read-only safe set, so the data path has no collective; the ONE exchange is per lap.  The reference has no counterpart (single
  * process); what is exchanged are the arguments of LMPC.addTrajectory / PredictiveModel.addTrajectory (:418-445, PredictiveModel.py:35-46).

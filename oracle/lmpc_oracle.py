@@ -156,6 +156,17 @@ DT = 0.1                 # :21
 SCALING = np.array([0.1, 1.0, 1.0, 1.0, 1.0])   # diag of :22-26
 
 
+def lti_regression(x, u, lamb):
+    """Utilities.Regression, fnc/Utilities.py:5-28: ridge least squares x_{k+1} ~ A x_k + B u_k over rows 1..T-2 of one lap.
+    Returns A (6,6), B (6,2), Error (2,6) = [max; min] over the rows of (X W - Y)."""
+    Y = x[2:x.shape[0], :]
+    X = np.hstack((x[1:(x.shape[0] - 1), :], u[1:(x.shape[0] - 1), :]))
+    Q = np.linalg.inv(np.dot(X.T, X) + lamb * np.eye(X.shape[1]))
+    W = np.dot(Q, np.dot(X.T, Y))
+    E = np.dot(X, W) - Y
+    return W.T[:, 0:6], W.T[:, 6:8], np.vstack((np.max(E, axis=0), np.min(E, axis=0)))
+
+
 def model_sorted_insert(xStored, uStored, lapTime, x, u):
     """PredictiveModel.addTrajectory, PredictiveModel.py:35-46 (ascending length, ties append)."""
     if lapTime == [] or x.shape[0] >= lapTime[-1]:

@@ -166,9 +166,14 @@ class MPC():
 
     def qp_matrices(self):
         """Reference-form QP of the last solve: (H_FTOCP, q_FTOCP, [F_FTOCP; G_FTOCP], l, u), dense."""
+        N = self.N
         ss = None if self._numSS_it == 0 else self.SS_PointSelectedTot.T[None]
         qs = None if self._numSS_it == 0 else self.Qfun_SelectedTot[None]
-        A, B, C = np.array(self.A)[None], np.array(self.B)[None], np.array(self.C)[None] if self.timeVarying else np.zeros((1, self.N, 6))
+        if self.timeVarying == True:
+            A, B, C = np.array(self.A)[None], np.array(self.B)[None], np.array(self.C)[None]
+        else:       # LTI: one (A, B) for every stage, no affine term
+            A = np.tile(np.asarray(self.A, float)[None, None], (1, N, 1, 1)); B = np.tile(np.asarray(self.B, float)[None, None], (1, N, 1, 1))
+            C = np.zeros((1, N, 6))
         P, q, Ad, l, u = self._ctx.assemble_batch(A, B, C, self._last_x0[None], self._last_uOld[None], ss, qs)
         return P[0], q[0], Ad[0], l[0], u[0]
 
@@ -216,6 +221,7 @@ class LMPC(MPC):
         self._out = out
         self.A, self.B, self.C = list(out["A"][0]), list(out["B"][0]), list(out["C"][0])
         self.SS_PointSelectedTot = out["ssSel"][0].T.copy()
+        self.Qfun_SelectedTot = out["qSel"][0].copy()
         self.unpackSolution()
         self.solverTime = datetime.datetime.now() - t0
         self.feasibleStateInput()
@@ -249,8 +255,8 @@ class LMPC(MPC):
         self.SS.append(x)
         self.SS_glob.append(x_glob)
         self.uSS.append(u)
-        self.Qfun.append(self.computeCost(x, u))
-        self._ctx.ss_add_trajectory(x, u)
+        self._ctx.ss_add_trajectory(x, u)                          # computeCost (:447-464) runs in the library
+        self.Qfun.append(self._ctx.ss_get_qfun(len(self.SS) - 1))
         if self.it == 0:
             self.xLin = self.SS[self.it][1:self.N + 2, :]
             self.uLin = self.uSS[self.it][1:self.N + 1, :]
@@ -261,17 +267,15 @@ class LMPC(MPC):
         self.timeStep = 0
 
     def computeCost(self, x, u):
-        T = x.shape[0]
-        TL = self.predictiveModel.map.TrackLength
-        Cost = 10000 * np.ones((T))
-        for i in range(0, T):
-            if (i == 0):
-                Cost[T - 1 - i] = 0
-            elif x[T - 1 - i, 4] < TL:
-                Cost[T - 1 - i] = Cost[T - 1 - i + 1] + 1
-            else:
-                Cost[T - 1 - i] = 0
-        return Cost
+        """Cost-to-go of a stored lap: steps until s >= TrackLength, 0 from there on (reference :447-464).  addTrajectory takes it from
+        the device store; this host form exists for callers of the reference's method."""
+        s = np.asarray(x, float)[:, 4]
+        T = s.shape[0]
+        stop = s >= self.predictiveModel.map.TrackLength
+        stop[T - 1] = True                                                   # the last row always costs 0
+        nxt = np.where(stop, np.arange(T), T)                                # index of the next row (>= r) with cost 0
+        nxt = np.minimum.accumulate(nxt[::-1])[::-1]
+        return (nxt - np.arange(T)).astype(float)
 
     def addPoint(self, x, u):
         TL = self.predictiveModel.map.TrackLength
@@ -282,18 +286,28 @@ class LMPC(MPC):
         self._ctx.ss_add_point(x, u)
 
     def selectPoints(self, it, zt, numPoints):
-        """Reference signature; evaluates the selection of ALL numSS_it laps on the GPU and returns lap `it`'s part."""
+        """Reference signature and return value (:478-514): (SS_Points (6, numPoints), SSu_Points (2, numPoints), Sel_Qfun (numPoints,)) of
+        stored lap `it` around its point nearest to zt.  The search (argmin of the 1-norm over all rows) runs on the GPU; the window rows
+        are then read from the host mirrors of the lap, the Q-function shift from the library's own selected costs."""
+        numPoints = int(numPoints)
+        ppl = self.numSS_Points // self.numSS_it
+        if numPoints != ppl + 1:
+            raise ValueError("the device selection uses windows of numSS_Points / numSS_it + 1 = %d points" % (ppl + 1))
         order = list(np.argsort(np.array(self.LapTime))[0:self.numSS_it])
         if it not in order:
             order[-1] = it
         self._ctx.ss_set_selected(order)
         has_pred = 0 if isinstance(self.xPred, list) else 1
         xpp = np.zeros((self.N + 1, 6)) if not has_pred else self.xPred
-        o = self._ctx.select_batch(np.asarray(zt, float)[None], np.asarray(zt, float)[None], xpp[None], np.array([has_pred]), np.array([self.timeStep]))
-        ppl = self.numSS_Points // self.numSS_it
+        z = np.asarray(zt, float)[None]
+        o = self._ctx.select_batch(z, z, xpp[None], np.array([has_pred]), np.array([self.timeStep]))    # x0 = zt: no wrap of zt[4] here
         j = order.index(it)
-        ss = np.hstack((o["ssSel"][0, j * ppl:(j + 1) * ppl].T, o["succ"][0, (j + 1) * ppl - 1:(j + 1) * ppl].T))
-        return ss, None, None
+        start = int(o["selStart"][0, j])
+        if start + numPoints > self.SS[it].shape[0]:
+            raise IndexError("safe-set window runs past the end of stored lap %d" % it)
+        rows = np.arange(start, start + numPoints)
+        shift = o["qSel"][0, j * ppl] - self.Qfun[it][start]                  # :502-512, as applied by the library
+        return self.SS[it][rows, :].T, self.uSS[it][rows, :].T, self.Qfun[it][rows] + shift
 
     def _resync_aliased_laps(self):
         """Quirk E-2: xLin may be a VIEW of a stored lap (first solve after addTrajectory, reference :432) -- the

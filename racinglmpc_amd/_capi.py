@@ -48,7 +48,7 @@ EXPORTS = [
     "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun",
     "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
-    "lmpc_comm_unique_id", "lmpc_comm_init", "lmpc_comm_destroy", "lmpc_comm_info", "lmpc_comm_allgather_dev", "lmpc_comm_allgather",
+    "lmpc_lti_regression", "lmpc_comm_unique_id", "lmpc_comm_init", "lmpc_comm_destroy", "lmpc_comm_info", "lmpc_comm_allgather_dev", "lmpc_comm_allgather",
     "lmpc_comm_allreduce_max", "lmpc_comm_barrier", "lmpc_rollout_exchange",
     "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_solver_waves", "lmpc_plant_step_batch", "lmpc_global_position_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap",
 ]
@@ -80,6 +80,15 @@ def comm_unique_id():
     buf = (C.c_ubyte * COMM_ID_BYTES)()
     _chk(load().lmpc_comm_unique_id(buf))
     return bytes(buf)
+
+
+def lti_regression(x, u, lamb, device=0):
+    """Utilities.Regression on the GPU: returns (A (6,6), B (6,2), Error (2,6), status)."""
+    x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+    assert x.ndim == 2 and x.shape[1] == 6 and u.shape == (x.shape[0], 2), (x.shape, u.shape)
+    A = np.zeros((6, 6)); B = np.zeros((6, 2)); E = np.zeros((2, 6)); st = C.c_int()
+    _chk(load().lmpc_lti_regression(C.c_int(int(device)), _d(x), _d(u), C.c_int(x.shape[0]), C.c_double(float(lamb)), _d(A), _d(B), _d(E), C.byref(st)))
+    return A, B, E, st.value
 
 
 def _chk(rc):
@@ -192,9 +201,9 @@ class Context:
         hp = None if hasPred is None else _i32(hasPred)
         ts = None if timeStep is None else _i32(timeStep)
         ss = np.zeros((B, S, 6)); q = np.zeros((B, S)); succ = np.zeros((B, S, 6)); succU = np.zeros((B, S, 2)); ztu = np.zeros((B, 6))
-        st = np.zeros(B, np.int32)
-        _chk(self.lib.lmpc_select_batch(self._h, C.c_int(B), _d(x0), _d(zt), _d(xpp), _d(hp), _d(ts), _d(ss), _d(q), _d(succ), _d(succU), _d(ztu), _d(st)))
-        return dict(ssSel=ss, qSel=q, succ=succ, succU=succU, ztUsed=ztu, status=st)
+        st = np.zeros(B, np.int32); start = np.zeros((B, max(self.cfg.numSS_it, 1)), np.int32)
+        _chk(self.lib.lmpc_select_batch(self._h, C.c_int(B), _d(x0), _d(zt), _d(xpp), _d(hp), _d(ts), _d(ss), _d(q), _d(succ), _d(succU), _d(ztu), _d(start), _d(st)))
+        return dict(ssSel=ss, qSel=q, succ=succ, succU=succU, ztUsed=ztu, selStart=start, status=st)
 
     def qp_solve_batch(self, A, Bm, Cc, x0, uOld, ssSel=None, qSel=None):
         N, S, M = self.N, self.S, self.M

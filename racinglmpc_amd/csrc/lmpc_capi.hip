@@ -428,7 +428,7 @@ int lmpc_regress_batch(lmpc_ctx *c, int B, const double *xLin, int xLinRowStride
 }
 
 int lmpc_select_batch(lmpc_ctx *c, int B, const double *x0, const double *zt, const double *xPredPrev, const int *hasPred, const int *timeStep,
-                      double *ssSel, double *qSel, double *succ, double *succU, double *ztUsed, int *status) {
+                      double *ssSel, double *qSel, double *succ, double *succU, double *ztUsed, int *selStart, int *status) {
     ARGCHK(c && x0 && zt && B >= 1 && B <= c->cfg.max_batch && c->cfg.numSS_it > 0);
     const int N = c->cfg.N, S = c->cfg.numSS_points;
     HIPCHK(hipSetDevice(c->cfg.device));
@@ -439,7 +439,10 @@ int lmpc_select_batch(lmpc_ctx *c, int B, const double *x0, const double *zt, co
     lmpc_solve_io io; memset(&io, 0, sizeof(io));
     io.mode = 1; io.x0 = c->w_x0; io.zt = c->w_zt; io.xPredPrev = c->w_xPP; io.hasPred = c->w_hasPred; io.timeStep = c->w_tstep;
     io.ssSelOut = c->w_ssSel; io.qSelOut = c->w_qSel; io.succOut = c->w_succ; io.succUOut = c->w_succU; io.ztUsed = c->w_ztUsed; io.status = c->w_status; io.iters = c->w_iters;
+    io.selStartOut = c->w_rstatus;                       // B x numSS_it <= B x N ints fit the regression status buffer when numSS_it <= N
+    ARGCHK(c->cfg.numSS_it <= c->cfg.N);
     int rc = launch_solve(c, B, io); if (rc) return rc;
+    D2H(selStart, c->w_rstatus, (size_t)B * c->cfg.numSS_it);
     D2H(ssSel, c->w_ssSel, (size_t)B * S * 6); D2H(qSel, c->w_qSel, (size_t)B * S); D2H(succ, c->w_succ, (size_t)B * S * 6); D2H(succU, c->w_succU, (size_t)B * S * 2);
     D2H(ztUsed, c->w_ztUsed, (size_t)B * 6); D2H(status, c->w_status, B);
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -737,6 +740,28 @@ int lmpc_ss_extend_lap(lmpc_ctx *c, int lap, const double *x, const double *u, i
     (void)hipFree(d_rows);
     if (e != hipSuccess) return set_err(LMPC_E_HIP, "lmpc_ss_extend_lap", hipGetErrorString(e));
     c->s_len[lap] += n; c->s_qlast[lap] = q;
+    return LMPC_OK;
+}
+
+int lmpc_lti_regression(int device, const double *x, const double *u, int T, double lamb, double *A, double *B, double *Error, int *status) {
+    // Utilities.Regression (fnc/Utilities.py:5-28), called by main.py:74-77 before any controller exists: no context needed
+    ARGCHK(x && u && A && B && Error && T >= 3);
+    HIPCHK(hipSetDevice(device));
+    double *d; HIPCHK(hipMalloc(&d, sizeof(double) * ((size_t)T * 8 + 60) + sizeof(int)));
+    double *dx = d, *du = d + (size_t)T * 6, *dout = du + (size_t)T * 2; int *dst = (int *)(dout + 60);
+    hipError_t e = hipMemcpy(dx, x, sizeof(double) * (size_t)T * 6, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(du, u, sizeof(double) * (size_t)T * 2, hipMemcpyHostToDevice);
+    double hout[60]; int hst = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(lmpc_lti_regress_kernel, dim3(1), dim3(LTI_NT), 0, 0, (const double *)dx, (const double *)du, T, lamb, dout, dst);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(hout, dout, sizeof(hout), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&hst, dst, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return set_err(LMPC_E_HIP, "lmpc_lti_regression", hipGetErrorString(e));
+    memcpy(A, hout, sizeof(double) * 36); memcpy(B, hout + 36, sizeof(double) * 12); memcpy(Error, hout + 48, sizeof(double) * 12);
+    if (status) *status = hst;
     return LMPC_OK;
 }
 

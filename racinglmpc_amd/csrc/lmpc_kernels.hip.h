@@ -85,6 +85,7 @@ struct lmpc_solve_io {
     const int *rstatus;       // optional per-point status of the regression kernel (B x N): OR-ed into status[b] (the reference raises there)
     double *xPred, *uPred, *slack, *lambda, *sTerm, *mu, *ztNext, *ztuNext;
     double *ssSelOut, *qSelOut, *succOut, *succUOut, *ztUsed, *resid;
+    int *selStartOut;         // optional: first row of the 13-row window per selected lap (B x numSS_it)
     int *status, *iters;
     long long *tbuf;          // optional cycle stamps of problem 0 (builds with -DLMPC_TIMING only)
 };
@@ -754,7 +755,7 @@ __device__ __forceinline__ void k2_select(const lmpc_dev_params &p, const lmpc_s
             wave_argmin(best, bi);                                              // np.argmin: first minimum
             const int MinNorm = bi;
             const int start = ((double)MinNorm - (double)npw / 2.0 >= 0.0) ? MinNorm - npw / 2 : MinNorm;   // :492-495
-            if (lane == 0) { sel_start[l] = start; if (start + npw > T) atomicOr(st_sh, LMPC_ST_WINDOW); }
+            if (lane == 0) { sel_start[l] = start; if (io.selStartOut) io.selStartOut[(size_t)b * p.L + l] = start; if (start + npw > T) atomicOr(st_sh, LMPC_ST_WINDOW); }
             double shift = 0.0;                                                 // :502-512
             if (hasPred && crossed > 0) {
                 if (p.sslapid[l] < p.cur_it - 1) shift = base[8 * ls];
@@ -1478,6 +1479,88 @@ __global__ void lmpc_rollout_plant_kernel(lmpc_dev_params p, int B, int t, lmpc_
             for (int j = 0; j < 6; j++) { r.finX[(size_t)b * 6 + j] = xo[j]; r.finG[(size_t)b * 6 + j] = go[j]; }
         }
     }
+}
+
+// =====================================================================================================
+// Utilities.Regression (fnc/Utilities.py:5-28): the LTI model of main.py's second stage (main.py:74-77), one ridge least-squares fit
+// over a whole lap: rows r = 0..T-3, z_r = [x_{r+1}, u_{r+1}] (8), y_r = x_{r+2} (6); W = (Z'Z + lamb I)^-1 Z'Y; A = W'[:, 0:6],
+// B = W'[:, 6:8]; Error = [max_r; min_r] of (Z W - Y) per column.  One work-group: 84 accumulated sums (36 Gram + 48 right-hand side
+// entries) x 12 row slices, an 8 x 8 Cholesky per output column, then the residual extrema by a block reduction.
+// out: A (36, row-major 6 x 6) | B (12, 6 x 2) | Error (12, 2 x 6).  status: LMPC_ST_REG_SINGULAR if Z'Z + lamb I is not positive definite.
+// =====================================================================================================
+#define LTI_NT 1024
+#define LTI_PARTS 12
+__global__ __launch_bounds__(LTI_NT) void lmpc_lti_regress_kernel(const double *__restrict__ x, const double *__restrict__ u, int T, double lamb,
+                                                                  double *__restrict__ out, int *__restrict__ status) {
+    __shared__ double part[LTI_PARTS][84];
+    __shared__ double G[8][8], bv[8][6], W[8][6];
+    __shared__ double emax[LTI_NT / WAVE][6], emin[LTI_NT / WAVE][6];
+    __shared__ int bad_s;
+    const int tid = threadIdx.x, R = T - 2;
+    auto zval = [&](int r, int i) { return i < 6 ? x[(size_t)(r + 1) * 6 + i] : u[(size_t)(r + 1) * 2 + (i - 6)]; };
+    if (tid == 0) bad_s = 0;
+    if (tid < 84 * LTI_PARTS) {
+        const int e = tid % 84, p = tid / 84;
+        int i, j; bool rhs = e >= 36;
+        if (!rhs) { i = 0; j = e; while (j >= 8 - i) { j -= 8 - i; i++; } j += i; }          // upper-triangular (i, j)
+        else { i = (e - 36) / 6; j = (e - 36) % 6; }
+        double acc = 0.0;
+        for (int r = p; r < R; r += LTI_PARTS) acc = fma(zval(r, i), rhs ? x[(size_t)(r + 2) * 6 + j] : zval(r, j), acc);
+        part[p][e] = acc;
+    }
+    __syncthreads();
+    if (tid < 84) {
+        double acc = 0.0;
+        for (int p = 0; p < LTI_PARTS; p++) acc += part[p][tid];
+        if (tid < 36) { int i = 0, j = tid; while (j >= 8 - i) { j -= 8 - i; i++; } j += i; if (i == j) acc += lamb; G[i][j] = acc; G[j][i] = acc; }
+        else bv[(tid - 36) / 6][(tid - 36) % 6] = acc;
+    }
+    __syncthreads();
+    if (tid < 6) {                                            // column tid of W: Cholesky G = L L', two triangular solves
+        double L[8][8]; int bad = 0;
+        for (int j = 0; j < 8; j++) {
+            double d = G[j][j];
+            for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+            if (!(d > 0.0)) { bad = 1; d = 1.0; }
+            d = sqrt(d); L[j][j] = d;
+            for (int r = j + 1; r < 8; r++) { double v = G[r][j]; for (int k = 0; k < j; k++) v -= L[r][k] * L[j][k]; L[r][j] = v / d; }
+        }
+        double y[8];
+        for (int r = 0; r < 8; r++) { double v = bv[r][tid]; for (int k = 0; k < r; k++) v -= L[r][k] * y[k]; y[r] = v / L[r][r]; }
+        for (int r = 7; r >= 0; r--) { double v = y[r]; for (int k = r + 1; k < 8; k++) v -= L[k][r] * y[k]; y[r] = v / L[r][r]; }
+        for (int r = 0; r < 8; r++) W[r][tid] = y[r];
+        if (bad) atomicOr(&bad_s, 1);
+    }
+    __syncthreads();
+    double mx[6], mn[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) { mx[c] = -INFINITY; mn[c] = INFINITY; }
+    for (int r = tid; r < R; r += LTI_NT) {
+        double z[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) z[i] = zval(r, i);
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            double e = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) e = fma(z[i], W[i][c], e);
+            e -= x[(size_t)(r + 2) * 6 + c];
+            mx[c] = fmax(mx[c], e); mn[c] = fmin(mn[c], e);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) { mx[c] = wave_max(mx[c]); mn[c] = wave_min(mn[c]); }
+    if ((tid & (WAVE - 1)) == 0) { for (int c = 0; c < 6; c++) { emax[tid >> 6][c] = mx[c]; emin[tid >> 6][c] = mn[c]; } }
+    __syncthreads();
+    if (tid < 36) out[tid] = W[tid % 6][tid / 6];                                  // A[c][i] = W[i][c]
+    else if (tid < 48) out[tid] = W[6 + (tid - 36) % 2][(tid - 36) / 2];           // B[c][j] = W[6 + j][c]
+    else if (tid < 60) {
+        const int c = (tid - 48) % 6; const bool is_min = tid >= 54;
+        double v = is_min ? INFINITY : -INFINITY;
+        for (int w = 0; w < LTI_NT / WAVE; w++) v = is_min ? fmin(v, emin[w][c]) : fmax(v, emax[w][c]);
+        out[tid] = v;
+    }
+    if (tid == 0) *status = bad_s ? LMPC_ST_REG_SINGULAR : 0;
 }
 
 // wave-reduction self test (exercised by lmpc_selftest): out[0..2] = sum, max, min of lane-dependent values

@@ -419,3 +419,22 @@ def test_global_position_batch(g):
     assert st2[0] == 4 and st2[1] == 0                                     # LMPC_ST_NO_SEGMENT where the reference raises
     assert np.allclose(xy2[1], orc.get_global_position(t["track"], 1.0, 0.1), atol=1e-13)
     ctx.close()
+
+
+def test_lti_regression_kernel_matches_reference(built):
+    """Utilities.Regression (main.py:74-77) as a HIP kernel vs the output of the executed reference function.  The normal matrix
+    has cond 1e5..5e7 and the reference forms an explicit inverse, so agreement is bounded by cond * eps: the stated tolerance is
+    1e-7 * (1 + |ref|) on A and B, 1e-9 on the residual extrema."""
+    from racinglmpc_amd import Utilities
+    from tests.test_oracle_golden import _regression_cases
+    worst = 0.0
+    for name, x, u, lamb, A, B, E, cond in _regression_cases():
+        A2, B2, E2 = Utilities.Regression(x, u, lamb)
+        assert A2.shape == (6, 6) and B2.shape == (6, 2) and E2.shape == (2, 6)
+        err = max((np.abs(A2 - A) / (1 + np.abs(A))).max(), (np.abs(B2 - B) / (1 + np.abs(B))).max())
+        worst = max(worst, err)
+        assert err < 1e-7, (name, err, cond)
+        assert np.abs(E2 - E).max() < 1e-9, (name, np.abs(E2 - E).max())
+    print("LTI regression worst rel err", worst)
+    with pytest.raises(np.linalg.LinAlgError):
+        Utilities.Regression(np.zeros((30, 6)), np.zeros((30, 2)), 0.0)

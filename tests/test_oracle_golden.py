@@ -103,3 +103,20 @@ def test_global_position_oracle_matches_reference_fixture():
     assert np.abs(got - t["xy"]).max() < 1e-12
     with pytest.raises(ValueError):
         orc.get_global_position(pt, float(2 * t["trackLength"]), 0.0)      # wraps to TrackLength exactly: on no segment
+
+
+def _regression_cases():
+    import os
+    g = common.load_lmpc_golden()
+    r = np.load(os.path.join(common.GOLDEN, "regression.npz"))
+    data = dict(pid=(g["xPID"], g["uPID"]), lap0=(g["lapx0"], g["lapu0"]), lap1=(g["lapx1"], g["lapu1"]), short=(g["xPID"][:40], g["uPID"][:40]))
+    return [(str(c), data[str(c)][0], data[str(c)][1], float(r[str(c) + "_lamb"]), r[str(c) + "_A"], r[str(c) + "_B"], r[str(c) + "_Error"], float(r[str(c) + "_cond"]))
+            for c in r["cases"]]
+
+
+def test_lti_regression_restatement_matches_reference():
+    """oracle.lti_regression vs the reference's Utilities.Regression output (fixture from the executed reference function)."""
+    from oracle import lmpc_oracle as orc
+    for name, x, u, lamb, A, B, E, cond in _regression_cases():
+        A2, B2, E2 = orc.lti_regression(x, u, lamb)
+        assert np.array_equal(A2, A) and np.array_equal(B2, B) and np.array_equal(E2, E), name
