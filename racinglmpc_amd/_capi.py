@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblmpc_hip.so")
+LIB_PATH = os.environ.get("LMPC_LIB") or os.path.join(_HERE, "liblmpc_hip.so")      # LMPC_LIB: developer builds (build.build_flavour)
 
 MAX_TRACK_ROWS = 16
 MAX_USED_LAPS = 8

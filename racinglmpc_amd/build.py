@@ -12,6 +12,20 @@ def _current():
     return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
 
 
+def build_flavour(suffix, defines, verbose=False):
+    """Developer builds next to the product library (e.g. the -DLMPC_TIMING flavour of tools/phase_timing.py): liblmpc_hip_<suffix>.so."""
+    out = os.path.join(_HERE, "liblmpc_hip_%s.so" % suffix)
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-unused-value", "-fPIC", "-shared"] + \
+          ["-D" + d for d in defines] + ["-o", out, SRC, "-L/opt/rocm/lib", "-lrccl"]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and _current():
         return OUT

@@ -34,7 +34,7 @@ struct lmpc_ctx {
     double *w_x0, *w_xLin, *w_uLin, *w_uOld, *w_zt, *w_xPP, *w_A, *w_B, *w_C, *w_ssSel, *w_qSel, *w_succ, *w_succU, *w_ztUsed;
     double *w_xPred, *w_uPred, *w_slack, *w_lam, *w_sT, *w_mu, *w_ztN, *w_ztuN, *w_resid;
     int *w_hasPred, *w_tstep, *w_status, *w_iters, *w_rstatus;
-    size_t lds_bytes;
+    size_t lds_bytes, lds_bytes1;            // dynamic LDS per QP: multi-wave kernels / one-wave kernels (solve_lds1)
     int (*solve_launch)(lmpc_ctx *, int, const lmpc_solve_io &);
     int (*solve_launch_mw)(lmpc_ctx *, int, const lmpc_solve_io &);
     int (*solve_launch_mw2)(lmpc_ctx *, int, const lmpc_solve_io &);  // 2 waves per QP, batches between one and two QPs per CU
@@ -46,11 +46,11 @@ struct lmpc_ctx {
 };
 
 template <int N, int S> static int solve_launch_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
-    hipLaunchKernelGGL((lmpc_solve_kernel<N, S>), dim3(B), dim3(WAVE), c->lds_bytes, c->stream, c->dp, B, io);
+    hipLaunchKernelGGL((lmpc_solve_kernel<N, S>), dim3(B), dim3(WAVE), c->lds_bytes1, c->stream, c->dp, B, io);
     return LMPC_OK;
 }
 template <int N, int S> static int solve_launch_retry_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
-    hipLaunchKernelGGL((lmpc_solve_kernel<N, S, true>), dim3(B), dim3(WAVE), c->lds_bytes, c->stream, c->dp, B, io);
+    hipLaunchKernelGGL((lmpc_solve_kernel<N, S, true>), dim3(B), dim3(WAVE), c->lds_bytes1, c->stream, c->dp, B, io);
     return LMPC_OK;
 }
 template <int N, int S> static int solve_launch_mw2_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
@@ -63,22 +63,40 @@ template <int N, int S> static int solve_launch_mw_t(lmpc_ctx *c, int B, const l
 }
 template <int N, int S> static bool try_pick(lmpc_ctx *c, int n, int s) {
     if (n != N || s != S) return false;
-    c->lds_bytes = (size_t)solve_lds<N, S>::tot * sizeof(double);
-    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
+    c->lds_bytes = (size_t)solve_lds<N, S>::tot * sizeof(double); c->lds_bytes1 = (size_t)solve_lds1<N, S>::tot * sizeof(double);
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes1) != hipSuccess) return false;
     if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
     c->solve_launch = &solve_launch_t<N, S>;
     c->solve_launch_mw = &solve_launch_mw_t<N, S>;
     if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
     c->solve_launch_mw2 = &solve_launch_mw2_t<N, S>;
-    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes1) != hipSuccess) return false;
     c->solve_launch_retry = &solve_launch_retry_t<N, S>;
     return true;
 }
+#ifdef LMPC_DEV_FAST
+// developer build (racinglmpc_amd.build.build_flavour("dev", ["LMPC_DEV_FAST"])): only the N = 12 variants, seconds to compile; LMPC_FORCE_NW=<1|2|4>
+// runs the multi-wave template with that many waves per QP at every batch size
+template <int N, int S> static int solve_launch_mw1_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
+    hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 1>), dim3(B), dim3(WAVE), c->lds_bytes, c->stream, c->dp, B, io);
+    return LMPC_OK;
+}
+static int (*g_dev_mw1)(lmpc_ctx *, int, const lmpc_solve_io &) = nullptr;
+static bool pick_solver(lmpc_ctx *c) {
+    const int n = c->cfg.N, s = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0;
+    if (try_pick<12, 48>(c, n, s)) {
+        (void)hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<12, 48, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+        g_dev_mw1 = &solve_launch_mw1_t<12, 48>; return true;
+    }
+    return try_pick<12, 0>(c, n, s);
+}
+#else
 static bool pick_solver(lmpc_ctx *c) {
     const int n = c->cfg.N, s = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0;
     return try_pick<8, 0>(c, n, s) || try_pick<12, 0>(c, n, s) || try_pick<14, 0>(c, n, s) || try_pick<20, 0>(c, n, s) || try_pick<40, 0>(c, n, s) ||
            try_pick<8, 48>(c, n, s) || try_pick<12, 48>(c, n, s) || try_pick<14, 48>(c, n, s) || try_pick<20, 48>(c, n, s) || try_pick<40, 48>(c, n, s);
 }
+#endif
 
 extern "C" {
 
@@ -134,7 +152,7 @@ static int create_body(lmpc_ctx *c) {
     }
     // a variant whose LDS footprint leaves room for one QP per CU (N = 40) keeps three SIMDs idle in the 1-wave kernel at any
     // batch size: always run it with four waves per QP (measured at N=40, B=1024: 2.80 vs 3.52 ms; N=20 and N=14 prefer 1 wave)
-    if (!getenv("LMPC_MW_MAX_BATCH") && 2 * c->lds_bytes > 160 * 1024) c->mw_max_batch = 1 << 30;
+    if (!getenv("LMPC_MW_MAX_BATCH") && 2 * c->lds_bytes1 > 160 * 1024) c->mw_max_batch = 1 << 30;
     HIPCHK(hipStreamCreate(&c->stream));
     const size_t store_elems = (size_t)cfg->max_laps * LMPC_COLS * cfg->max_lap_len;
     HIPCHK(hipMalloc(&c->mstore, store_elems * sizeof(double)));
@@ -382,9 +400,16 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
     const bool term = c->cfg.numSS_it > 0;
     int rc = refresh_params(c, false, term && (io.mode & 1)); if (rc) return rc;
     ev_begin(c, 1);
-    // waves per QP so that every SIMD has a wave: 4 up to one QP per CU, 2 up to two QPs per CU, 1 beyond
+    // waves per QP: 4 up to one QP per CU, 2 up to four QPs per CU (what the multi-wave LDS layout holds: two waves per SIMD), beyond that
+    // the one-wave kernel, whose slim LDS layout keeps six QPs resident per CU
+#ifdef LMPC_DEV_FAST
+    if (const char *f = getenv("LMPC_FORCE_NW")) {
+        const int nw = atoi(f);
+        rc = nw == 4 ? c->solve_launch_mw(c, B, io) : nw == 2 ? c->solve_launch_mw2(c, B, io) : (nw == 1 && g_dev_mw1 && c->cfg.numSS_it > 0) ? g_dev_mw1(c, B, io) : c->solve_launch(c, B, io);
+    } else
+#endif
     rc = (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->solve_launch_mw(c, B, io)
-       : (B <= 2 * c->n_cu && c->mw_max_batch == c->n_cu && !io.tbuf) ? c->solve_launch_mw2(c, B, io) : c->solve_launch(c, B, io);
+       : (B <= 4 * c->n_cu && c->mw_max_batch == c->n_cu && !io.tbuf) ? c->solve_launch_mw2(c, B, io) : c->solve_launch(c, B, io);
     ev_end(c);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -780,7 +805,7 @@ int lmpc_selftest(lmpc_ctx *c) {
     return LMPC_OK;
 }
 
-int lmpc_solver_waves(lmpc_ctx *c, int B) { if (!c) return LMPC_E_ARG; return B <= c->mw_max_batch ? 4 : (B <= 2 * c->n_cu && c->mw_max_batch == c->n_cu) ? 2 : 1; }
+int lmpc_solver_waves(lmpc_ctx *c, int B) { if (!c) return LMPC_E_ARG; return B <= c->mw_max_batch ? 4 : (B <= 4 * c->n_cu && c->mw_max_batch == c->n_cu) ? 2 : 1; }
 
 int lmpc_set_profiling(lmpc_ctx *c, int on) { ARGCHK(c); c->profiling = on ? 1 : 0; return LMPC_OK; }
 static int drain_events(lmpc_ctx *c) {

@@ -661,7 +661,7 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
         // unsymmetrised, that asymmetry feeds back into the symmetric part at first order (it cost definiteness near convergence
         // at N = 40).  One cross-lane transpose per stage removes it.
         Piq = 0.5 * (Piu + lane_gather(Piu, c.qT));
-        Phi[k * 64 + c.qR * 8 + c.qC] = Phq; PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
+        Phi[k * 64 + c.qR * 8 + c.qC] = Phq; if (PiAll) PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
         if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 3 ? i11 : i01);
     }
     return bad;
@@ -682,6 +682,44 @@ template <int N, int S> struct solve_lds {
     static constexpr int oMt = oct + WAVE, oWl = oMt + (S > 0 ? 8 * WAVE : 0), oMc = oWl + (S > 0 ? 64 : 0);   // M transposed (col-major, 8 per column), Gram matrix, M c~
     static constexpr int oSS = oMc + 8, oQsel = oSS + 6 * S, oy7 = oQsel + S, oz7 = oy7 + 8, ow7 = oz7 + 8, oPiT = ow7 + 8, osT = oPiT + 36;
     static constexpr int opar = osT + 8, tot = opar + PAR_TOT;
+};
+
+// LDS layout of the ONE-WAVE kernel (lmpc_solve_kernel).  Per-QP footprint decides how many QPs a CU holds (160 KB / footprint), so
+// everything with a bounded lifetime inside one Newton iteration shares a scratch region SCR:
+//   t1  terminal factor   : Mt (M transposed, 8 x 64) | Wl (Gram matrix)
+//   t2  stage recursion   : Phi_k, full 8 x 8 tiles (read back once into the sweep registers; rows 6, 7 are kept in PhiK)
+//   t3+ Newton solves ... : h / dm | dx du ds dl | gamma (= phi = dnu) | gu' | costates p | k0 | eta | e | c~ | costate right-hand sides
+// and the cost-to-go Hessians Pi_k are not stored at all (the equality multipliers follow from a backward recursion with A_k').
+// N = 12, S = 48: 24.5 KB per QP = 6 QPs per CU (the multi-wave layout above: 39.1 KB = 4).
+template <int N, int S> struct solve_lds1 {
+    static constexpr int M = 8 * N + S;
+    static constexpr int oAB = 0, oC = oAB + 48 * N;
+    static constexpr int ox = oC + 6 * N, ou = ox + 6 * (N + 1), os = ou + 2 * N, olam = os + 2 * N, onu = olam + S;
+    static constexpr int om = onu + 6 * N, oth = om + M;
+    static constexpr int orx = oth + M, oru = orx + 6 * (N + 1), ors = oru + 2 * N, orl = ors + 2 * N;
+    static constexpr int oPhiK = orl + S, oMi = oPhiK + 16 * N, okap = oMi + 4 * N, orDs = okap + 2 * N;
+    static constexpr int oRi = orDs + 2 * N, orsq = oRi + 56, oMc = orsq + WAVE;
+    static constexpr int oSS = oMc + 8, oQsel = oSS + 6 * S, oy7 = oQsel + S, oz7 = oy7 + 8, ow7 = oz7 + 8, oPiT = ow7 + 8, osT = oPiT + 36;
+    static constexpr int opar = osT + 8, oscr = opar + PAR_TOT;
+    // scratch region, by phase
+    static constexpr int oMt = oscr, oWl = oMt + 8 * WAVE;                                     // t1
+#ifdef LMPC_DBG_NOALIAS
+    static constexpr int oPhi = oscr + 8 * WAVE + 64;
+    static constexpr int oh = oPhi + 64 * N;
+#else
+    static constexpr int oPhi = oscr;                                                          // t2
+    static constexpr int oh = oscr;
+#endif
+    static constexpr int odm = oh, odx = oh + M, odu = odx + 6 * (N + 1), ods = odu + 2 * N, odl = ods + 2 * N;   // t3+
+    static constexpr int ogam = odl + S, odnu = ogam, ogup = ogam + 8 * N, opst = ogup + 2 * N, ok0 = opst + 8 * (N + 1);
+    static constexpr int oeta = ok0 + 2 * N, oe = oeta + 2 * N, oct = oe + 2 * N, ott = oct + WAVE, oend3 = ott + 6 * N;
+    static constexpr int scr1 = S > 0 ? 8 * WAVE + 64 : 0, scr2 = 64 * N, scr3 = oend3 - oscr;
+    static constexpr int scr = scr1 > scr2 ? (scr1 > scr3 ? scr1 : scr3) : (scr2 > scr3 ? scr2 : scr3);
+#ifdef LMPC_DBG_NOALIAS
+    static constexpr int tot = oend3;
+#else
+    static constexpr int tot = oscr + scr;
+#endif
 };
 
 #define FOR_LANES(idx, n) for (int idx = lane; idx < (n); idx += WAVE)
@@ -788,9 +826,10 @@ __device__ __forceinline__ void k2_select(const lmpc_dev_params &p, const lmpc_s
 }
 
 template <int N, int S, bool EQ = false>
-__global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
+// (two waves per SIMD -- at most 256 registers -- only where the LDS footprint lets more than four QPs share a CU)
+__global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024) ? 2 : 1) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
     extern __shared__ double sm[];
-    using LL = solve_lds<N, S>;
+    using LL = solve_lds1<N, S>;
     constexpr int M = LL::M;
     constexpr bool term = S > 0;
     constexpr int RPL = (M + WAVE - 1) / WAVE;              // inequality rows per lane
@@ -805,7 +844,8 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
     double *dx = sm + LL::odx, *du = sm + LL::odu, *ds = sm + LL::ods, *dl = sm + LL::odl, *nu = sm + LL::onu, *dnu = sm + LL::odnu;
     double *m = sm + LL::om, *th = sm + LL::oth, *h = sm + LL::oh, *dm = sm + LL::odm;
     double *rx = sm + LL::orx, *ru = sm + LL::oru, *rs = sm + LL::ors, *rl = sm + LL::orl;
-    double *Phi = sm + LL::oPhi, *PiAll = sm + LL::oPiAll, *Mi = sm + LL::oMi, *gam = sm + LL::ogam, *gup = sm + LL::ogup, *pst = sm + LL::opst, *k0 = sm + LL::ok0;
+    double *Phi = sm + LL::oPhi, *PhiK = sm + LL::oPhiK, *Mi = sm + LL::oMi, *gam = sm + LL::ogam, *gup = sm + LL::ogup, *pst = sm + LL::opst, *k0 = sm + LL::ok0;
+    double *tt = sm + LL::ott;                             // right-hand sides of the costate recursion
     double *phi = gam;                                     // gamma is dead (kept in registers) once the backward sweep starts
     double *kap = sm + LL::okap, *rDs = sm + LL::orDs, *eta = sm + LL::oeta, *ee = sm + LL::oe;
     double *Ri = sm + LL::oRi, *rsq = sm + LL::orsq, *ct = sm + LL::oct, *Mt = sm + LL::oMt, *Wl = sm + LL::oWl, *McL = sm + LL::oMc;
@@ -914,15 +954,16 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         double c_t = 0.0;
         if constexpr (term) {
             if (lane < S) c_t = (rl[lane] + h[8 * N + lane]) * rsq[lane];
-            ct[lane] = c_t;
+            ct[lane] = lane < S ? c_t * rsq[lane] : 0.0;       // D^-1/2 c~ (the slack columns of M meet zeros of c~)
         }
         __syncthreads();
         if constexpr (term) {
-            // M c~ : lane (j, part) adds 8 of the 64 columns, the 8 lanes of a group are summed with DPP
+            // M c~ = [SS; 1'] (D^-1/2 c~): lane (j, part) adds every 8th column, the 8 lanes of a group are summed with DPP.
+            // (M itself -- the Mt tile of the terminal factor -- is gone by now: its LDS holds the Newton-solve temporaries.)
             double acc = 0.0;
             if (lg < 7) {
 #pragma unroll
-                for (int q = 0; q < 8; q++) acc = fma(Mt[(lc + 8 * q) * 8 + lg], ct[lc + 8 * q], acc);
+                for (int c = lc; c < S; c += 8) acc = lg < 6 ? fma(SS[lg * S + c], ct[c], acc) : acc + ct[c];
             }
             acc = sum_over_c(acc);
             if (lg < 7 && lc == 0) McL[lg] = acc;
@@ -931,8 +972,8 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             const int k = i >> 3, c = i & 7;
             double v = 0.0;
             if (c < 6) { v = rx[k * 6 + c]; v -= Fx[c] * eta[2 * k] + Fx[6 + c] * eta[2 * k + 1]; }
-            v = fma(Phi[k * 64 + 48 + c], gup[2 * k], v);
-            v = fma(Phi[k * 64 + 56 + c], gup[2 * k + 1], v);
+            v = fma(PhiK[k * 16 + c], gup[2 * k], v);
+            v = fma(PhiK[k * 16 + 8 + c], gup[2 * k + 1], v);
             gam[i] = v;
         }
         __syncthreads();
@@ -1201,13 +1242,15 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             __syncthreads();
         }
         TSTAMP(12);
-        numeric_bad |= ricc_factor<N, term>(rc, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
+        numeric_bad |= ricc_factor<N, term>(rc, AB, kap, th, Qf2, PiT, Phi, (double *)nullptr, Mi);
         // a breakdown of the factorisation once the iterate is optimal to working accuracy (gap at its floor, residuals small: the
         // barrier weights span > 1e26 there) is reported as INEXACT, not as a failure: the iterate whose residuals were just measured is returned
         if (numeric_bad) { if (lane == 0) atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_NUMERIC); break; }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < N; k++) ph[k] = (k & 1) ? Phi[k * 64 + lc * 8 + lg] : Phi[k * 64 + lg * 8 + lc];
+        FOR_LANES(i, 16 * N) PhiK[i] = Phi[(i >> 4) * 64 + 48 + (i & 15)];       // rows 6, 7 (= -K_k) outlive the scratch tiles
+        __syncthreads();                                                         // the tiles are dead from here on: the region is reused
 
         TSTAMP(13);
         // ---- predictor (affine scaling) direction: h = mu -------------------------------------------------
@@ -1279,27 +1322,56 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
             }
         }
         TSTAMP(17);
-        // ---- multipliers of the equality rows (costates): nu_k = -(Pi_k xi_k + p_k)_x, all stages at once ----
+        // ---- multipliers of the equality rows (costates) -------------------------------------------------------------------
+        // The x-rows of the Newton system read  2Q dx_k + Fx' dmu_k + dnu_k - A_k' dnu_{k+1} = -rx_k  (dmu_k: the step of the stage's two
+        // lane-boundary multipliers, just computed), so y_k = -dnu_k obeys  y_k = A_k' y_{k+1} + tt_k,  tt_k = rx_k + 2Q dx_k + Fx' dmu_k,
+        // y_N = tt_N = rx_N + 2Qf dx_N - T ds_T: a backward recursion over stage data that is in LDS anyway -- the cost-to-go Hessians
+        // Pi_k need not be kept (6 KB per QP at N = 12).  Same register scheme as the sweeps (alternating sum over c / sum over g).
         if constexpr (term) {
             ss_times<S>(SS, dl, dx + N * 6, w7, lane);                                                // d s_T
         }
         __syncthreads();
         FOR_LANES(i, 6 * N) {
-            const int k = i / 6 + 1, c = i % 6;                  // multiplier of the row defining x_k, k = 1..N
-            double g;
+            const int k = i / 6 + 1, c = i % 6;                  // row defining x_k, k = 1..N
+            double g = rx[k * 6 + c];
             if (k == N) {
-                g = rx[N * 6 + c];
 #pragma unroll
                 for (int j = 0; j < 6; j++) g = fma(Qf2[c * 6 + j], dx[N * 6 + j], g);
                 if constexpr (term) g -= T2p[c] * w7[c];
             } else {
-                g = pst[k * 8 + c];
+                g += Fx[c] * dm[2 * k] + Fx[6 + c] * dm[2 * k + 1];                      // Fx' dmu of the stage's two lane rows
 #pragma unroll
-                for (int j = 0; j < 6; j++) g = fma(PiAll[k * 64 + c * 8 + j], dx[k * 6 + j], g);
-                g = fma(PiAll[k * 64 + c * 8 + 6], du[(k - 1) * 2], g);
-                g = fma(PiAll[k * 64 + c * 8 + 7], du[(k - 1) * 2 + 1], g);
+                for (int j = 0; j < 6; j++) g = fma(Q2[c * 6 + j], dx[k * 6 + j], g);
             }
-            dnu[i] = -g;
+            tt[i] = g;
+        }
+        __syncthreads();
+        // the primal / inequality-dual part of the step does not wait for the costates: issued here, it fills the recursion's latency
+        FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
+        FOR_LANES(i, 2 * N) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
+        if constexpr (term) { FOR_LANES(c, S) lam[c] = fma(al, dl[c], lam[c]); }
+        FOR_LANES(r, M) m[r] = fma(ald, dm[r], m[r]);
+        {
+            double aa[N], tm[N];
+#pragma unroll
+            for (int k = 1; k < N; k++) {
+                const bool in = lg < 6 && lc < 6;
+                const double a_ = (k & 1) ? AB[k * 48 + (in ? lc : 0) * 8 + (in ? lg : 0)] : AB[k * 48 + (in ? lg : 0) * 8 + (in ? lc : 0)];
+                aa[k] = in ? a_ : 0.0;
+                const int ix = (k & 1) ? lg : lc;
+                const double t_ = tt[(k - 1) * 6 + (ix < 6 ? ix : 0)];
+                tm[k] = ix < 6 ? t_ : 0.0;
+            }
+            const int i0 = ((N - 1) & 1) ? lc : lg;
+            double pv = tt[(N - 1) * 6 + (i0 < 6 ? i0 : 0)];
+            pv = i0 < 6 ? pv : 0.0;
+            if (lane < 6) dnu[(N - 1) * 6 + lane] = -tt[(N - 1) * 6 + lane];
+#pragma unroll
+            for (int k = N - 1; k >= 1; k--) {
+                double pr = aa[k] * pv;
+                if (k & 1) { pr = sum_over_c(pr); pv = pr + tm[k]; if (lc == 0 && lg < 6) dnu[(k - 1) * 6 + lg] = -pv; }
+                else { pr = sum_over_g(pr); pv = pr + tm[k]; if (lg == 0 && lc < 6) dnu[(k - 1) * 6 + lc] = -pv; }
+            }
         }
         double deta = 0.0;
         if constexpr (term) {
@@ -1312,10 +1384,6 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel(lmpc_dev_params p, int
         __syncthreads();
         TSTAMP(18);
         // ---- step ------------------------------------------------------------------------------------------
-        FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
-        FOR_LANES(i, 2 * N) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
-        if constexpr (term) { FOR_LANES(c, S) lam[c] = fma(al, dl[c], lam[c]); }
-        FOR_LANES(r, M) m[r] = fma(ald, dm[r], m[r]);
         FOR_LANES(i, 6 * N) nu[i] = fma(ald, dnu[i], nu[i]);
         eta_m = fma(ald, deta, eta_m);
         __syncthreads();

@@ -20,7 +20,7 @@
 #endif
 
 template <int N, int S, int NW>
-__global__ __launch_bounds__(WAVE *NW) void lmpc_solve_kernel_mw(lmpc_dev_params p, int B, lmpc_solve_io io) {
+__global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_mw(lmpc_dev_params p, int B, lmpc_solve_io io) {
     extern __shared__ double sm[];
     using LL = solve_lds<N, S>;
     constexpr int M = LL::M;

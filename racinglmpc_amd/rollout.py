@@ -77,6 +77,7 @@ class LmpcGeneration:
             raise ValueError("every rank needs at least one rollout (total %d, world %d)" % (total_rollouts, self.world))
         self.parents = None            # [(x, u, x_glob, final12, stored_lap_index)] of the previous generation
         self.last_exchange = None      # (bytes per rank, seconds) of the last all-gather
+        self.last_status = self.last_done = None
 
     def run(self, x0_all=None, xLin0=None, uLin0=None):
         import time
@@ -111,6 +112,7 @@ class LmpcGeneration:
                 if owned[k] and nmin > 0:
                     ctx.ss_extend_lap(self.parents[k][4], rows[k, :nmin, 0:6], rows[k, :nmin, 6:8])
         ctx.rollout_run(self.T_max)
+        _, _, _, self.last_done, self.last_status, _, _ = ctx.rollout_fetch(0, 0)     # per-rollout finish step / accumulated status bits
         t0 = time.perf_counter()
         recs, lens, n_valid = ctx.rollout_exchange(K, self.T_max) if self.comm.backend != "gloo" else self._host_exchange()
         self.last_exchange = (recs[0].nbytes + lens[0].nbytes, time.perf_counter() - t0)

@@ -1,6 +1,6 @@
 """Developer tool: per-phase cycle breakdown of one QP solve (problem 0) inside lmpc_solve_kernel.
 Builds a separate timing variant (liblmpc_hip_timing.so, -DLMPC_TIMING) so the product .so carries no stamps.
-Run on the GPU box:  python tools/phase_timing.py [record]"""
+Build here (python -c 'from racinglmpc_amd import build; build.build_flavour("timing", ["LMPC_TIMING"])'), then on the GPU box:  python tools/phase_timing.py [record]"""
 import ctypes as C
 import collections
 import os
@@ -11,9 +11,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, "racinglmpc_amd", "liblmpc_hip_timing.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC", "-shared", "-DLMPC_TIMING",
-                       "-o", so, os.path.join(ROOT, "racinglmpc_amd", "csrc", "lmpc_capi.hip")])
+from racinglmpc_amd import build as _build
+so = _build.build_flavour("timing", ["LMPC_TIMING"])          # build it in the container first: the .so travels with the snapshot
 from racinglmpc_amd import _capi
 _capi.LIB_PATH = so
 from tests import common
