@@ -32,6 +32,8 @@ extern "C" {
 #define LMPC_E_HIP (-2)            /* a HIP runtime call failed (see lmpc_last_error) */
 #define LMPC_E_CAPACITY (-3)       /* lap store / batch capacity exceeded */
 #define LMPC_E_STATE (-4)          /* call not valid in the current state (e.g. no laps stored) */
+#define LMPC_E_VARIANT (-5)        /* lmpc_create: the solve kernels for this (N, numSS_points) are not part of the library and their shared object
+                                      liblmpc_var_N<N>_S<S>.so (next to liblmpc_hip.so) has not been built yet; racinglmpc_amd builds it on demand */
 
 /* per-problem status bits (status[] outputs); 0 == solved */
 #define LMPC_ST_MAXITER 1          /* interior-point iteration limit hit before tolerances met */
@@ -52,7 +54,7 @@ typedef struct lmpc_ctx lmpc_ctx;
 typedef struct {
     int N;                      /* horizon (reference main.py:43 uses 14; BASELINE metric uses 12) */
     int numSS_it;               /* laps in the safe set per solve; 0 => plain MPC/LTV-MPC, no terminal set */
-    int numSS_points;           /* total safe-set columns (reference: 12 * numSS_it = 48); <= 58 */
+    int numSS_points;           /* total safe-set columns (reference: 12 * numSS_it = 48); any multiple of numSS_it up to 58 */
     int trToUse;                /* laps used by the regression (PredictiveModel usedIt) */
     int maxNumPoint;            /* 7   (PredictiveModel.py:18) */
     double h, lamb, dt;         /* 5, 0.0, 0.1 (PredictiveModel.py:19-21) */

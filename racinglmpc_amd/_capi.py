@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("LMPC_LIB") or os.path.join(_HERE, "liblmpc_hip.so")  
 MAX_TRACK_ROWS = 16
 MAX_USED_LAPS = 8
 COMM_ID_BYTES = 128
+E_VARIANT = -5
 
 ST_MAXITER, ST_REG_SINGULAR, ST_NO_SEGMENT, ST_WINDOW, ST_NUMERIC, ST_NOT_INTERIOR, ST_INEXACT = 1, 2, 4, 8, 16, 32, 64
 
@@ -139,7 +140,12 @@ class Context:
         self.S = cfg.numSS_points if cfg.numSS_it > 0 else 0
         self.M = 8 * self.N + self.S
         self._h = C.c_void_p()
-        _chk(self.lib.lmpc_create(C.byref(cfg), C.byref(self._h)))
+        rc = self.lib.lmpc_create(C.byref(cfg), C.byref(self._h))
+        if rc == E_VARIANT:             # (N, numSS_points) outside the built-in set: compile its shared object once (hipcc, ~20 s), then retry
+            from . import build
+            build.build_variant(self.N, self.S)
+            rc = self.lib.lmpc_create(C.byref(cfg), C.byref(self._h))
+        _chk(rc)
 
     def close(self):
         if self._h:

@@ -4,7 +4,13 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "lmpc_capi.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "lmpc_kernels.hip.h"), os.path.join(_HERE, "csrc", "lmpc_solve_mw.hip.h"), os.path.join(_HERE, "csrc", "lmpc_comm.hip.h"), os.path.join(os.path.dirname(_HERE), "include", "lmpc_hip.h")]
+KDEPS = [os.path.join(_HERE, "csrc", f) for f in ("lmpc_kernels.hip.h", "lmpc_solve_mw.hip.h", "lmpc_variant.hip.h")] + [os.path.join(os.path.dirname(_HERE), "include", "lmpc_hip.h")]
+DEPS = [SRC, os.path.join(_HERE, "csrc", "lmpc_comm.hip.h")] + KDEPS
+VSRC = os.path.join(_HERE, "csrc", "lmpc_variant.hip")
+# (N, numSS_points) pairs compiled into liblmpc_hip.so itself (lmpc_capi.hip: builtin_variant) and the extra ones build() prepares as
+# shared objects of their own, in parallel; anything else is built the first time a Context asks for it
+BUILTIN = {(n, s) for n in (8, 12, 14, 20, 40) for s in (0, 48)}
+EXTRA_VARIANTS = [(10, 48), (16, 48), (24, 48), (30, 48), (12, 24), (12, 36), (16, 36), (10, 0), (16, 0)]
 OUT = os.path.join(_HERE, "liblmpc_hip.so")
 
 
@@ -42,6 +48,40 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
             os.replace(tmp, OUT)
     return OUT
+
+
+def variant_path(N, S):
+    return os.path.join(_HERE, "liblmpc_var_N%d_S%d.so" % (N, S))
+
+
+def build_variant(N, S, force=False):
+    """One (N, numSS_points) instantiation of the solve kernels as liblmpc_var_N<N>_S<S>.so (csrc/lmpc_variant.hip); ~20 s of hipcc."""
+    N, S = int(N), int(S)
+    if not (2 <= N <= 64 and 0 <= S <= 58):
+        raise ValueError("solve kernels exist for 2 <= N <= 64 and numSS_points <= 58 (got N=%d, numSS_points=%d)" % (N, S))
+    out = variant_path(N, S)
+    deps = [VSRC] + KDEPS
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    import fcntl
+    with open(out + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not (os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)):
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            tmp = out + ".tmp%d" % os.getpid()
+            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-unused-value", "-fPIC", "-shared",
+                                   "-DLMPC_VARIANT_TU", "-DLMPC_VAR_N=%d" % N, "-DLMPC_VAR_S=%d" % S, "-o", tmp, VSRC])
+            os.replace(tmp, out)
+    return out
+
+
+def build_all(force=False, variants=None, jobs=None):
+    """The library plus the extra variants, compiled concurrently (one hipcc process each)."""
+    from concurrent.futures import ThreadPoolExecutor
+    todo = list(EXTRA_VARIANTS if variants is None else variants)
+    with ThreadPoolExecutor(max_workers=jobs or min(8, (os.cpu_count() or 2))) as ex:
+        futs = [ex.submit(build, force)] + [ex.submit(build_variant, n, s, force) for n, s in todo]
+        return [f.result() for f in futs]
 
 
 if __name__ == "__main__":

@@ -1,9 +1,9 @@
 // racinglmpc_amd/csrc/lmpc_capi.hip -- host side of liblmpc_hip.so: the C ABI declared in include/lmpc_hip.h.
 // Owns the device lap stores, work buffers, stream and HIP-event timers; launches the kernels of
 // lmpc_kernels.hip.h.  No CPU compute path exists here: if HIP fails, the call fails.
-#include "lmpc_kernels.hip.h"
-#include "lmpc_solve_mw.hip.h"
+#include "lmpc_variant.hip.h"
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -34,69 +34,54 @@ struct lmpc_ctx {
     double *w_x0, *w_xLin, *w_uLin, *w_uOld, *w_zt, *w_xPP, *w_A, *w_B, *w_C, *w_ssSel, *w_qSel, *w_succ, *w_succU, *w_ztUsed;
     double *w_xPred, *w_uPred, *w_slack, *w_lam, *w_sT, *w_mu, *w_ztN, *w_ztuN, *w_resid;
     int *w_hasPred, *w_tstep, *w_status, *w_iters, *w_rstatus;
-    size_t lds_bytes, lds_bytes1;            // dynamic LDS per QP: multi-wave kernels / one-wave kernels (solve_lds1)
-    int (*solve_launch)(lmpc_ctx *, int, const lmpc_solve_io &);
-    int (*solve_launch_mw)(lmpc_ctx *, int, const lmpc_solve_io &);
-    int (*solve_launch_mw2)(lmpc_ctx *, int, const lmpc_solve_io &);  // 2 waves per QP, batches between one and two QPs per CU
-    int (*solve_launch_retry)(lmpc_ctx *, int, const lmpc_solve_io &);   // equal-step re-run of the problems that hit the iteration limit   // 4 waves per QP, used for small batches
+    lmpc_variant_api var;                    // launchers of the (N, numSS_points) instantiation of the solve kernels in use
+    void *var_dl;                            // dlopen handle when that instantiation lives in its own shared object (lmpc_variant.hip)
     int mw_max_batch, n_cu;
     int profiling; std::vector<evpair> events; lmpc_stats stats;
     struct lmpc_rollout_session *ro;
     void *comm; int comm_rank, comm_world;   // RCCL communicator of this rank (lmpc_comm.hip.h); null = single process
 };
 
-template <int N, int S> static int solve_launch_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
-    hipLaunchKernelGGL((lmpc_solve_kernel<N, S>), dim3(B), dim3(WAVE), c->lds_bytes1, c->stream, c->dp, B, io);
-    return LMPC_OK;
-}
-template <int N, int S> static int solve_launch_retry_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
-    hipLaunchKernelGGL((lmpc_solve_kernel<N, S, true>), dim3(B), dim3(WAVE), c->lds_bytes1, c->stream, c->dp, B, io);
-    return LMPC_OK;
-}
-template <int N, int S> static int solve_launch_mw2_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
-    hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 2>), dim3(B), dim3(WAVE * 2), c->lds_bytes, c->stream, c->dp, B, io);
-    return LMPC_OK;
-}
-template <int N, int S> static int solve_launch_mw_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
-    hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 4>), dim3(B), dim3(WAVE * 4), c->lds_bytes, c->stream, c->dp, B, io);
-    return LMPC_OK;
-}
-template <int N, int S> static bool try_pick(lmpc_ctx *c, int n, int s) {
-    if (n != N || s != S) return false;
-    c->lds_bytes = (size_t)solve_lds<N, S>::tot * sizeof(double); c->lds_bytes1 = (size_t)solve_lds1<N, S>::tot * sizeof(double);
-    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes1) != hipSuccess) return false;
-    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
-    c->solve_launch = &solve_launch_t<N, S>;
-    c->solve_launch_mw = &solve_launch_mw_t<N, S>;
-    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes) != hipSuccess) return false;
-    c->solve_launch_mw2 = &solve_launch_mw2_t<N, S>;
-    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes1) != hipSuccess) return false;
-    c->solve_launch_retry = &solve_launch_retry_t<N, S>;
-    return true;
-}
 #ifdef LMPC_DEV_FAST
 // developer build (racinglmpc_amd.build.build_flavour("dev", ["LMPC_DEV_FAST"])): only the N = 12 variants, seconds to compile; LMPC_FORCE_NW=<1|2|4>
 // runs the multi-wave template with that many waves per QP at every batch size
-template <int N, int S> static int solve_launch_mw1_t(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
-    hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 1>), dim3(B), dim3(WAVE), c->lds_bytes, c->stream, c->dp, B, io);
-    return LMPC_OK;
+static int dev_launch_mw1(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
+    const size_t lds = lmpc_variant_launchers<12, 48>::ldsm;
+    hipLaunchKernelGGL((lmpc_solve_kernel_mw<12, 48, 1>), dim3(B), dim3(WAVE), lds, st, p, B, io); return 0;
 }
-static int (*g_dev_mw1)(lmpc_ctx *, int, const lmpc_solve_io &) = nullptr;
-static bool pick_solver(lmpc_ctx *c) {
-    const int n = c->cfg.N, s = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0;
-    if (try_pick<12, 48>(c, n, s)) {
-        (void)hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<12, 48, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
-        g_dev_mw1 = &solve_launch_mw1_t<12, 48>; return true;
-    }
-    return try_pick<12, 0>(c, n, s);
+static bool builtin_variant(lmpc_variant_api *v, int n, int s) {
+    if (n == 12 && s == 48) { (void)hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<12, 48, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmpc_variant_launchers<12, 48>::ldsm);
+                              return lmpc_variant_fill<12, 48>(v); }
+    return n == 12 && s == 0 && lmpc_variant_fill<12, 0>(v);
 }
 #else
-static bool pick_solver(lmpc_ctx *c) {
-    const int n = c->cfg.N, s = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0;
-    return try_pick<8, 0>(c, n, s) || try_pick<12, 0>(c, n, s) || try_pick<14, 0>(c, n, s) || try_pick<20, 0>(c, n, s) || try_pick<40, 0>(c, n, s) ||
-           try_pick<8, 48>(c, n, s) || try_pick<12, 48>(c, n, s) || try_pick<14, 48>(c, n, s) || try_pick<20, 48>(c, n, s) || try_pick<40, 48>(c, n, s);
+template <int N, int S> static bool try_builtin(lmpc_variant_api *v, int n, int s) { return n == N && s == S && lmpc_variant_fill<N, S>(v); }
+static bool builtin_variant(lmpc_variant_api *v, int n, int s) {    // the reference's configurations (main.py:43 N = 14, BASELINE N = 12 / 40) are part of the library
+    return try_builtin<8, 0>(v, n, s) || try_builtin<12, 0>(v, n, s) || try_builtin<14, 0>(v, n, s) || try_builtin<20, 0>(v, n, s) || try_builtin<40, 0>(v, n, s) ||
+           try_builtin<8, 48>(v, n, s) || try_builtin<12, 48>(v, n, s) || try_builtin<14, 48>(v, n, s) || try_builtin<20, 48>(v, n, s) || try_builtin<40, 48>(v, n, s);
 }
 #endif
+// any other (N, numSS_points): liblmpc_var_N<N>_S<S>.so next to this library
+static int load_variant(lmpc_ctx *c, int n, int s) {
+    Dl_info info;
+    if (!dladdr((const void *)&load_variant, &info) || !info.dli_fname) return set_err(LMPC_E_VARIANT, "variant lookup", "cannot locate liblmpc_hip.so");
+    std::string dir(info.dli_fname); const size_t sl = dir.rfind('/'); dir = sl == std::string::npos ? std::string(".") : dir.substr(0, sl);
+    char name[96]; snprintf(name, sizeof(name), "/liblmpc_var_N%d_S%d.so", n, s);
+    const std::string path = dir + name;
+    void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) return set_err(LMPC_E_VARIANT, "solve-kernel variant not built (racinglmpc_amd.build.build_variant(N, numSS_points) makes it)", path.c_str());
+    typedef int (*get_t)(lmpc_variant_api *, int);
+    get_t get = (get_t)dlsym(h, "lmpc_variant_get");
+    const int rc = get ? get(&c->var, LMPC_VARIANT_ABI) : -1;
+    if (rc != 0 || c->var.N != n || c->var.S != s) { dlclose(h); return set_err(rc == -2 ? LMPC_E_ARG : LMPC_E_VARIANT, rc == -2 ? "variant exceeds the LDS of a CU" : "stale or foreign variant library (rebuild it)", path.c_str()); }
+    c->var_dl = h;
+    return LMPC_OK;
+}
+static int pick_solver(lmpc_ctx *c) {
+    const int n = c->cfg.N, s = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0;
+    if (builtin_variant(&c->var, n, s)) return LMPC_OK;
+    return load_variant(c, n, s);
+}
 
 extern "C" {
 
@@ -144,7 +129,7 @@ static int create_body(lmpc_ctx *c) {
     const lmpc_config *cfg = &c->cfg;
     HIPCHK(hipSetDevice(cfg->device));
     // an unsupported (N, numSS_points) pair is an ordinary user error: find that out before anything is allocated
-    if (!pick_solver(c)) return set_err(LMPC_E_ARG, "unsupported (N, numSS_points): built variants are N in {8,12,14,20,40} x numSS_points in {0,48}", "");
+    { const int rc = pick_solver(c); if (rc) return rc; }
     {   // batches that leave SIMDs idle (B <= number of CUs) run the 4-waves-per-QP kernel
         const char *e = getenv("LMPC_MW_MAX_BATCH"); hipDeviceProp_t prop; int cus = 256;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
@@ -152,7 +137,7 @@ static int create_body(lmpc_ctx *c) {
     }
     // a variant whose LDS footprint leaves room for one QP per CU (N = 40) keeps three SIMDs idle in the 1-wave kernel at any
     // batch size: always run it with four waves per QP (measured at N=40, B=1024: 2.80 vs 3.52 ms; N=20 and N=14 prefer 1 wave)
-    if (!getenv("LMPC_MW_MAX_BATCH") && 2 * c->lds_bytes1 > 160 * 1024) c->mw_max_batch = 1 << 30;
+    if (!getenv("LMPC_MW_MAX_BATCH") && 2 * c->var.lds_1w > 160 * 1024) c->mw_max_batch = 1 << 30;
     HIPCHK(hipStreamCreate(&c->stream));
     const size_t store_elems = (size_t)cfg->max_laps * LMPC_COLS * cfg->max_lap_len;
     HIPCHK(hipMalloc(&c->mstore, store_elems * sizeof(double)));
@@ -191,7 +176,7 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     ARGCHK(cfg->track_rows >= 0 && cfg->track_rows <= LMPC_MAX_TRACK_ROWS);
     ARGCHK(cfg->max_batch >= 1 && cfg->max_laps >= 1 && cfg->max_lap_len >= 8);
     lmpc_ctx *c = new lmpc_ctx();                      // value-initialised: every pointer starts as nullptr, so lmpc_destroy is safe at any point
-    c->cfg = *cfg; c->profiling = 0; c->ro = nullptr; c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    c->cfg = *cfg; c->profiling = 0; c->ro = nullptr; c->var_dl = nullptr; c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
     memset(&c->stats, 0, sizeof(c->stats));
     int rc = create_body(c);
     if (rc != LMPC_OK) { const std::string keep = g_err; lmpc_destroy(c); g_err = keep; return rc; }
@@ -213,6 +198,7 @@ int lmpc_destroy(lmpc_ctx *c) {
                     c->w_hasPred, c->w_tstep, c->w_status, c->w_iters, c->w_rstatus};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->var_dl) dlclose(c->var_dl);
     delete c;
     return LMPC_OK;
 }
@@ -405,11 +391,12 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
 #ifdef LMPC_DEV_FAST
     if (const char *f = getenv("LMPC_FORCE_NW")) {
         const int nw = atoi(f);
-        rc = nw == 4 ? c->solve_launch_mw(c, B, io) : nw == 2 ? c->solve_launch_mw2(c, B, io) : (nw == 1 && g_dev_mw1 && c->cfg.numSS_it > 0) ? g_dev_mw1(c, B, io) : c->solve_launch(c, B, io);
+        rc = nw == 4 ? c->var.launch_mw4(c->stream, c->dp, B, io) : nw == 2 ? c->var.launch_mw2(c->stream, c->dp, B, io)
+           : (nw == 1 && c->var.N == 12 && c->var.S == 48) ? dev_launch_mw1(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     } else
 #endif
-    rc = (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->solve_launch_mw(c, B, io)
-       : (B <= 4 * c->n_cu && c->mw_max_batch == c->n_cu && !io.tbuf) ? c->solve_launch_mw2(c, B, io) : c->solve_launch(c, B, io);
+    rc = (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->var.launch_mw4(c->stream, c->dp, B, io)
+       : (B <= 4 * c->n_cu && c->mw_max_batch == c->n_cu && !io.tbuf) ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     ev_end(c);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -419,7 +406,7 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
         // into the dual residual, the next equal step is blocked) -- about 6 problems per million in closed loop end at the iteration
         // limit that way, and most of them converge in 10-12 iterations from the start point with equal steps only.  A second launch
         // (1-wave kernel, equal-step variant) re-runs exactly those: every other work-group returns at once (~1.5 us per launch).
-        rc = c->solve_launch_retry(c, B, io);
+        rc = c->var.launch_retry(c->stream, c->dp, B, io);
         if (rc) return rc;
         HIPCHK(hipGetLastError());
     }

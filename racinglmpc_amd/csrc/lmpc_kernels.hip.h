@@ -17,6 +17,7 @@
 #include "../../include/lmpc_hip.h"
 
 #define WAVE 64
+#define LMPC_VARIANT_ABI 2              // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change
 #define LMPC_COLS 9                 // lap-store columns: x0..x5, u0, u1, Qfun
 
 struct lmpc_dev_params {
@@ -164,6 +165,7 @@ __device__ __forceinline__ double frsqrt(double x) {
     return y;
 }
 
+#ifndef LMPC_VARIANT_TU
 // Map.getGlobalPosition, Track.py:135-189: curvilinear (s, ey) -> inertial (X, Y), one thread per point (batched plotting /
 // logging export of predicted trajectories and safe-set points).  Row i - 1 of the table wraps to the last
 // row for i = 0, as the reference's negative index does.
@@ -196,6 +198,7 @@ __global__ void lmpc_global_position_kernel(lmpc_dev_params p, int n, const doub
     xy[2 * e] = x; xy[2 * e + 1] = y; status[e] = 0;
 }
 
+#endif  // LMPC_VARIANT_TU
 // =====================================================================================================
 // K1 (block form): regression + linearisation of ALL horizon steps of one problem by one work-group.
 //
@@ -1438,6 +1441,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
 }
 
 
+#ifndef LMPC_VARIANT_TU
 // =====================================================================================================
 // K4: plant integrator + closed-loop bookkeeping for device-resident batched rollouts.
 // One thread per rollout (the plant is 100 dependent Euler sub-steps of ~60 flops: no intra-rollout parallelism).
@@ -1631,6 +1635,8 @@ __global__ __launch_bounds__(LTI_NT) void lmpc_lti_regress_kernel(const double *
     if (tid == 0) *status = bad_s ? LMPC_ST_REG_SINGULAR : 0;
 }
 
+#endif  // LMPC_VARIANT_TU
+#ifndef LMPC_VARIANT_TU
 // wave-reduction self test (exercised by lmpc_selftest): out[0..2] = sum, max, min of lane-dependent values
 __global__ void lmpc_selftest_kernel(double *out) {
     const int lane = threadIdx.x;
@@ -1705,3 +1711,4 @@ __global__ __launch_bounds__(256) void lmpc_assemble_kernel(lmpc_dev_params p, i
         lb[mi + r] = be; ub[mi + r] = be;
     }
 }
+#endif  // LMPC_VARIANT_TU

@@ -1,0 +1,45 @@
+// racinglmpc_amd/csrc/lmpc_variant.hip.h -- one (N, numSS_points) instantiation of the solve kernels behind a small table of launchers.
+//
+// The solve kernels are templates on the horizon N and the number of safe-set columns S (every LDS offset, trip count and register array
+// is a compile-time constant).  The library carries the reference's configurations built in (lmpc_capi.hip: N in {8,12,14,20,40} x S in
+// {0,48}); any other pair -- the reference takes any N (main.py:43) and numSS_Points = 12 numSS_it (initControllerParameters.py:43-44) -- is
+// a shared object of its own, liblmpc_var_N<N>_S<S>.so next to the library (racinglmpc_amd/csrc/lmpc_variant.hip compiled with
+// -DLMPC_VAR_N / -DLMPC_VAR_S; racinglmpc_amd.build.build_variant), loaded by lmpc_create on demand.
+#pragma once
+#include "lmpc_kernels.hip.h"
+#include "lmpc_solve_mw.hip.h"
+
+struct lmpc_variant_api {
+    int N, S;
+    size_t lds_mw, lds_1w;                    // dynamic LDS per QP: multi-wave kernels / one-wave kernels
+    int (*launch_1w)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &);      // lmpc_solve_kernel<N,S>
+    int (*launch_retry)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &);   // lmpc_solve_kernel<N,S,true>
+    int (*launch_mw4)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &);     // lmpc_solve_kernel_mw<N,S,4>
+    int (*launch_mw2)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &);     // lmpc_solve_kernel_mw<N,S,2>
+};
+
+template <int N, int S> struct lmpc_variant_launchers {
+    static constexpr size_t lds1 = (size_t)solve_lds1<N, S>::tot * sizeof(double), ldsm = (size_t)solve_lds<N, S>::tot * sizeof(double);
+    static int l1(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
+        hipLaunchKernelGGL((lmpc_solve_kernel<N, S>), dim3(B), dim3(WAVE), lds1, st, p, B, io); return 0; }
+    static int lr(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
+        hipLaunchKernelGGL((lmpc_solve_kernel<N, S, true>), dim3(B), dim3(WAVE), lds1, st, p, B, io); return 0; }
+    static int l4(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
+        hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 4>), dim3(B), dim3(WAVE * 4), ldsm, st, p, B, io); return 0; }
+    static int l2(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
+        hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 2>), dim3(B), dim3(WAVE * 2), ldsm, st, p, B, io); return 0; }
+};
+
+// fills the table and raises the kernels' dynamic-LDS limit; false if the device refuses (footprint beyond 160 KB)
+template <int N, int S> static bool lmpc_variant_fill(lmpc_variant_api *v) {
+    static_assert(N >= 2 && N <= LMPC_MAX_N && S >= 0 && S + 6 <= WAVE, "unsupported variant");
+    using L = lmpc_variant_launchers<N, S>;
+    v->N = N; v->S = S;
+    v->lds_mw = (size_t)solve_lds<N, S>::tot * sizeof(double); v->lds_1w = (size_t)solve_lds1<N, S>::tot * sizeof(double);
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_1w) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_1w) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_mw) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_mw) != hipSuccess) return false;
+    v->launch_1w = &L::l1; v->launch_retry = &L::lr; v->launch_mw4 = &L::l4; v->launch_mw2 = &L::l2;
+    return true;
+}

@@ -24,12 +24,12 @@ def load_ltv_golden():
     return np.load(os.path.join(GOLDEN, "ltvmpc_n12.npz"))
 
 
-def lmpc_config(g, N=12, max_batch=64, **kw):
+def lmpc_config(g, N=12, max_batch=64, numSS_it=4, numSS_Points=None, **kw):
     from oracle import lmpc_oracle as orc
     from racinglmpc_amd import _capi
     par = orc.QPParams.lmpc_default(N)
     cfg = _capi.config_from(N, par.Q, par.R, par.Qf, par.dR, par.Qslack, par.Fx, par.bx, par.Fu, par.bu, par.xRef,
-                            QterminalSlack=par.QterminalSlack, numSS_Points=48, numSS_it=4, trToUse=4,
+                            QterminalSlack=par.QterminalSlack, numSS_Points=12 * numSS_it if numSS_Points is None else numSS_Points, numSS_it=numSS_it, trToUse=4,
                             track=g["track"], trackLength=float(g["trackLength"]), max_batch=max_batch, **kw)
     return cfg, par
 

@@ -35,3 +35,15 @@ def test_no_cpu_fallback_in_product():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("no CPU oracle", ""), f
+
+
+def test_variant_libraries_build_and_export_their_entry_point(built):
+    """build() leaves one shared object per extra (N, numSS_points) variant next to the library, each exporting lmpc_variant_get."""
+    import ctypes as C
+    from racinglmpc_amd import build
+    for n, s in build.EXTRA_VARIANTS:
+        path = build.variant_path(n, s)
+        assert os.path.exists(path), path
+        lib = C.CDLL(path)
+        assert hasattr(lib, "lmpc_variant_get")
+    assert not (set(build.EXTRA_VARIANTS) & build.BUILTIN)

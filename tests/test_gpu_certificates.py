@@ -238,3 +238,96 @@ def test_regression_status_reaches_device_paths(built):
     ctx.rollout_end()
     assert st[3] & _capi.ST_NO_SEGMENT and np.all(np.delete(st, 3) == 0), st
     ctx.close()
+
+
+@pytest.mark.parametrize("N,numSS_it", [(10, 4), (16, 4), (24, 4), (30, 4), (12, 2), (12, 3), (16, 3)])
+def test_general_horizon_and_safe_set_size(built, N, numSS_it):
+    """(N, numSS_Points) outside the reference's own configurations (main.py:43 takes any N, initControllerParameters.py:43-44 sets
+    numSS_Points = 12 numSS_it): the solve kernels come from liblmpc_var_N<N>_S<S>.so (built by build() / on demand by Context).
+    Every problem of a batch that touches all three kernel routes is certified; two problems are compared with the oracle's optimum of
+    the reference-form QP and the selection with the oracle's selectPoints."""
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    g = common.load_lmpc_golden()
+    S = 12 * numSS_it
+    xP, uP = g["xPID"], g["uPID"]
+    track = np.array(g["track"]); TL = float(g["trackLength"])
+    par = orc.QPParams.lmpc_default(N)
+    par.numSS_Points, par.numSS_it = S, numSS_it
+    for B in (48, 700, 1300):
+        cfg, _ = common.lmpc_config(g, N, max_batch=B, numSS_it=numSS_it)
+        ctx = _capi.Context(cfg)
+        assert ctx.S == S
+        for _ in range(4):
+            ctx.model_add_trajectory(xP, uP); ctx.ss_add_trajectory(xP, uP)
+        tb = (37 * np.arange(B)) % 900
+        rng = np.random.default_rng(99)
+        inp = dict(x0=xP[tb] + rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02]),
+                   xLin=np.stack([xP[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uP[t + 1:t + N + 1] for t in tb]),
+                   uOld=uP[tb].copy(), zt=xP[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
+        out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+        _certify(par, out, inp, what="N=%d numSS_it=%d B=%d (%d wave(s) per QP)" % (N, numSS_it, B, ctx.solver_waves(B)))
+        if B == 48:
+            worst = 0.0
+            for b in (0, 31):
+                A, Bm, C = orc.compute_ltv_dynamics([xP] * 4, [uP] * 4, list(range(4)), track, inp["xLin"][b], inp["uLin"][b], N)
+                z = inp["zt"][b].copy()
+                if z[4] - inp["x0"][b][4] > TL / 2:
+                    z[4] = np.max([z[4] - TL, 0])
+                SSsel, Qsel, Succ, SuccU = orc.terminal_components([xP] * numSS_it, [uP] * numSS_it, [orc.compute_cost(xP, TL)] * numSS_it, [1000] * numSS_it, z,
+                                                                   S, numSS_it, None, numSS_it, int(inp["timeStep"][b]), N, TL)
+                assert np.array_equal(out["ssSel"][b], SSsel.T) and np.array_equal(out["qSel"][b], Qsel)
+                P, q, Ao, l, u = orc.assemble_lmpc_qp(par, A, Bm, C, inp["x0"][b], inp["uOld"][b], SSsel, Qsel)
+                ex, cert = orc.osqp_solve_exact(P, q, Ao, l, u, want=1e-8)
+                w = np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()])
+                worst = max(worst, np.abs(w - ex.x[:8 * N + 6]).max())
+            print("N=%d numSS_it=%d: worst |xu - oracle optimum| %.2e" % (N, numSS_it, worst))
+            assert worst < common.TOL_XU
+        ctx.close()
+
+
+@pytest.mark.parametrize("N", [10, 16])
+def test_general_horizon_plain_mpc(built, N):
+    """No-terminal-set variant (reference MPC class) at horizons outside the built-in set."""
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    gl = common.load_ltv_golden()
+    cfg, _ = common.mpc_config(gl, N, max_batch=8)
+    par = orc.QPParams.mpc_default(N, 0.8)
+    ctx = _capi.Context(cfg)
+    A1, B1 = gl["A"][0][0], gl["B"][0][0]
+    x0 = gl["x0"][:6]; uOld = gl["OldInput"][:6]
+    out = ctx.qp_solve_batch(np.tile(A1[None, None], (6, N, 1, 1)), np.tile(B1[None, None], (6, N, 1, 1)), np.zeros((6, N, 6)), x0, uOld)
+    assert np.all(out["status"] == 0), out["status"]
+    for b in (0, 5):
+        P, q, A, l, u = orc.assemble_mpc_qp(par, A1, B1, None, x0[b], uOld[b])
+        ex, cert = orc.osqp_solve_exact(P, q, A, l, u)
+        w = np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()])
+        assert cert < 1e-8 and np.abs(w - ex.x[:8 * N + 6]).max() < common.TOL_XU
+    ctx.close()
+
+
+def test_unbuilt_variant_is_compiled_on_demand(built):
+    """A horizon nobody prepared (N = 9, no terminal set): lmpc_create answers LMPC_E_VARIANT, the binding compiles
+    liblmpc_var_N9_S0.so with hipcc and retries -- the way an arbitrary main.py:43 N reaches the GPU."""
+    import os
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi, build
+    N = 9
+    path = build.variant_path(N, 0)
+    if os.path.exists(path):
+        os.remove(path)
+    gl = common.load_ltv_golden()
+    cfg, _ = common.mpc_config(gl, N, max_batch=4)
+    h = _capi.C.c_void_p()
+    assert _capi.load().lmpc_create(_capi.C.byref(cfg), _capi.C.byref(h)) == _capi.E_VARIANT and b"build_variant" in _capi.load().lmpc_last_error()
+    ctx = _capi.Context(cfg)                               # builds, then creates
+    assert os.path.exists(path)
+    par = orc.QPParams.mpc_default(N, 0.8)
+    A1, B1 = gl["A"][0][0], gl["B"][0][0]
+    out = ctx.qp_solve_batch(np.tile(A1[None, None], (2, N, 1, 1)), np.tile(B1[None, None], (2, N, 1, 1)), np.zeros((2, N, 6)), gl["x0"][:2], gl["OldInput"][:2])
+    assert np.all(out["status"] == 0)
+    P, q, A, l, u = orc.assemble_mpc_qp(par, A1, B1, None, gl["x0"][0], gl["OldInput"][0])
+    ex, cert = orc.osqp_solve_exact(P, q, A, l, u)
+    assert np.abs(np.concatenate([out["xPred"][0].ravel(), out["uPred"][0].ravel()]) - ex.x[:8 * N + 6]).max() < common.TOL_XU
+    ctx.close()
