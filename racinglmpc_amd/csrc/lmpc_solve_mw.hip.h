@@ -120,13 +120,19 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
     };
     auto rowb = [&](int r) -> double { if (r < 2 * N) return bx[r & 1]; if (r < 6 * N) return bu[(r - 2 * N) & 3]; return 0.0; };
 
-    double t_r[RPL], rt_r[RPL], tp_r[RPL], dt_r[RPL];      // per-thread row state (row = tid + NT j)
+    // Per-thread row state (row = tid + NT j).  The slack t of an inequality row, its reciprocal and the barrier weight theta = mu / t are
+    // carried from iteration to iteration by the thread that owns the row (t <- t + alpha dt with dt = -F dw: the rows are linear, and the
+    // update keeps the relative accuracy of a slack that has shrunk to 1e-13, which b - F w recomputed from the iterate does not); the
+    // terminal slack likewise (s_T <- s_T + alpha ds_T).  One pass over the rows per iteration, together with the step, instead of three.
+    double t_r[RPL], rt_r[RPL], tp_r[RPL], dt_r[RPL];
+    double gsum_c = 0.0;                                   // this thread's share of sum t mu (the complementarity gap)
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
         const int r = tid + NT * j;
         t_r[j] = 1.0; rt_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
-        if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; m[r] = mu0 / tt; }
+        if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam), mm = mu0 / tt; t_r[j] = tt; m[r] = mm; rt_r[j] = frcp(tt); th[r] = mm * rt_r[j]; gsum_c = fma(tt, mm, gsum_c); }
     }
+    if constexpr (term) { if (wave == NW - 1) ss_times<S>(SS, lam, x + N * 6, sT, lane); }      // terminal slack s_T = SS lambda - x_N
     // loop-invariant pieces of the stage Hessian W for this lane's (a, c) = (lg, lc) tile entry (used by wave 0)
     const ricc_consts rc = ricc_setup(lane, Q2, Fx, R2, dR2, Fu);
     double ph[N];
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                     double v = 0.0;
                     for (int j = 0; j <= lane; j++) v = fma(Ri[j * 7 + lane], McL[j], v);
                     y7[lane] = v;
-                    sT[lane] = Ri[6 * 7 + lane] * (-re_sum) + v;
+                    z7[lane] = Ri[6 * 7 + lane] * (-re_sum) + v;   // Ri' d0 + y7 (z7 is free until the forward sweep has finished)
                 }
                 WSYNC();
             }
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 double v = 0.0;
                 if (lane < 6) {
                     v = rx[N * 6 + lane];
-                    if constexpr (term) { for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], sT[j], v); }
+                    if constexpr (term) { for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], z7[j], v); }
                 }
                 pst[N * 8 + lane] = v;
             }
@@ -278,15 +284,8 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
     for (it = 0; it <= p.max_iter; it++) {
         TSMW(10);
         // ---- slacks of the inequality rows, terminal slack --------------------------------------------
-        double gsum = 0.0, rmax = 0.0, remax = 0.0;
-#pragma unroll
-        for (int j = 0; j < RPL; j++) {
-            const int r = tid + NT * j;
-            if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; rt_r[j] = frcp(tt); gsum = fma(tt, m[r], gsum); }
-        }
-        if constexpr (term) { if (wave == NW - 1) ss_times<S>(SS, lam, x + N * 6, sT, lane); }
-        __syncthreads();
-        // ---- residuals (different loops on different waves) --------------------------------------------
+        double gsum = gsum_c, rmax = 0.0, remax = 0.0;
+        // ---- residuals (different loops on different waves; slacks, barrier weights and s_T were refreshed with the step) ----
         for (int i = tid; i < 6 * (N + 1); i += NT) {
             const int k = i / 6, c = i % 6; double v = 0.0;
             if (k >= 1) {
@@ -346,9 +345,6 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
 
         TSMW(11);
         // ---- barrier weights ----------------------------------------------------------------------------
-#pragma unroll
-        for (int j = 0; j < RPL; j++) { const int r = tid + NT * j; if (r < M) th[r] = m[r] * rt_r[j]; }
-        __syncthreads();
         FOR_OFF(i, 2 * N, O1) {
             const double d_ = frcp(a_s + th[i] + th[6 * N + i]);
             rDs[i] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
@@ -498,7 +494,7 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
             if (r < M) {
                 const double dtt = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dmm = -h[r] - th[r] * dtt;
-                dm[r] = dmm;
+                dm[r] = dmm; dt_r[j] = dtt;
                 if (dtt < 0.0) apx = fmin(apx, -t_r[j] * frcp(dtt));
                 if (dmm < 0.0) adx = fmin(adx, -mr * frcp(dmm));
             }
@@ -545,7 +541,16 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
         for (int i = tid; i < 6 * (N + 1); i += NT) x[i] = fma(al, dx[i], x[i]);
         FOR_OFF(i, 2 * N, O1) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
         if constexpr (term) { FOR_OFF(c, S, O2) lam[c] = fma(al, dl[c], lam[c]); }
-        for (int r = tid; r < M; r += NT) m[r] = fma(ald, dm[r], m[r]);
+        gsum_c = 0.0;
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {                         // inequality rows: slack, multiplier, barrier weight, gap share
+            const int r = tid + NT * j;
+            if (r < M) {
+                const double tt = fma(al, dt_r[j], t_r[j]), mm = fma(ald, dm[r], m[r]);
+                t_r[j] = tt; m[r] = mm; rt_r[j] = frcp(tt); th[r] = mm * rt_r[j]; gsum_c = fma(tt, mm, gsum_c);
+            }
+        }
+        if constexpr (term) { if (tid < 6) sT[tid] = fma(al, w7[tid], sT[tid]); }
         FOR_OFF(i, 6 * N, O3) nu[i] = fma(ald, dnu[i], nu[i]);
         eta_m = fma(ald, deta, eta_m);
         __syncthreads();
