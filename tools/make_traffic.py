@@ -1,11 +1,13 @@
-"""tools/make_traffic.py profiles/<tag>  ->  profiles/traffic.json
+"""tools/make_traffic.py profiles/<tag>_B<batch> [...]  ->  profiles/traffic.json   (keys carry the batch size parsed from the tag)
 
 HBM bytes per launch of the two hot kernels from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are collected in separate
 passes, tools/collect_profiles.sh), corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950:
 bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (FETCH_SIZE reports half of wide coalesced reads)."""
 import csv, json, sys, collections
 
+import re, os
 tag = sys.argv[1]
+BK = "B%s_N12" % (re.search(r"_B(\d+)$", tag).group(1) if re.search(r"_B(\d+)$", tag) else "256")
 
 
 def mean_counter(path, name):
@@ -20,8 +22,10 @@ def mean_counter(path, name):
 fetch = mean_counter(tag + "_pmc_pass1.csv", "FETCH_SIZE")
 write = mean_counter(tag + "_pmc_pass2.csv", "WRITE_SIZE")
 out = {}
+if os.path.exists("profiles/traffic.json") and os.environ.get("TRAFFIC_MERGE", "1") == "1":
+    out = json.load(open("profiles/traffic.json"))
 def short_name(kname):
-    if "true>" in kname:                      # the retry variant lmpc_solve_kernel<N, S, true>: every work-group exits at once
+    if "lmpc_solve_kernel<" in kname and "true>" in kname:                      # the retry variant lmpc_solve_kernel<N, S, true>: every work-group exits at once
         return None
     return "lmpc_solve_kernel" if "lmpc_solve_kernel" in kname else ("lmpc_regress_kernel" if "lmpc_regress_kernel" in kname else None)
 
@@ -30,8 +34,8 @@ for kname in fetch:
     short = short_name(kname)
     if short is None:
         continue
-    out[short + "_bytes_per_launch_B256_N12"] = 2 * fetch[kname] * 1024 + write.get(kname, 0.0) * 1024
-    out[short + "_raw"] = {"kernel": kname[:60], "FETCH_SIZE_KB": fetch[kname], "WRITE_SIZE_KB": write.get(kname, 0.0)}
+    out[short + "_bytes_per_launch_" + BK] = 2 * fetch[kname] * 1024 + write.get(kname, 0.0) * 1024
+    out[short + "_raw_" + BK] = {"kernel": kname[:60], "FETCH_SIZE_KB": fetch[kname], "WRITE_SIZE_KB": write.get(kname, 0.0)}
 # instruction mix and utilisation of the solve kernel (passes 3-6), per launch
 def all_counters(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -58,8 +62,8 @@ for short, d in cnt.items():
         d["valu_utilisation"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
     if "SQ_LDS_IDX_ACTIVE" in d and d["SQ_LDS_IDX_ACTIVE"] > 0:
         d["lds_bank_conflict_rate"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
-    out[short + "_counters_B256_N12"] = d
-out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, %s_pmc_pass1/2.csv), mean over the bench launches at B=256, N=12; "
+    out[short + "_counters_" + BK] = d
+out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, %s_pmc_pass1/2.csv), mean over the bench launches, N=12; "
                "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950; "
                "WRITE_SIZE uncalibrated; Infinity-Cache hits are included)." % tag)
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
