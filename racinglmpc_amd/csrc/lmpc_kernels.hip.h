@@ -158,6 +158,15 @@ __device__ __forceinline__ double frcp(double x) {
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }
+// Step rules of the interior-point iteration (both solve kernels; tests/ipm_model.py mirrors them).
+//  * fraction to the boundary: 0.995, and once the predictor says the iteration is in its final phase (centring parameter sigma < 1e-3,
+//    i.e. the affine step alone removes > 90 % of the gap) 1 - 10 gap: the gap then contracts quadratically instead of by 1 / 200 per
+//    step (about one iteration less per solve).  Ungated, the longer step lets single complementarity products collapse while the
+//    iterate is still far from the path (one 38-iteration stall in 1024 problems of the NumPy model); gated it never fired there.
+//  * separate primal / dual step lengths after an iteration whose gap shrank by less than 1 / LMPC_SEP_THRESHOLD.
+#define LMPC_SEP_THRESHOLD 0.1
+__device__ __forceinline__ double step_fraction(double sig, double gap) { return sig < 1e-3 ? fmax(0.995, 1.0 - 10.0 * gap) : 0.995; }
+
 __device__ __forceinline__ double frsqrt(double x) {
     double y = __builtin_amdgcn_rsq(x);
     y = y * fma(-0.5 * x * y, y, 1.5);
@@ -267,7 +276,8 @@ template <bool OCC>
 __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_dev_params p, int B, int qg, const double *__restrict__ xLin, int xstride,
                                                              const double *__restrict__ uLin, double *__restrict__ Aout,
                                                              double *__restrict__ Bout, double *__restrict__ Cout, int *__restrict__ status) {
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave-uniform by construction: lap pointers, row counts and loop bounds stay in SGPRs
     __shared__ double qf[K1_QG][5];                                        // xuLin of the queries in flight (PredictiveModel.py:54)
     __shared__ int cseg[K1_NW][K1_QG][16]; __shared__ int ccnt[K1_NW][K1_QG];   // prefilter survivors (row indices) per wave and query
     __shared__ double seld[K1_QG][LMPC_MAX_USED_LAPS][8]; __shared__ int seli[K1_QG][LMPC_MAX_USED_LAPS][8];
@@ -324,9 +334,12 @@ __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_d
                 for (int j = 0; j < K1_RPL; j++) if (t0 + lane + WAVE * j >= nrows) qv[2][j] |= 0xffff0000u;
                 // ---- step A: integer prefilter, one query at a time; survivors (row indices) go to the query's 16-slot LDS segment ----
                 const int nqw = nq > sgi ? (nq - sgi + nsub - 1) / nsub : 0;                  // queries of this wave: qi = sgi + s nsub
-                // (two queries per trip: their reduction chains are independent and interleave)
-                for (int s = 0; s < nqw; s += 2) {
-                    const bool two = s + 1 < nqw;
+                // (two queries per trip: their reduction chains are independent and interleave.  The occupancy build takes one per trip:
+                //  with four waves per SIMD the other waves fill the chain's latency, and the second query's 16 distances cost registers
+                //  it does not have -- spilled registers are scratch WRITES: 134 MB per launch at batch 4096 before this)
+                constexpr bool PAIR = !OCC;
+                for (int s = 0; s < nqw; s += PAIR ? 2 : 1) {
+                    const bool two = PAIR && s + 1 < nqw;
                     const int qa = sgi + s * nsub, qb2 = two ? qa + nsub : qa;
                     unsigned ta5[5], tb5[5];
 #pragma unroll
@@ -341,14 +354,14 @@ __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_d
                     for (int j = 0; j < K1_RPL; j++) {
                         unsigned a_ = 0, b_ = 0;
 #pragma unroll
-                        for (int k = 0; k < 3; k++) { a_ = sad_u16(qv[k][j], ya[k], a_); b_ = sad_u16(qv[k][j], yb[k], b_); }
+                        for (int k = 0; k < 3; k++) { a_ = sad_u16(qv[k][j], ya[k], a_); if (PAIR) b_ = sad_u16(qv[k][j], yb[k], b_); }
                         ea[j] = a_; eb[j] = b_; ma = a_ < ma ? a_ : ma; mb = b_ < mb ? b_ : mb;
                     }
                     // MAXP-th smallest distinct lane minimum: at least MAXP rows lie at or below it (one-instruction DPP integer minima)
                     unsigned ba = 0u, bb = 0u;
                     for (int r = 0; r < MAXP; r++) {
                         ba = wminu((r == 0 || ma > ba) ? ma : 0xffffffffu);
-                        bb = wminu((r == 0 || mb > bb) ? mb : 0xffffffffu);
+                        if (PAIR) bb = wminu((r == 0 || mb > bb) ? mb : 0xffffffffu);
                     }
                     // Two-sided bound.  Per feature |floor(a) - floor(b)| differs from |a - b| by < 1, so over the five features the
                     // integer distance e of a row and its exact scaled distance d satisfy |e - d| < 5.  (i) At least MAXP rows have
@@ -359,8 +372,8 @@ __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_d
                     int na = 0, nb = 0;
 #pragma unroll
                     for (int j = 0; j < K1_RPL; j++) {
-                        const bool ca = ea[j] <= ta, cb = eb[j] <= tb;
-                        const unsigned long long mka = __ballot(ca), mkb = __ballot(cb);
+                        const bool ca = ea[j] <= ta, cb = PAIR && eb[j] <= tb;
+                        const unsigned long long mka = __ballot(ca), mkb = PAIR ? __ballot(cb) : 0ull;
                         if (mka | mkb) {
                             const int pa = na + __builtin_amdgcn_mbcnt_hi((unsigned)(mka >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mka, 0));
                             const int pb = nb + __builtin_amdgcn_mbcnt_hi((unsigned)(mkb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mkb, 0));
@@ -609,7 +622,10 @@ __device__ __forceinline__ ricc_consts ricc_setup(int lane, const double *Q2, co
 //   T = Pi_{k+1} Ar,  Mr = Ar' T + W_k,  eliminate u_k (2 x 2 pivot M_uu):  Pi_k = Base - U' M_uu^-1 U,  Phi_k = [[A,0],[0,0]] - [B; I] M_uu^-1 U
 // executed by ONE full wave; writes Phi_k, Pi_k (row-major 8 x 8) and M_uu^-1 to LDS for the sweeps.  Returns non-zero if a pivot is not
 // positive.  kap / th must be visible to the calling wave.
-template <int N, bool term>
+// STEP (multi-wave kernel): a work-group barrier closes every stage, so that follower waves can start the predictor's backward sweep one
+// stage behind the recursion instead of after it.  LDS operations of one wave execute in issue order: a wave released by the barrier
+// finds Phi_k, Pi_k and M_uu^-1 of the stage in place, and no s_waitcnt is needed on this side.
+template <int N, bool term, bool STEP = false>
 __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *AB, const double *kap, const double *th, const double *Qf2,
                                            const double *PiT, double *Phi, double *PiAll, double *Mi) {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -666,6 +682,7 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
         Piq = 0.5 * (Piu + lane_gather(Piu, c.qT));
         Phi[k * 64 + c.qR * 8 + c.qC] = Phq; if (PiAll) PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
         if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 3 ? i11 : i01);
+        if constexpr (STEP) { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     }
     return bad;
 }
@@ -751,6 +768,20 @@ template <int S> __device__ __forceinline__ void ss_times(const double *SS, cons
     }
     acc = sum_over_c(acc);
     if (j < 6 && part == 0) out[j] = acc - sub[j];
+}
+
+// Products with the terminal factor R^-1 = Ri (upper triangular 7 x 7, row-major in LDS, zeros below the diagonal) by one wave: lane
+// (i, j) = (lane >> 3, lane & 7) forms one product and the 8 lanes of a group are summed by DPP, so every lane of group i < 7 receives
+// element i of the result -- one LDS round trip and three DPP steps instead of a 7-term chain of broadcast reads on 7 lanes.
+__device__ __forceinline__ double ri_t_times(const double *Ri, const double *b, int lg, int lc) {     // (Ri' b)[lg] = sum_{j <= lg} Ri[j][lg] b[j]
+    const bool on = lg < 7 && lc <= lg;
+    const double v = on ? Ri[(on ? lc : 0) * 7 + (on ? lg : 0)] * b[on ? lc : 0] : 0.0;
+    return sum_over_c(v);
+}
+__device__ __forceinline__ double ri_times(const double *Ri, const double *b, int lg, int lc) {       // (Ri b)[lg] = sum_{j >= lg} Ri[lg][j] b[j]
+    const bool on = lg < 7 && lc >= lg && lc < 7;
+    const double v = on ? Ri[(on ? lg : 0) * 7 + (on ? lc : 0)] * b[on ? lc : 0] : 0.0;
+    return sum_over_c(v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,11 +931,16 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
         }
         __syncthreads();
     }
+    // Lane slacks: a row the roll-out violates starts one unit inside (s = violation + 1); every other slack starts at 1 / c_s, where
+    // the multiplier of s >= 0 (mu0 / s) already balances the slack's linear cost c_s -- from s = 1 the first Newton steps were spent
+    // driving ~2N slacks to zero against the positivity bound (11.0 -> 9.5 iterations on the bench batch, 12 -> 6 on the LTV-MPC QPs)
+    const double s_init = c_s > 1.0 ? 1.0 / c_s : 1.0;
     FOR_LANES(i, 2 * N) {
         const int k = i >> 1, j = i & 1; double f = 0.0;
 #pragma unroll
         for (int c = 0; c < 6; c++) f = fma(Fx[j * 6 + c], x[k * 6 + c], f);
-        s[i] = fmax(f - bx[j], 0.0) + 1.0;
+        const double viol = f - bx[j];
+        s[i] = viol > 0.0 ? viol + 1.0 : s_init;
     }
     double qmax = 0.0;
     if constexpr (term) { FOR_LANES(c, S) { lam[c] = 1.0 / (double)S; qmax = fmax(qmax, fabs(Qsel[c])); } qmax = wmax(qmax); }
@@ -935,6 +971,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
     const ricc_consts rc = ricc_setup(lane, Q2, Fx, R2, dR2, Fu);
     double ph[N];                                          // Phi_k entry this lane multiplies with in the register sweeps
     double mcol[7];                                        // this lane's column of M = [E D^-1/2 | T7^-1/2]
+    const double tsq_lane = (term && lane >= S && lane < S + 6) ? frsqrt(T2p[lane - S]) : 0.0;   // T^-1/2 entry of this lane's slack column of M (loop invariant)
 #pragma unroll
     for (int j = 0; j < 7; j++) mcol[j] = 0.0;
 #pragma unroll
@@ -980,22 +1017,15 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
             gam[i] = v;
         }
         __syncthreads();
-        if constexpr (term) {
-            if (lane < 7) {                                     // y7 = Ri' (M c~) ; sT <- Ri' d0 + y7 (scratch)
-                double v = 0.0;
-                for (int j = 0; j <= lane; j++) v = fma(Ri[j * 7 + lane], McL[j], v);
-                y7[lane] = v;
-                sT[lane] = Ri[6 * 7 + lane] * (-re_sum) + v;
-            }
-            __syncthreads();
-        }
-        if (lane < 8) {                                         // terminal costate p_N = (rx_N + [Ri (Ri' d0 + y7)]_{0:6}, 0)
+        {   // terminal costate p_N = (rx_N + [Ri (Ri' d0 + y7)]_{0:6}, 0), y7 = Ri' (M c~), d0 = (0, -re_sum)
             double v = 0.0;
-            if (lane < 6) {
-                v = rx[N * 6 + lane];
-                if constexpr (term) { for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], sT[j], v); }
+            if constexpr (term) {
+                const double yv = ri_t_times(Ri, McL, lg, lc);
+                if (lc == 0 && lg < 7) { y7[lg] = yv; sT[lg] = fma(Ri[6 * 7 + lg], -re_sum, yv); }      // sT: scratch for Ri' d0 + y7
+                __syncthreads();
+                v = ri_times(Ri, sT, lg, lc);
             }
-            pst[N * 8 + lane] = v;
+            if (lc == 0) pst[N * 8 + lg] = lg < 6 ? rx[N * 6 + lg] + v : 0.0;
         }
         __syncthreads();
         TSTAMP(30);
@@ -1056,18 +1086,17 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
             ds[i] = (th[i] * f + ee[i]) * rDs[i];
         }
         if constexpr (term) {
-            if (lane < 7) {                                     // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum)
-                double v = y7[lane];
-                for (int j = 0; j <= lane; j++) v = fma(Ri[j * 7 + lane], j < 6 ? dx[N * 6 + j] : -re_sum, v);
-                z7[lane] = v;
+            {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
+                if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;               // d7 (w7 is free until omega' is written)
+                __syncthreads();
+                const double zv = ri_t_times(Ri, w7, lg, lc) + y7[lg < 7 ? lg : 0];
+                __syncthreads();
+                if (lc == 0 && lg < 7) z7[lg] = zv;
+                __syncthreads();
+                const double wv = ri_times(Ri, z7, lg, lc);
+                if (lc == 0 && lg < 7) w7[lg] = wv;
+                __syncthreads();
             }
-            __syncthreads();
-            if (lane < 7) {                                     // omega' = Ri z7
-                double v = 0.0;
-                for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], z7[j], v);
-                w7[lane] = v;
-            }
-            __syncthreads();
             double v = -c_t;                                    // v = -c~ + M' omega'
 #pragma unroll
             for (int j = 0; j < 7; j++) v = fma(mcol[j], w7[j], v);
@@ -1143,7 +1172,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
         const double re_sum = term ? wsum(lsum) - 1.0 : 0.0;
         ren = fmax(wmax(remax), fabs(re_sum));
         if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res) { converged = 1; break; }
-        if (gap_prev >= 0.0) sep = !EQ && gap > 0.3 * gap_prev;
+        if (gap_prev >= 0.0) sep = !EQ && gap > LMPC_SEP_THRESHOLD * gap_prev;
         gap_prev = gap;
         if (it == p.max_iter) break;
         if (!(gap == gap) || !(rdn == rdn)) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
@@ -1171,13 +1200,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
             } else {
                 rsq[lane] = 1.0;
 #pragma unroll
-                for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = frsqrt(T2p[j]);
+                for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = tsq_lane;
             }
-            double Rr[7][7], Rv[7][7], rinv[7];
-#pragma unroll
-            for (int i = 0; i < 7; i++)
-#pragma unroll
-                for (int j = 0; j < 7; j++) { Rr[i][j] = 0.0; Rv[i][j] = 0.0; }
+            double Rr[7][7], rinv[7];
             // Gram matrix W = M M' (7 x 7, K = 64 columns) on the matrix cores: v_mfma_f64_16x16x4 over 16 K-chunks.
             // operand layout: lane = 16 k + i holds M[i][4 s + k] for both A and B (W is M times its own transpose);
             // accumulator: lane l, register r holds W[4 r + l / 16][l % 16].
@@ -1187,17 +1212,19 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
             __syncthreads();
             {
                 typedef double v4d __attribute__((ext_vector_type(4)));
-                v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;   // four independent accumulation chains (the dependent latency of this shape is ~100 cycles)
                 const int kk = lane >> 4, ii = lane & 15;
                 const bool live = ii < 8;
 #pragma unroll
-                for (int s_ = 0; s_ < 16; s_ += 2) {
-                    double a0 = Mt[(4 * s_ + kk) * 8 + (ii & 7)], a1 = Mt[(4 * (s_ + 1) + kk) * 8 + (ii & 7)];
-                    a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0;
+                for (int s_ = 0; s_ < 16; s_ += 4) {
+                    double a0 = Mt[(4 * s_ + kk) * 8 + (ii & 7)], a1 = Mt[(4 * (s_ + 1) + kk) * 8 + (ii & 7)], a2 = Mt[(4 * (s_ + 2) + kk) * 8 + (ii & 7)], a3 = Mt[(4 * (s_ + 3) + kk) * 8 + (ii & 7)];
+                    a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0; a2 = live ? a2 : 0.0; a3 = live ? a3 : 0.0;
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc3, 0, 0, 0);
                 }
-                if (ii < 8) { Wl[kk * 8 + ii] = acc0[0] + acc1[0]; Wl[(4 + kk) * 8 + ii] = acc0[1] + acc1[1]; }
+                if (ii < 8) { Wl[kk * 8 + ii] = (acc0[0] + acc1[0]) + (acc2[0] + acc3[0]); Wl[(4 + kk) * 8 + ii] = (acc0[1] + acc1[1]) + (acc2[1] + acc3[1]); }
             }
             __syncthreads();
 #pragma unroll
@@ -1219,22 +1246,20 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
                     Rr[i][j] = v * rinv[i];
                 }
             }
+            {   // Ri = R^-1 (upper): lane j < 7 back-substitutes column j (R is uniform across the lanes), 28 dependent operations instead of 140.
+                // Terms beyond the diagonal multiply exact zeros, so every entry is bit-identical to the column-by-column form.
+                double col[7];
 #pragma unroll
-            for (int j = 0; j < 7; j++) {                                                 // Ri = R^-1 (upper), column by column
-                Rv[j][j] = rinv[j];
-#pragma unroll
-                for (int i = j - 1; i >= 0; i--) {
+                for (int i = 6; i >= 0; i--) {
                     double v = 0.0;
 #pragma unroll
-                    for (int k = i + 1; k <= j; k++) v = fma(-Rr[i][k], Rv[k][j], v);
-                    Rv[i][j] = v * rinv[i];
+                    for (int k = i + 1; k < 7; k++) v = fma(-Rr[i][k], col[k], v);
+                    col[i] = lane == i ? rinv[i] : (lane > i ? v * rinv[i] : 0.0);
                 }
-            }
-            if (lane == 0) {
+                if (lane < 7) {
 #pragma unroll
-                for (int i = 0; i < 7; i++)
-#pragma unroll
-                    for (int j = 0; j < 7; j++) Ri[i * 7 + j] = Rv[i][j];
+                    for (int i = 0; i < 7; i++) Ri[i * 7 + lane] = col[i];
+                }
             }
             __syncthreads();
             if (lane < 36) {                                     // Pi_term = (Ri Ri')[0:6,0:6]
@@ -1306,7 +1331,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
             }
         }
         apx = wmin(apx); adx = wmin(adx);
-        double al = fmin(1.0, 0.995 * apx), ald = fmin(1.0, 0.995 * adx);
+        const double frac = EQ ? 0.995 : step_fraction(sig, gap);
+        double al = fmin(1.0, frac * apx), ald = fmin(1.0, frac * adx);
         if (!sep) { al = fmin(al, ald); ald = al; }
         if constexpr (EQ) {
             // retry variant only: stay in a wide neighbourhood of the central path -- shorten the step until every complementarity

@@ -13,8 +13,11 @@
 #include "lmpc_kernels.hip.h"
 
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// barrier of one pipeline step (phase 2 of the Newton iteration): every wave of the work-group executes the same number of them
+#define STEP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #ifdef LMPC_TIMING
-#define TSMW(id) do { if (io.tbuf && b == 0 && tid == 0 && tcnt < 4000) { io.tbuf[2 * tcnt] = (id); io.tbuf[2 * tcnt + 1] = (long long)__builtin_readcyclecounter(); tcnt++; } } while (0)
+// (every wave stamps through its lane 0 into its own quarter of the buffer: 4000 (id, cycle) pairs per wave)
+#define TSMW(id) do { if (io.tbuf && b == 0 && lane == 0 && tcnt < 4000) { io.tbuf[2 * (4000 * wave + tcnt)] = (id); io.tbuf[2 * (4000 * wave + tcnt) + 1] = (long long)__builtin_readcyclecounter(); tcnt++; } } while (0)
 #else
 #define TSMW(id) do { } while (0)
 #endif
@@ -46,6 +49,7 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
     __shared__ double red[12 * 4];                           // cross-wave reduction slots
     __shared__ double phi_sh[8 * N];
     __shared__ int st_sh, bad_sh;
+    __shared__ double gs0[WAVE];                             // wave 0's per-lane share of sum t mu (it does not take part in the residual reductions)
     __shared__ int sel_start[LMPC_MAX_USED_LAPS];
     double *phi = phi_sh;
     if (tid == 0) { st_sh = 0; bad_sh = 0; }
@@ -93,11 +97,13 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
         }
     }
     __syncthreads();
+    const double s_init = c_s > 1.0 ? 1.0 / c_s : 1.0;      // see lmpc_solve_kernel
     for (int i = tid; i < 2 * N; i += NT) {
         const int k = i >> 1, j = i & 1; double f = 0.0;
 #pragma unroll
         for (int c = 0; c < 6; c++) f = fma(Fx[j * 6 + c], x[k * 6 + c], f);
-        s[i] = fmax(f - bx[j], 0.0) + 1.0;
+        const double viol = f - bx[j];
+        s[i] = viol > 0.0 ? viol + 1.0 : s_init;
     }
     double qmax = 0.0;
     if constexpr (term) {
@@ -132,11 +138,13 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
         t_r[j] = 1.0; rt_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
         if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam), mm = mu0 / tt; t_r[j] = tt; m[r] = mm; rt_r[j] = frcp(tt); th[r] = mm * rt_r[j]; gsum_c = fma(tt, mm, gsum_c); }
     }
+    if (w0) gs0[lane] = gsum_c;                            // wave 0's share of sum t mu: folded into the gap by wave 1 (wave 0 skips the residual reductions)
     if constexpr (term) { if (wave == NW - 1) ss_times<S>(SS, lam, x + N * 6, sT, lane); }      // terminal slack s_T = SS lambda - x_N
     // loop-invariant pieces of the stage Hessian W for this lane's (a, c) = (lg, lc) tile entry (used by wave 0)
     const ricc_consts rc = ricc_setup(lane, Q2, Fx, R2, dR2, Fu);
     double ph[N];
     double mcol[7];
+    const double tsq_lane = (term && lane >= S && lane < S + 6) ? frsqrt(T2p[lane - S]) : 0.0;   // T^-1/2 entry of this lane's slack column of M (loop invariant)
 #pragma unroll
     for (int j = 0; j < 7; j++) mcol[j] = 0.0;
 #pragma unroll
@@ -174,26 +182,21 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 double acc = 0.0;                               // M c~ : lane (j, part) adds 8 of the 64 columns
                 if (lg < 7) {
 #pragma unroll
-                    for (int q = 0; q < 8; q++) acc = fma(Mt[(lc + 8 * q) * 8 + lg], ct[lc + 8 * q], acc);
+                    for (int q = 0; q < 8; q++) acc = fma(Mt[lc * 8 + lg + 64 * q], ct[lc + 8 * q], acc);
                 }
                 acc = sum_over_c(acc);
                 if (lg < 7 && lc == 0) McL[lg] = acc;
                 WSYNC();
-                if (lane < 7) {                                 // y7 = Ri' (M c~) ; sT <- Ri' d0 + y7 (scratch)
-                    double v = 0.0;
-                    for (int j = 0; j <= lane; j++) v = fma(Ri[j * 7 + lane], McL[j], v);
-                    y7[lane] = v;
-                    z7[lane] = Ri[6 * 7 + lane] * (-re_sum) + v;   // Ri' d0 + y7 (z7 is free until the forward sweep has finished)
-                }
-                WSYNC();
             }
-            if (lane < 8) {                                     // terminal costate p_N
+            {   // terminal costate p_N = (rx_N + [Ri (Ri' d0 + y7)]_{0:6}, 0), y7 = Ri' (M c~) (ri_t_times / ri_times: lmpc_kernels.hip.h)
                 double v = 0.0;
-                if (lane < 6) {
-                    v = rx[N * 6 + lane];
-                    if constexpr (term) { for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], z7[j], v); }
+                if constexpr (term) {
+                    const double yv = ri_t_times(Ri, McL, lg, lc);
+                    if (lc == 0 && lg < 7) { y7[lg] = yv; z7[lg] = fma(Ri[6 * 7 + lg], -re_sum, yv); }   // z7 is free until the forward sweep has finished
+                    WSYNC();
+                    v = ri_times(Ri, z7, lg, lc);
                 }
-                pst[N * 8 + lane] = v;
+                if (lc == 0) pst[N * 8 + lg] = lg < 6 ? rx[N * 6 + lg] + v : 0.0;
             }
         }
         FOR_OFF(i, 8 * N, O1) {                                 // gamma_k = [gx';0] + Phi[6:8,:]' gu'
@@ -256,18 +259,17 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
         }
         if constexpr (term) {
             if (w0) {
-                if (lane < 7) {                                 // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum)
-                    double v = y7[lane];
-                    for (int j = 0; j <= lane; j++) v = fma(Ri[j * 7 + lane], j < 6 ? dx[N * 6 + j] : -re_sum, v);
-                    z7[lane] = v;
+                {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
+                    if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;           // d7 (w7 is free until omega' is written)
+                    WSYNC();
+                    const double zv = ri_t_times(Ri, w7, lg, lc) + y7[lg < 7 ? lg : 0];
+                    WSYNC();
+                    if (lc == 0 && lg < 7) z7[lg] = zv;
+                    WSYNC();
+                    const double wv = ri_times(Ri, z7, lg, lc);
+                    if (lc == 0 && lg < 7) w7[lg] = wv;
+                    WSYNC();
                 }
-                WSYNC();
-                if (lane < 7) {                                 // omega' = Ri z7
-                    double v = 0.0;
-                    for (int j = lane; j < 7; j++) v = fma(Ri[lane * 7 + j], z7[j], v);
-                    w7[lane] = v;
-                }
-                WSYNC();
                 double v = -c_t;                                // v = -c~ + M' omega'
 #pragma unroll
                 for (int j = 0; j < 7; j++) v = fma(mcol[j], w7[j], v);
@@ -278,81 +280,20 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
     };
 
     int it = 0, converged = 0, sep = 0;
-    double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0;
+    double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0, lsum_all = 0.0;
     const double qscale = fmax(1.0, qmax);
+    // Helper waves stride their loops over the NT3 = NT - 64 threads of waves 1 .. NW-1 (wave 0 is busy with the sequential work)
+    constexpr int NT3 = NT - WAVE;
+    const int t3 = tid - WAVE;
+#define FOR_HELP(i, n, off) for (int i = (t3 >= ((off) % NT3) ? t3 - ((off) % NT3) : t3 - ((off) % NT3) + NT3); i < (n); i += NT3)
+    constexpr int FB_WAVE = NW > 2 ? 2 : 1;                  // wave that runs the feed-forward follower (its own wave when there are three helpers)
 #pragma unroll 1
     for (it = 0; it <= p.max_iter; it++) {
         TSMW(10);
-        // ---- slacks of the inequality rows, terminal slack --------------------------------------------
-        double gsum = gsum_c, rmax = 0.0, remax = 0.0;
-        // ---- residuals (different loops on different waves; slacks, barrier weights and s_T were refreshed with the step) ----
-        for (int i = tid; i < 6 * (N + 1); i += NT) {
-            const int k = i / 6, c = i % 6; double v = 0.0;
-            if (k >= 1) {
-                const double *Qk = k < N ? Q2 : Qf2;
-#pragma unroll
-                for (int j = 0; j < 6; j++) v = fma(Qk[c * 6 + j], x[k * 6 + j] - xRef[j], v);
-                v += nu[(k - 1) * 6 + c];
-                if (k < N) {
-                    v += Fx[c] * m[2 * k] + Fx[6 + c] * m[2 * k + 1];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) v -= AB[k * 48 + j * 8 + c] * nu[k * 6 + j];
-                } else if (term) v -= T2p[c] * sT[c];
-                rmax = fmax(rmax, fabs(v));
-            }
-            rx[i] = v;
-        }
-        FOR_OFF(i, 2 * N, O2) {
-            const int k = i >> 1, c = i & 1;
-            const double up = k > 0 ? u[(k - 1) * 2 + c] : (c == 0 ? uOld0 : uOld1);
-            double v = R2[c * 2] * u[k * 2] + R2[c * 2 + 1] * u[k * 2 + 1] + dR2[c] * (u[i] - up);
-            if (k < N - 1) v += dR2[c] * (u[i] - u[(k + 1) * 2 + c]);
-#pragma unroll
-            for (int j = 0; j < 4; j++) v = fma(Fu[j * 2 + c], m[2 * N + 4 * k + j], v);
-#pragma unroll
-            for (int j = 0; j < 6; j++) v -= AB[k * 48 + j * 8 + 6 + c] * nu[k * 6 + j];
-            ru[i] = v; rmax = fmax(rmax, fabs(v));
-            const double vs = a_s * s[i] + c_s - m[i] - m[6 * N + i];
-            rs[i] = vs; rmax = fmax(rmax, fabs(vs));
-        }
-        double lsum = 0.0;
-        if constexpr (term) {
-            FOR_OFF(c, S, O3) {
-                double v = Qsel[c] - m[8 * N + c] + eta_m;
-#pragma unroll
-                for (int j = 0; j < 6; j++) v = fma(SS[j * S + c], T2p[j] * sT[j], v);
-                rl[c] = v; rmax = fmax(rmax, fabs(v)); lsum += lam[c];
-            }
-        }
-        FOR_OFF(i, 6 * N, O1 + 16) {                             // dynamics residual (monitoring only)
-            const int k = i / 6, c = i % 6;
-            double v = x[(k + 1) * 6 + c] - C[i] - AB[k * 48 + c * 8 + 6] * u[k * 2] - AB[k * 48 + c * 8 + 7] * u[k * 2 + 1];
-#pragma unroll
-            for (int j = 0; j < 6; j++) v -= AB[k * 48 + c * 8 + j] * x[k * 6 + j];
-            remax = fmax(remax, fabs(v));
-        }
-        red_put(0, wsum(gsum)); red_put(1, wmax(rmax)); red_put(2, wsum(lsum)); red_put(3, wmax(remax));
-        __syncthreads();
-        gap = red_sum(0) / (double)M;
-        rdn = red_max(1);
-        const double re_sum = term ? red_sum(2) - 1.0 : 0.0;
-        ren = fmax(red_max(3), fabs(re_sum));
-        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res) { converged = 1; break; }
-        if (gap_prev >= 0.0) sep = gap > 0.3 * gap_prev;
-        gap_prev = gap;
-        if (it == p.max_iter) break;
-        if (!(gap == gap) || !(rdn == rdn)) { if (tid == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
-
-        TSMW(11);
-        // ---- barrier weights ----------------------------------------------------------------------------
-        FOR_OFF(i, 2 * N, O1) {
-            const double d_ = frcp(a_s + th[i] + th[6 * N + i]);
-            rDs[i] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
-        }
-        FOR_OFF(r, M, O2) h[r] = m[r];                           // predictor right-hand side: h = mu
-        // ---- factorisation: wave 0 alone, ordered by s_waitcnt ---------------------------------------------
+        // ---- phase 1: wave 0 factorises the terminal block of this iterate; meanwhile the helper waves evaluate the residuals, the slack
+        //      eliminations and everything of the predictor's right-hand side (h = mu) that does not need the factorisation -------------
+        int numeric_bad = 0;
         if (w0) {
-            int numeric_bad = 0;
             if constexpr (term) {
 #pragma unroll
                 for (int j = 0; j < 7; j++) mcol[j] = 0.0;
@@ -364,30 +305,28 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 } else {
                     rsq[lane] = 1.0;
 #pragma unroll
-                    for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = frsqrt(T2p[j]);
+                    for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = tsq_lane;
                 }
-                double Rr[7][7], Rv[7][7], rinv[7];
-#pragma unroll
-                for (int i = 0; i < 7; i++)
-#pragma unroll
-                    for (int j = 0; j < 7; j++) { Rr[i][j] = 0.0; Rv[i][j] = 0.0; }
+                double Rr[7][7], rinv[7];
 #pragma unroll
                 for (int j = 0; j < 7; j++) Mt[lane * 8 + j] = mcol[j];
                 Mt[lane * 8 + 7] = 0.0;
                 WSYNC();
                 {   // Gram matrix W = M M' on the matrix cores (see lmpc_solve_kernel)
                     typedef double v4d __attribute__((ext_vector_type(4)));
-                    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;   // four independent accumulation chains (the dependent latency of this shape is ~100 cycles)
                     const int kk = lane >> 4, ii = lane & 15;
                     const bool live = ii < 8;
 #pragma unroll
-                    for (int s_ = 0; s_ < 16; s_ += 2) {
-                        double a0 = Mt[(4 * s_ + kk) * 8 + (ii & 7)], a1 = Mt[(4 * (s_ + 1) + kk) * 8 + (ii & 7)];
-                        a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0;
+                    for (int s_ = 0; s_ < 16; s_ += 4) {
+                        double a0 = Mt[(4 * s_ + kk) * 8 + (ii & 7)], a1 = Mt[(4 * (s_ + 1) + kk) * 8 + (ii & 7)], a2 = Mt[(4 * (s_ + 2) + kk) * 8 + (ii & 7)], a3 = Mt[(4 * (s_ + 3) + kk) * 8 + (ii & 7)];
+                        a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0; a2 = live ? a2 : 0.0; a3 = live ? a3 : 0.0;
                         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc3, 0, 0, 0);
                     }
-                    if (ii < 8) { Wl[kk * 8 + ii] = acc0[0] + acc1[0]; Wl[(4 + kk) * 8 + ii] = acc0[1] + acc1[1]; }
+                    if (ii < 8) { Wl[kk * 8 + ii] = (acc0[0] + acc1[0]) + (acc2[0] + acc3[0]); Wl[(4 + kk) * 8 + ii] = (acc0[1] + acc1[1]) + (acc2[1] + acc3[1]); }
                 }
                 WSYNC();
 #pragma unroll
@@ -409,22 +348,20 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                         Rr[i][j] = v * rinv[i];
                     }
                 }
+                {   // Ri = R^-1 (upper): lane j < 7 back-substitutes column j (R is uniform across the lanes), 28 dependent operations instead of 140.
+                    // Terms beyond the diagonal multiply exact zeros, so every entry is bit-identical to the column-by-column form.
+                    double col[7];
 #pragma unroll
-                for (int j = 0; j < 7; j++) {                                                 // Ri = R^-1 (upper)
-                    Rv[j][j] = rinv[j];
-#pragma unroll
-                    for (int i = j - 1; i >= 0; i--) {
+                    for (int i = 6; i >= 0; i--) {
                         double v = 0.0;
 #pragma unroll
-                        for (int k = i + 1; k <= j; k++) v = fma(-Rr[i][k], Rv[k][j], v);
-                        Rv[i][j] = v * rinv[i];
+                        for (int k = i + 1; k < 7; k++) v = fma(-Rr[i][k], col[k], v);
+                        col[i] = lane == i ? rinv[i] : (lane > i ? v * rinv[i] : 0.0);
                     }
-                }
-                if (lane == 0) {
+                    if (lane < 7) {
 #pragma unroll
-                    for (int i = 0; i < 7; i++)
-#pragma unroll
-                        for (int j = 0; j < 7; j++) Ri[i * 7 + j] = Rv[i][j];
+                        for (int i = 0; i < 7; i++) Ri[i * 7 + lane] = col[i];
+                    }
                 }
                 WSYNC();
                 if (lane < 36) {                                 // Pi_term = (Ri Ri')[0:6,0:6]
@@ -432,26 +369,202 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                     for (int k = (i > j ? i : j); k < 7; k++) v = fma(Ri[i * 7 + k], Ri[j * 7 + k], v);
                     PiT[lane] = v;
                 }
-                WSYNC();
             }
             WSYNC();
-            __builtin_amdgcn_s_barrier();                        // B_KAP: pairs with the helpers' barrier below; kap / rDs written by another wave are complete
-            TSMW(12);
-            numeric_bad |= ricc_factor<N, term>(rc, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
-            WSYNC();
+        } else {
+            double rmax = 0.0, remax = 0.0, lsum = 0.0;
+            FOR_HELP(i, 6 * (N + 1), 0) {                     // stationarity rows of x_k
+                const int k = i / 6, c = i % 6; double v = 0.0;
+                if (k >= 1) {
+                    const double *Qk = k < N ? Q2 : Qf2;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) v = fma(Qk[c * 6 + j], x[k * 6 + j] - xRef[j], v);
+                    v += nu[(k - 1) * 6 + c];
+                    if (k < N) {
+                        v += Fx[c] * m[2 * k] + Fx[6 + c] * m[2 * k + 1];
+#pragma unroll
+                        for (int j = 0; j < 6; j++) v -= AB[k * 48 + j * 8 + c] * nu[k * 6 + j];
+                    } else if (term) v -= T2p[c] * sT[c];
+                    rmax = fmax(rmax, fabs(v));
+                }
+                rx[i] = v;
+                if (i < 6) dx[i] = 0.0;
+            }
+            FOR_HELP(i, 2 * N, 6 * (N + 1)) {                 // rows of u_k and s_k; slack elimination and the predictor's (h = mu) reduced gradients
+                const int k = i >> 1, c = i & 1;
+                const double up = k > 0 ? u[(k - 1) * 2 + c] : (c == 0 ? uOld0 : uOld1);
+                double v = R2[c * 2] * u[k * 2] + R2[c * 2 + 1] * u[k * 2 + 1] + dR2[c] * (u[i] - up);
+                if (k < N - 1) v += dR2[c] * (u[i] - u[(k + 1) * 2 + c]);
+                double fh = 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) fh = fma(Fu[j * 2 + c], m[2 * N + 4 * k + j], fh);
+                v += fh;
+#pragma unroll
+                for (int j = 0; j < 6; j++) v -= AB[k * 48 + j * 8 + 6 + c] * nu[k * 6 + j];
+                ru[i] = v; rmax = fmax(rmax, fabs(v));
+                gup[i] = v - fh;                              // gu' = ru - Fu' h_u with h = mu
+                const double ml = m[i], ms = m[6 * N + i];
+                const double vs = a_s * s[i] + c_s - ml - ms;
+                rs[i] = vs; rmax = fmax(rmax, fabs(vs));
+                const double d_ = frcp(a_s + th[i] + th[6 * N + i]);
+                rDs[i] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
+                const double e_ = -(vs + ml + ms);
+                ee[i] = e_; eta[i] = ml + th[i] * e_ * d_;
+            }
+            if constexpr (term) {
+                FOR_HELP(c, S, 6 * (N + 1) + 2 * N) {
+                    double v = Qsel[c] - m[8 * N + c] + eta_m;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) v = fma(SS[j * S + c], T2p[j] * sT[j], v);
+                    rl[c] = v; rmax = fmax(rmax, fabs(v)); lsum += lam[c];
+                }
+            }
+            FOR_HELP(i, 6 * N, 6 * (N + 1) + 2 * N + S) {     // dynamics residual (monitoring only)
+                const int k = i / 6, c = i % 6;
+                double v = x[(k + 1) * 6 + c] - C[i] - AB[k * 48 + c * 8 + 6] * u[k * 2] - AB[k * 48 + c * 8 + 7] * u[k * 2 + 1];
+#pragma unroll
+                for (int j = 0; j < 6; j++) v -= AB[k * 48 + c * 8 + j] * x[k * 6 + j];
+                remax = fmax(remax, fabs(v));
+            }
+            double gsum = gsum_c;
+            if (wave == 1) gsum += gs0[lane];                // (written by wave 0 together with the step, a barrier ago)
+            red_put(0, wsum(gsum)); red_put(1, wmax(rmax)); red_put(2, wsum(lsum)); red_put(3, wmax(remax));
+        }
+        __syncthreads();                                     // B1
+        {
+            double gs = 0.0, rm = 0.0, ls = 0.0, rem = 0.0;
+            for (int w = 1; w < NW; w++) { gs += red[w]; rm = fmax(rm, red[4 + w]); ls += red[8 + w]; rem = fmax(rem, red[12 + w]); }
+            gap = gs / (double)M; rdn = rm; ren = rem; lsum_all = ls;
+        }
+        const double re_sum = term ? lsum_all - 1.0 : 0.0;
+        ren = fmax(ren, fabs(re_sum));
+        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res) { converged = 1; break; }
+        if (gap_prev >= 0.0) sep = gap > LMPC_SEP_THRESHOLD * gap_prev;
+        gap_prev = gap;
+        if (it == p.max_iter) break;
+        if (!(gap == gap) || !(rdn == rdn)) { if (tid == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
+        TSMW(12);
+        // ---- phase 2: a pipeline of N + 1 steps, each closed by a work-group barrier.  Step s: wave 0 factorises stage N-1-s (Riccati
+        //      recursion on the matrix cores); one step behind, wave 1 extends the predictor's backward sweep  p_k = Phi_k' p_{k+1} + gamma_k
+        //      to the stage just factorised and wave FB_WAVE computes that stage's feed-forward term phi_k (it needs the stage's factors and
+        //      p_{k+1}, both complete since the previous barrier).  Step 0 of wave 1 is the terminal costate p_N; the last step of wave 0
+        //      is the read-back of its sweep operands.  After the last barrier the forward sweep can start at once. ------------------------
+        if (w0) {
+            if constexpr (NW == 2) {
+                // two waves per SIMD (<= 256 registers): the ~40 registers of per-lane recursion constants are rebuilt here every iteration
+                // instead of being carried through the whole loop by both waves (the opaque copy of `lane` keeps the compiler from hoisting it)
+                int l2 = lane; asm volatile("" : "+v"(l2));
+                const ricc_consts rc2 = ricc_setup(l2, Q2, Fx, R2, dR2, Fu);
+                numeric_bad |= ricc_factor<N, term, true>(rc2, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
+            } else numeric_bad |= ricc_factor<N, term, true>(rc, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
             if (numeric_bad && lane == 0) bad_sh = 1;
 #pragma unroll
             for (int k = 0; k < N; k++) ph[k] = (k & 1) ? Phi[k * 64 + lc * 8 + lg] : Phi[k * 64 + lg * 8 + lc];
+            TSMW(19);
+            STEP_BARRIER();                                  // step N
         } else {
-            WSYNC();
-            __builtin_amdgcn_s_barrier();                        // B_KAP (helpers): their kap / rDs / h writes are complete
+            double pv = 0.0;
+            if (wave == 1) {                                 // step 0: terminal costate p_N
+                double c_t = 0.0;
+                if constexpr (term) {
+                    if (lane < S) c_t = (rl[lane] + m[8 * N + lane]) * rsq[lane];
+                    ct[lane] = c_t;
+                    WSYNC();
+                    double acc = 0.0;                               // M c~ : lane (j, part) adds 8 of the 64 columns
+                    if (lg < 7) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) acc = fma(Mt[lc * 8 + lg + 64 * q], ct[lc + 8 * q], acc);
+                    }
+                    acc = sum_over_c(acc);
+                    if (lg < 7 && lc == 0) McL[lg] = acc;
+                    WSYNC();
+                }
+                double v = 0.0;
+                if constexpr (term) {
+                    const double yv = ri_t_times(Ri, McL, lg, lc);
+                    if (lc == 0 && lg < 7) { y7[lg] = yv; z7[lg] = fma(Ri[6 * 7 + lg], -re_sum, yv); }
+                    WSYNC();
+                    v = ri_times(Ri, z7, lg, lc);
+                }
+                if (lc == 0) pst[N * 8 + lg] = lg < 6 ? rx[N * 6 + lg] + v : 0.0;
+                WSYNC();
+                pv = ((N - 1) & 1) ? pst[N * 8 + lc] : pst[N * 8 + lg];
+            }
+            STEP_BARRIER();                                  // step 0
+#pragma unroll
+            for (int k = N - 1; k >= 0; k--) {               // step N - k: stage k was factorised during the previous step
+                if (wave == FB_WAVE) {
+                    // phi_k = [-B k0 ; -k0],  k0_k = M_uu^-1 (gu' + [B; I]' p_{k+1}): lane c of every group of 8 holds row c of [B_k; I] and p_{k+1}[c]
+                    // (per-lane loads, no chain of broadcast reads), the two 8-term sums are DPP reductions inside the group
+                    const double bq0 = lc < 6 ? AB[k * 48 + lc * 8 + 6] : (lc == 6 ? 1.0 : 0.0), bq1 = lc < 6 ? AB[k * 48 + lc * 8 + 7] : (lc == 7 ? 1.0 : 0.0);
+                    const double pq = pst[(k + 1) * 8 + lc], gq = lc >= 6 ? gup[2 * k + lc - 6] : 0.0;
+                    const double m00 = Mi[k * 4], m01 = Mi[k * 4 + 1], m10 = Mi[k * 4 + 2], m11 = Mi[k * 4 + 3];
+                    const double w0_ = sum_over_c(fma(bq0, pq, lc == 6 ? gq : 0.0)), w1_ = sum_over_c(fma(bq1, pq, lc == 7 ? gq : 0.0));
+                    const double k00 = m00 * w0_ + m01 * w1_, k01 = m10 * w0_ + m11 * w1_;
+                    if (lane < 8) phi[k * 8 + lc] = -(bq0 * k00 + bq1 * k01);
+                }
+                if (wave == 1) {
+                    // gamma_k = [gx' ; 0] + Phi_k[6:8,:]' gu' in the sweep's register layout, then p_k
+                    const int ix = (k & 1) ? lg : lc;
+                    double g0 = 0.0;
+                    if (ix < 6) { g0 = rx[k * 6 + ix]; g0 -= Fx[ix] * eta[2 * k] + Fx[6 + ix] * eta[2 * k + 1]; }
+                    const double phk = (k & 1) ? Phi[k * 64 + lc * 8 + lg] : Phi[k * 64 + lg * 8 + lc];
+                    const double gk = fma(Phi[k * 64 + 56 + ix], gup[2 * k + 1], fma(Phi[k * 64 + 48 + ix], gup[2 * k], g0));
+                    double pr = phk * pv;
+                    if (k & 1) { pr = sum_over_c(pr); pv = pr + gk; if (lc == 0) pst[k * 8 + lg] = pv; }
+                    else { pr = sum_over_g(pr); pv = pr + gk; if (lg == 0) pst[k * 8 + lc] = pv; }
+                }
+                TSMW(200 + k);
+                STEP_BARRIER();
+            }
+        }
+        // (the last step's barrier is the hand-over to the forward sweep: LDS writes of a wave that precede its barrier are in place)
+        if (bad_sh) { if (tid == 0) atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_NUMERIC); break; }   // see lmpc_solve_kernel
+        TSMW(13);
+        // ---- predictor (affine scaling) direction, rest: forward sweep on wave 0, then the slack and terminal steps ----------------
+        if (w0) {
+            double fm[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
+            double xi = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                double pr = ph[k] * xi;
+                int idx;
+                if (k & 1) { pr = sum_over_g(pr); idx = lc; } else { pr = sum_over_c(pr); idx = lg; }
+                xi = pr + fm[k];
+                const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
+                if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
+            }
         }
         __syncthreads();
-        if (bad_sh) { if (tid == 0) atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_NUMERIC); break; }   // see lmpc_solve_kernel
-
-        TSMW(13);
-        // ---- predictor (affine scaling) direction ----------------------------------------------------------
-        kkt_solve(re_sum);
+        TSMW(33);
+        FOR_OFF(i, 2 * N, O1) {
+            const int k = i >> 1, j = i & 1; double f = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) f = fma(Fx[j * 6 + c], dx[k * 6 + c], f);
+            ds[i] = (th[i] * f + ee[i]) * rDs[i];
+        }
+        if constexpr (term) {
+            if (w0) {
+                {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
+                    if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;           // d7 (w7 is free until omega' is written)
+                    WSYNC();
+                    const double zv = ri_t_times(Ri, w7, lg, lc) + y7[lg < 7 ? lg : 0];
+                    WSYNC();
+                    if (lc == 0 && lg < 7) z7[lg] = zv;
+                    WSYNC();
+                    const double wv = ri_times(Ri, z7, lg, lc);
+                    if (lc == 0 && lg < 7) w7[lg] = wv;
+                    WSYNC();
+                }
+                double v = -ct[lane];                           // v = -c~ + M' omega'
+#pragma unroll
+                for (int j = 0; j < 7; j++) v = fma(mcol[j], w7[j], v);
+                if (lane < S) dl[lane] = v * rsq[lane];
+            }
+        }
+        __syncthreads();
         TSMW(14);
         double apmax = 1.0, admax = 1.0, dma_r[RPL];
 #pragma unroll
@@ -502,7 +615,8 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
         red_put(7, wmin(apx)); red_put(8, wmin(adx));
         if constexpr (term) { if (wave == NW - 1) ss_times<S>(SS, dl, dx + N * 6, w7, lane); }          // d s_T
         __syncthreads();
-        double al = fmin(1.0, 0.995 * red_min(7)), ald = fmin(1.0, 0.995 * red_min(8));
+        const double frac = step_fraction(sig, gap);
+        double al = fmin(1.0, frac * red_min(7)), ald = fmin(1.0, frac * red_min(8));
         if (!sep) { al = fmin(al, ald); ald = al; }
         TSMW(17);
         // ---- multipliers of the equality rows (costates) -------------------------------------------------
@@ -550,6 +664,7 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 t_r[j] = tt; m[r] = mm; rt_r[j] = frcp(tt); th[r] = mm * rt_r[j]; gsum_c = fma(tt, mm, gsum_c);
             }
         }
+        if (w0) gs0[lane] = gsum_c;
         if constexpr (term) { if (tid < 6) sT[tid] = fma(al, w7[tid], sT[tid]); }
         FOR_OFF(i, 6 * N, O3) nu[i] = fma(ald, dnu[i], nu[i]);
         eta_m = fma(ald, deta, eta_m);
@@ -600,4 +715,5 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
         if (io.resid) { io.resid[(size_t)b * 3] = gap; io.resid[(size_t)b * 3 + 1] = rdn; io.resid[(size_t)b * 3 + 2] = ren; }
     }
 #undef FOR_OFF
+#undef FOR_HELP
 }

@@ -139,7 +139,8 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=Fa
     x = np.zeros((N + 1, 6)); u = np.zeros((N, 2)); x[0] = qp.x0
     for k in range(N):
         x[k + 1] = A[k] @ x[k] + B[k] @ u[k] + C[k]
-    s = np.maximum(x[:N] @ Fx.T - bx, 0) + 1.0
+    viol = x[:N] @ Fx.T - bx
+    s = np.where(viol > 0, viol + 1.0, 1.0 / c1 if c1 > 1.0 else 1.0)      # violated rows one unit inside, the others at 1 / c_s
     lam = np.ones(S) / S if qp.term else np.zeros(0)
     nu = np.zeros((N, 6)); eta_m = 0.0
     def slacks():
@@ -156,7 +157,7 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=Fa
         t_lane, t_u, t_s, t_l = slacks()
         gap = (t_lane.ravel() @ m_lane.ravel() + t_u.ravel() @ m_u.ravel() + t_s.ravel() @ m_s.ravel() + t_l @ m_l) / mtot
         if gap_prev is not None:
-            sep = gap > 0.3 * gap_prev
+            sep = gap > 0.1 * gap_prev
         gap_prev = gap
         # ---- residuals
         sT = qp.SS @ lam - x[N] if qp.term else None
@@ -212,7 +213,8 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=Fa
         dx, du, ds, dl = solve(*hs)
         dt = ineq_steps(dx, du, ds, dl)
         dm = [(-r - m * d) / t for r, m, d, t in zip(rc, ms, dt, ts)]
-        al = min(1.0, 0.995 * maxstep(ts, dt)); ald = min(1.0, 0.995 * maxstep(ms, dm))
+        frac = max(0.995, 1.0 - 10.0 * gap) if sig < 1e-3 else 0.995      # longer steps in the final phase only (step_fraction in the kernel)
+        al = min(1.0, frac * maxstep(ts, dt)); ald = min(1.0, frac * maxstep(ms, dm))
         if not sep:
             al = ald = min(al, ald)
         # costates (delta): dnu_N from terminal, then backwards

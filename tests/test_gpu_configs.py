@@ -89,17 +89,21 @@ def test_batch4096_safe_set_from_30_laps(built):
     perm = rng.permutation(B)[:2048]                                           # (> 4 QPs per CU: still the one-wave kernel)
     out2 = ctx.step_batch(inp["x0"][perm], inp["xLin"][perm], inp["uLin"][perm], inp["uOld"][perm], zt=inp["zt"][perm], timeStep=inp["timeStep"][perm])
     assert np.array_equal(out2["xPred"], out["xPred"][perm]) and np.array_equal(out2["uPred"], out["uPred"][perm])
-    # small batches run the 4-waves-per-QP kernel variant: same answers up to summation order
+    # small batches run the 4-waves-per-QP kernel variant: same answers up to summation order.  (Two iterates that both satisfy the
+    # termination test lie within ~2e-7 of the optimum each -- measured 1.6e-7 on the golden steps -- and a different summation order can
+    # end one variant an iteration earlier than the other: the cross-variant distance is bounded by half the stated tolerance TOL_XU, the
+    # comparison with the certified optimum below is the parity statement.)
+    XV = 0.5 * common.TOL_XU
     sub = perm[:200]
     out3 = ctx.step_batch(inp["x0"][sub], inp["xLin"][sub], inp["uLin"][sub], inp["uOld"][sub], zt=inp["zt"][sub], timeStep=inp["timeStep"][sub])
     assert np.all(out3["status"] == 0)
-    assert np.abs(out3["xPred"] - out["xPred"][sub]).max() < 1e-7 and np.abs(out3["uPred"] - out["uPred"][sub]).max() < 1e-7
+    assert np.abs(out3["xPred"] - out["xPred"][sub]).max() < XV and np.abs(out3["uPred"] - out["uPred"][sub]).max() < XV
     assert np.array_equal(out3["ssSel"], out["ssSel"][sub])
     # batches between one and two QPs per CU run it with two waves per QP
     sub = perm[:400]
     out4 = ctx.step_batch(inp["x0"][sub], inp["xLin"][sub], inp["uLin"][sub], inp["uOld"][sub], zt=inp["zt"][sub], timeStep=inp["timeStep"][sub])
     assert np.all(out4["status"] == 0) and ctx.solver_waves(400) in (2, 1)
-    assert np.abs(out4["xPred"] - out["xPred"][sub]).max() < 1e-7 and np.abs(out4["uPred"] - out["uPred"][sub]).max() < 1e-7
+    assert np.abs(out4["xPred"] - out["xPred"][sub]).max() < XV and np.abs(out4["uPred"] - out["uPred"][sub]).max() < XV
     assert np.array_equal(out4["ssSel"], out["ssSel"][sub])
     # sampled comparison with the oracle (stores in the library's order: model sorted ascending, safe set = argsort(LapTime))
     model_sorted = [laps[i] for i in order]

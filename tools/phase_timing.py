@@ -20,20 +20,22 @@ g = common.load_lmpc_golden()
 r = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 cfg, par = common.lmpc_config(g, 12, max_batch=4)
 ctx = _capi.Context(cfg)
-NT = 8000
+NT = 32000          # 4 waves x 4000 (id, cycle) pairs (the multi-wave kernel stamps per wave)
 tb = np.zeros(NT, np.int64)
 f = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data_as(C.c_void_p)
 for rep in range(2):
     rc = ctx.lib.lmpc_debug_timing(ctx._h, f(g["rec_A"][r]), f(g["rec_B"][r]), f(g["rec_C"][r]), f(g["rec_x0"][r]), f(g["rec_OldInput"][r]),
                                    f(np.ascontiguousarray(g["rec_SSsel"][r].T)), f(g["rec_Qsel"][r]), tb.ctypes.data_as(C.c_void_p), C.c_int(NT))
     assert rc == 0, ctx.lib.lmpc_last_error()
-ids, cyc = tb[0::2], tb[1::2]
+ids_all, cyc_all = tb[0::2], tb[1::2]
+ids, cyc = ids_all[:4000], cyc_all[:4000]
 n = int(np.argmax(ids == 21)) + 1
 ids, cyc = ids[:n], cyc[:n]
 names = {(0, 1): "prologue+select", (1, 10): "init (load, rollout)", (10, 11): "residuals", (11, 12): "factor: terminal (MGS2, Ri, PiT)",
          (12, 13): "factor: stages", (13, 30): "solve A: pre", (30, 31): "solve: backward sweep", (31, 32): "solve: k0/phi", (32, 33): "solve: forward sweep",
          (33, 14): "solve A: post", (14, 15): "predictor post (steps, sigma, h)", (15, 30): "solve B: pre", (33, 16): "solve B: post",
-         (16, 17): "corrector post (dm, alpha)", (17, 18): "costates", (12, 13): "factor: stages", (11, 12): "kappa + terminal factor", (18, 10): "update", (18, 20): "update(last)", (10, 20): "final residual check", (20, 21): "epilogue"}
+         (10, 12): "mw phase 1: terminal factor || residuals + predictor rhs", (12, 13): "mw phase 2: Riccati stages || predictor back-sweep + phi followers",
+         (13, 33): "mw solve A: forward sweep", (16, 17): "corrector post (dm, alpha)", (17, 18): "costates", (12, 13): "factor: stages", (11, 12): "kappa + terminal factor", (18, 10): "update", (18, 20): "update(last)", (10, 20): "final residual check", (20, 21): "epilogue"}
 acc = collections.OrderedDict()
 for i in range(1, n):
     key = (int(ids[i - 1]), int(ids[i]))
@@ -43,3 +45,15 @@ iters = int(np.sum(ids == 11))
 print("total cycles %d, IPM iterations %d (%.0f cycles / iteration)" % (tot, iters, tot / max(iters, 1)))
 for key, v in acc.items():
     print("%-40s n=%3d mean %8.0f  total %9d  (%.1f%%)" % (names.get(key, str(key)), len(v), np.mean(v), np.sum(v), 100.0 * np.sum(v) / tot))
+
+if os.environ.get("LMPC_TIMING_MW"):
+    # helper waves of the multi-wave kernel: the cycle at which each of them finished its share of pipeline step N - k (stamp 200 + k), relative to
+    # wave 0's stamp 12 (start of phase 2) of the same Newton iteration; printed for the second iteration
+    t12 = cyc[ids == 12]; t19 = cyc[ids == 19]; t13 = cyc[ids == 13]
+    if len(t12) > 1:
+        base = t12[1]
+        print("iteration 1: wave 0 has its sweep operands at +%d, phase 2 ends at +%d" % (t19[1] - base, t13[1] - base))
+        for w in (1, 2):
+            wi, wc = ids_all[4000 * w:4000 * (w + 1)], cyc_all[4000 * w:4000 * (w + 1)]
+            sel = (wc > base) & (wc < t13[1] + 2000) & (wi >= 200)
+            print("wave %d:" % w, " ".join("%d@%d" % (i, c - base) for i, c in zip(wi[sel], wc[sel])))
