@@ -44,14 +44,9 @@ struct lmpc_ctx {
 
 #ifdef LMPC_DEV_FAST
 // developer build (racinglmpc_amd.build.build_flavour("dev", ["LMPC_DEV_FAST"])): only the N = 12 variants, seconds to compile; LMPC_FORCE_NW=<1|2|4>
-// runs the multi-wave template with that many waves per QP at every batch size
-static int dev_launch_mw1(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
-    const size_t lds = lmpc_variant_launchers<12, 48>::ldsm;
-    hipLaunchKernelGGL((lmpc_solve_kernel_mw<12, 48, 1>), dim3(B), dim3(WAVE), lds, st, p, B, io); return 0;
-}
+// picks the waves per QP at every batch size (1 = the one-wave kernel)
 static bool builtin_variant(lmpc_variant_api *v, int n, int s) {
-    if (n == 12 && s == 48) { (void)hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<12, 48, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmpc_variant_launchers<12, 48>::ldsm);
-                              return lmpc_variant_fill<12, 48>(v); }
+    if (n == 12 && s == 48) return lmpc_variant_fill<12, 48>(v);
     return n == 12 && s == 0 && lmpc_variant_fill<12, 0>(v);
 }
 #else
@@ -391,8 +386,7 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
 #ifdef LMPC_DEV_FAST
     if (const char *f = getenv("LMPC_FORCE_NW")) {
         const int nw = atoi(f);
-        rc = nw == 4 ? c->var.launch_mw4(c->stream, c->dp, B, io) : nw == 2 ? c->var.launch_mw2(c->stream, c->dp, B, io)
-           : (nw == 1 && c->var.N == 12 && c->var.S == 48) ? dev_launch_mw1(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
+        rc = nw == 4 ? c->var.launch_mw4(c->stream, c->dp, B, io) : nw == 2 ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     } else
 #endif
     rc = (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->var.launch_mw4(c->stream, c->dp, B, io)

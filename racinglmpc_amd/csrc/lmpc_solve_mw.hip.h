@@ -24,6 +24,7 @@
 
 template <int N, int S, int NW>
 __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_mw(lmpc_dev_params p, int B, lmpc_solve_io io) {
+    static_assert(NW == 2 || NW == 4, "wave 0 runs the sequential recursions, waves 1 .. NW-1 everything that can run beside them");
     extern __shared__ double sm[];
     using LL = solve_lds<N, S>;
     constexpr int M = LL::M;
@@ -155,30 +156,23 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
     constexpr int O1 = NW > 1 ? WAVE : 0, O2 = NW > 2 ? 2 * WAVE : O1, O3 = NW > 3 ? 3 * WAVE : O2;
 #define FOR_OFF(i, n, off) for (int i = (tid >= (off) ? tid - (off) : tid - (off) + NT); i < (n); i += NT)
 
-    // one Newton-system solve for the right-hand side currently in (rx,ru,rs,rl,h); result in dx,du,ds,dl
+    // Helper waves stride their loops over the NT3 = NT - 64 threads of waves 1 .. NW-1 (wave 0 is busy with the sequential work)
+    constexpr int NT3 = NT - WAVE;
+    const int t3 = tid - WAVE;
+#define FOR_HELP(i, n, off) for (int i = (t3 >= ((off) % NT3) ? t3 - ((off) % NT3) : t3 - ((off) % NT3) + NT3); i < (n); i += NT3)
     int tcnt = 0;
+    // Corrector solve (right-hand side h in LDS; the factors of this iterate are in place).  Three barriers:
+    //   C1  wave 0: terminal costate p_N;  helper waves: gamma_k for every stage, each entry rebuilding the two slack eliminations and the
+    //       reduced input gradient of its stage from h (no intermediate arrays, hence no barrier between them and gamma)
+    //   C2  wave 0 alone: backward sweep, feed-forward terms phi_k (lane-parallel, two passes of eight stages), forward sweep
+    //   C3  slack and terminal steps
     auto kkt_solve = [&](double re_sum) {
-        FOR_OFF(i, 2 * N, O1) {                                 // slack elimination, per lane row (k,j)
-            const double hl = h[i], hs = h[6 * N + i];
-            const double e_ = -(rs[i] + hl + hs);
-            ee[i] = e_; eta[i] = hl + th[i] * e_ * rDs[i];
-        }
-        FOR_OFF(i, 2 * N, O2) {                                 // gu' = ru - Fu' h_u
-            const int k = i >> 1, c = i & 1; double v = ru[i];
-#pragma unroll
-            for (int j = 0; j < 4; j++) v -= Fu[j * 2 + c] * h[2 * N + 4 * k + j];
-            gup[i] = v;
-        }
         double c_t = 0.0;
-        if constexpr (term) {
-            if (w0) {
-                if (lane < S) c_t = (rl[lane] + h[8 * N + lane]) * rsq[lane];
-                ct[lane] = c_t;
-            }
-        }
-        __syncthreads();
         if (w0) {
             if constexpr (term) {
+                if (lane < S) c_t = (rl[lane] + h[8 * N + lane]) * rsq[lane];
+                ct[lane] = c_t;
+                WSYNC();
                 double acc = 0.0;                               // M c~ : lane (j, part) adds 8 of the 64 columns
                 if (lg < 7) {
 #pragma unroll
@@ -198,58 +192,71 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 }
                 if (lc == 0) pst[N * 8 + lg] = lg < 6 ? rx[N * 6 + lg] + v : 0.0;
             }
+            if (lane < 6) dx[lane] = 0.0;
+        } else {
+            FOR_HELP(i, 8 * N, 0) {                             // gamma_k = [gx' - Fx' eta ; 0] + Phi[6:8,:]' gu'
+                const int k = i >> 3, c = i & 7, i0 = 2 * k, i1 = 2 * k + 1;
+                const double hl0 = h[i0], hl1 = h[i1];
+                const double e0 = -(rs[i0] + hl0 + h[6 * N + i0]), e1 = -(rs[i1] + hl1 + h[6 * N + i1]);     // slack elimination of the stage's two lane rows
+                const double eta0 = hl0 + th[i0] * e0 * rDs[i0], eta1 = hl1 + th[i1] * e1 * rDs[i1];
+                double g0 = ru[i0], g1 = ru[i1];                // gu' = ru - Fu' h_u
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const double hu = h[2 * N + 4 * k + j]; g0 -= Fu[j * 2] * hu; g1 -= Fu[j * 2 + 1] * hu; }
+                double v = 0.0;
+                if (c < 6) { v = rx[k * 6 + c]; v -= Fx[c] * eta0 + Fx[6 + c] * eta1; }
+                v = fma(Phi[k * 64 + 48 + c], g0, v);
+                v = fma(Phi[k * 64 + 56 + c], g1, v);
+                gam[i] = v;
+                if (c == 0) { ee[i0] = e0; ee[i1] = e1; gup[i0] = g0; gup[i1] = g1; }
+            }
         }
-        FOR_OFF(i, 8 * N, O1) {                                 // gamma_k = [gx';0] + Phi[6:8,:]' gu'
-            const int k = i >> 3, c = i & 7;
-            double v = 0.0;
-            if (c < 6) { v = rx[k * 6 + c]; v -= Fx[c] * eta[2 * k] + Fx[6 + c] * eta[2 * k + 1]; }
-            v = fma(Phi[k * 64 + 48 + c], gup[2 * k], v);
-            v = fma(Phi[k * 64 + 56 + c], gup[2 * k + 1], v);
-            gam[i] = v;
-        }
-        __syncthreads();
+        __syncthreads();                                        // C1
         TSMW(30);
-        if (w0) {   // backward sweep p_k = Phi_k' p_{k+1} + gamma_k in registers (see lmpc_solve_kernel)
-            double gm[N];
+        if (w0) {
+            {   // backward sweep p_k = Phi_k' p_{k+1} + gamma_k in registers (see lmpc_solve_kernel)
+                double gm[N];
 #pragma unroll
-            for (int k = 0; k < N; k++) gm[k] = (k & 1) ? gam[k * 8 + lg] : gam[k * 8 + lc];
-            double pv = ((N - 1) & 1) ? pst[N * 8 + lc] : pst[N * 8 + lg];
+                for (int k = 0; k < N; k++) gm[k] = (k & 1) ? gam[k * 8 + lg] : gam[k * 8 + lc];
+                double pv = ((N - 1) & 1) ? pst[N * 8 + lc] : pst[N * 8 + lg];
 #pragma unroll
-            for (int k = N - 1; k >= 0; k--) {
-                double pr = ph[k] * pv;
-                if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; if (lc == 0) pst[k * 8 + lg] = pv; }
-                else { pr = sum_over_g(pr); pv = pr + gm[k]; if (lg == 0) pst[k * 8 + lc] = pv; }
+                for (int k = N - 1; k >= 0; k--) {
+                    double pr = ph[k] * pv;
+                    if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; if (lc == 0) pst[k * 8 + lg] = pv; }
+                    else { pr = sum_over_g(pr); pv = pr + gm[k]; if (lg == 0) pst[k * 8 + lc] = pv; }
+                }
+            }
+            WSYNC();
+            TSMW(31);
+            // phi_k = [-B k0 ; -k0],  k0_k = M_uu^-1 (gu' + [B; I]' p_{k+1}): group lg takes stage lg + 8 pass, lane lc row lc of [B_k; I]
+#pragma unroll
+            for (int k0_ = 0; k0_ < N; k0_ += 8) {
+                const int k = k0_ + lg; const bool on = k < N; const int kk = on ? k : 0;
+                const double bq0 = lc < 6 ? AB[kk * 48 + lc * 8 + 6] : (lc == 6 ? 1.0 : 0.0), bq1 = lc < 6 ? AB[kk * 48 + lc * 8 + 7] : (lc == 7 ? 1.0 : 0.0);
+                const double pq = pst[(kk + 1) * 8 + lc], gq = lc >= 6 ? gup[2 * kk + lc - 6] : 0.0;
+                const double m00 = Mi[kk * 4], m01 = Mi[kk * 4 + 1], m10 = Mi[kk * 4 + 2], m11 = Mi[kk * 4 + 3];
+                const double w0_ = sum_over_c(fma(bq0, pq, lc == 6 ? gq : 0.0)), w1_ = sum_over_c(fma(bq1, pq, lc == 7 ? gq : 0.0));
+                const double k00 = m00 * w0_ + m01 * w1_, k01 = m10 * w0_ + m11 * w1_;
+                if (on) phi[k * 8 + lc] = -(bq0 * k00 + bq1 * k01);
+            }
+            WSYNC();
+            TSMW(32);
+            {   // forward sweep xi_{k+1} = Phi_k xi_k + phi_k in registers
+                double fm[N];
+#pragma unroll
+                for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
+                double xi = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    double pr = ph[k] * xi;
+                    int idx;
+                    if (k & 1) { pr = sum_over_g(pr); idx = lc; } else { pr = sum_over_c(pr); idx = lg; }
+                    xi = pr + fm[k];
+                    const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
+                    if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
+                }
             }
         }
-        __syncthreads();
-        TSMW(31);
-        for (int i = tid; i < 8 * N; i += NT) {                 // phi_k = [-B k0 ; -k0], k0_k = Mi_k (gu' + B' p_x + p_u) recomputed per entry
-            const int k = i >> 3, c = i & 7;
-            double w0_ = gup[2 * k] + pst[(k + 1) * 8 + 6], w1_ = gup[2 * k + 1] + pst[(k + 1) * 8 + 7];
-#pragma unroll
-            for (int j = 0; j < 6; j++) { w0_ = fma(AB[k * 48 + j * 8 + 6], pst[(k + 1) * 8 + j], w0_); w1_ = fma(AB[k * 48 + j * 8 + 7], pst[(k + 1) * 8 + j], w1_); }
-            const double k00 = Mi[k * 4] * w0_ + Mi[k * 4 + 1] * w1_, k01 = Mi[k * 4 + 2] * w0_ + Mi[k * 4 + 3] * w1_;
-            phi[i] = c < 6 ? -(AB[k * 48 + c * 8 + 6] * k00 + AB[k * 48 + c * 8 + 7] * k01) : (c == 6 ? -k00 : -k01);
-        }
-        if (tid < 6) dx[tid] = 0.0;
-        __syncthreads();
-        TSMW(32);
-        if (w0) {   // forward sweep xi_{k+1} = Phi_k xi_k + phi_k in registers
-            double fm[N];
-#pragma unroll
-            for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
-            double xi = 0.0;
-#pragma unroll
-            for (int k = 0; k < N; k++) {
-                double pr = ph[k] * xi;
-                int idx;
-                if (k & 1) { pr = sum_over_g(pr); idx = lc; } else { pr = sum_over_c(pr); idx = lg; }
-                xi = pr + fm[k];
-                const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
-                if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
-            }
-        }
-        __syncthreads();
+        __syncthreads();                                        // C2
         TSMW(33);
         FOR_OFF(i, 2 * N, O1) {
             const int k = i >> 1, j = i & 1; double f = 0.0;
@@ -276,16 +283,12 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 if (lane < S) dl[lane] = v * rsq[lane];
             }
         }
-        __syncthreads();
+        __syncthreads();                                        // C3
     };
 
     int it = 0, converged = 0, sep = 0;
     double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0, lsum_all = 0.0;
     const double qscale = fmax(1.0, qmax);
-    // Helper waves stride their loops over the NT3 = NT - 64 threads of waves 1 .. NW-1 (wave 0 is busy with the sequential work)
-    constexpr int NT3 = NT - WAVE;
-    const int t3 = tid - WAVE;
-#define FOR_HELP(i, n, off) for (int i = (t3 >= ((off) % NT3) ? t3 - ((off) % NT3) : t3 - ((off) % NT3) + NT3); i < (n); i += NT3)
     constexpr int FB_WAVE = NW > 2 ? 2 : 1;                  // wave that runs the feed-forward follower (its own wave when there are three helpers)
 #pragma unroll 1
     for (it = 0; it <= p.max_iter; it++) {
@@ -452,7 +455,8 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
         if (w0) {
             if constexpr (NW == 2) {
                 // two waves per SIMD (<= 256 registers): the ~40 registers of per-lane recursion constants are rebuilt here every iteration
-                // instead of being carried through the whole loop by both waves (the opaque copy of `lane` keeps the compiler from hoisting it)
+                // instead of being carried through the whole loop by both waves (the opaque copy of `lane` keeps the compiler from hoisting it;
+                // with four waves -- 512 registers per wave -- carrying them measured the same as rebuilding them)
                 int l2 = lane; asm volatile("" : "+v"(l2));
                 const ricc_consts rc2 = ricc_setup(l2, Q2, Fx, R2, dR2, Fu);
                 numeric_bad |= ricc_factor<N, term, true>(rc2, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
@@ -619,7 +623,8 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
         double al = fmin(1.0, frac * red_min(7)), ald = fmin(1.0, frac * red_min(8));
         if (!sep) { al = fmin(al, ald); ald = al; }
         TSMW(17);
-        // ---- multipliers of the equality rows (costates) -------------------------------------------------
+        // ---- step.  The multipliers of the equality rows (costates nu_k = -(Pi_k xi_k + p_k)_x for all stages at once) are formed and
+        //      applied in the same pass as the primal step and the inequality rows: nothing here reads what another thread writes. ----------
         for (int i = tid; i < 6 * N; i += NT) {
             const int k = i / 6 + 1, c = i % 6;
             double g;
@@ -635,11 +640,10 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 g = fma(PiAll[k * 64 + c * 8 + 6], du[(k - 1) * 2], g);
                 g = fma(PiAll[k * 64 + c * 8 + 7], du[(k - 1) * 2 + 1], g);
             }
-            dnu[i] = -g;
+            nu[i] = fma(ald, -g, nu[i]);
         }
-        double deta = 0.0;
         if constexpr (term) {
-            if (wave == NW - 1) {
+            if (wave == NW - 1) {                                // multiplier of sum(lambda) = 1: mean over the lambda rows
                 double v = 0.0;
                 if (lane < S) { v = -rl[lane] + dm[8 * N + lane];
 #pragma unroll
@@ -648,13 +652,9 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 if (lane == 0) red[9 * 4] = v;
             }
         }
-        __syncthreads();
-        if constexpr (term) deta = red[9 * 4];
-        TSMW(18);
-        // ---- step ------------------------------------------------------------------------------------------
-        for (int i = tid; i < 6 * (N + 1); i += NT) x[i] = fma(al, dx[i], x[i]);
-        FOR_OFF(i, 2 * N, O1) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
-        if constexpr (term) { FOR_OFF(c, S, O2) lam[c] = fma(al, dl[c], lam[c]); }
+        FOR_OFF(i, 6 * (N + 1), O1) x[i] = fma(al, dx[i], x[i]);
+        FOR_OFF(i, 2 * N, O2) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
+        if constexpr (term) { FOR_OFF(c, S, (O2 + 2 * N) % NT) lam[c] = fma(al, dl[c], lam[c]); }
         gsum_c = 0.0;
 #pragma unroll
         for (int j = 0; j < RPL; j++) {                         // inequality rows: slack, multiplier, barrier weight, gap share
@@ -666,9 +666,9 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
         }
         if (w0) gs0[lane] = gsum_c;
         if constexpr (term) { if (tid < 6) sT[tid] = fma(al, w7[tid], sT[tid]); }
-        FOR_OFF(i, 6 * N, O3) nu[i] = fma(ald, dnu[i], nu[i]);
-        eta_m = fma(ald, deta, eta_m);
         __syncthreads();
+        if constexpr (term) eta_m = fma(ald, red[9 * 4], eta_m);
+        TSMW(18);
     }
     if (!converged && tid == 0 && !(st_sh & (LMPC_ST_NUMERIC | LMPC_ST_INEXACT)))
         atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_MAXITER);

@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from racinglmpc_amd import build as _build
-so = _build.build_flavour("timing", ["LMPC_TIMING"])          # build it in the container first: the .so travels with the snapshot
+so = os.environ.get("LMPC_LIB") or _build.build_flavour("timing", ["LMPC_TIMING"])   # build it in the container first: the .so travels with the snapshot
 from racinglmpc_amd import _capi
 _capi.LIB_PATH = so
 from tests import common
