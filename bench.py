@@ -110,7 +110,7 @@ def run_config(g, N, B, device, steps, warmup, laps=None, query_lap=None, **kw):
     """One extra configuration: build, time, check the status of every problem, free."""
     ctx = make_ctx(g, N, B, device, laps=laps, **kw)
     inp = synth_batch(g, B, N, lap=query_lap)
-    a, keep = ctx.step_dev_buffers(inp)
+    a, keep = ctx.step_dev_buffers(inp, diagnostics=False)
     dt, st = time_steps(ctx, B, a, steps, warmup)
     status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32)
     ctx.dev_download(a.status, status); ctx.dev_download(a.iters, iters)
@@ -259,7 +259,7 @@ def main():
     S = ctx.S
     comm = parallel.comm_from_env(ctx, force_rccl=os.environ.get("LMPC_BENCH_FORCE_DIST") == "1")
     inp = synth_batch(g, B, N, seed=1234 + rank)
-    a, keep = ctx.step_dev_buffers(inp)
+    a, keep = ctx.step_dev_buffers(inp, diagnostics=False)      # the outputs MPC.solve produces (xPred, uPred, slack, lambda, s_T, zt, zt_u, SS_sel); no mu / residual dumps
 
     def sync_all():                                  # device drained on this rank, then on every rank
         ctx.sync()
@@ -268,8 +268,8 @@ def main():
     dt, st = time_steps(ctx, B, a, args.steps, args.warmup, sync=sync_all)
     dt = float(comm.allreduce_max(dt)[0])
 
-    status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); resid = np.zeros((B, 3))
-    ctx.dev_download(a.status, status); ctx.dev_download(a.iters, iters); ctx.dev_download(a.resid, resid)
+    status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32)
+    ctx.dev_download(a.status, status); ctx.dev_download(a.iters, iters)
     n_ok = int(comm.allgather(np.array([np.sum(status == 0)], dtype=np.int64)).sum())
     comm_info = ctx.comm_info()
 

@@ -287,9 +287,11 @@ class Context:
     def step_batch_dev(self, B, args):
         _chk(self.lib.lmpc_step_batch_dev(self._h, C.c_int(B), C.byref(args)))
 
-    def step_dev_buffers(self, inp):
+    def step_dev_buffers(self, inp, diagnostics=True):
         """HBM-resident inputs/outputs of lmpc_step_batch_dev for a batch given as host arrays (keys x0, xLin, uLin, uOld, zt,
-        xPredPrev, hasPred, timeStep).  Returns (StepDevArgs, device pointers to free with dev_free)."""
+        xPredPrev, hasPred, timeStep).  Returns (StepDevArgs, device pointers to free with dev_free).  diagnostics=False leaves out what
+        the reference's solve() does not produce (inequality multipliers mu, residual triple, the Q-function values of the selection):
+        those pointers stay NULL and the kernels skip the stores."""
         N, S, M = self.N, self.S, self.M
         B = np.asarray(inp["x0"]).shape[0]
         a = StepDevArgs(); keep = []
@@ -306,8 +308,10 @@ class Context:
         a.timeStep = up(inp["timeStep"] if inp.get("timeStep") is not None else np.zeros(B), np.int32)
         a.xPred, a.uPred, a.slack = alloc(B * (N + 1) * 6 * 8), alloc(B * N * 2 * 8), alloc(B * N * 2 * 8)
         a.lambda_, a.sTerm, a.ztNext, a.ztuNext = alloc(B * S * 8), alloc(B * 6 * 8), alloc(B * 6 * 8), alloc(B * 2 * 8)
-        a.ssSel, a.qSel, a.A, a.Bm, a.C = alloc(B * S * 6 * 8), alloc(B * S * 8), alloc(B * N * 36 * 8), alloc(B * N * 12 * 8), alloc(B * N * 6 * 8)
-        a.mu, a.resid, a.status, a.iters = alloc(B * M * 8), alloc(B * 3 * 8), alloc(B * 4), alloc(B * 4)
+        a.ssSel, a.A, a.Bm, a.C = alloc(B * S * 6 * 8), alloc(B * N * 36 * 8), alloc(B * N * 12 * 8), alloc(B * N * 6 * 8)
+        a.status, a.iters = alloc(B * 4), alloc(B * 4)
+        if diagnostics:
+            a.qSel, a.mu, a.resid = alloc(B * S * 8), alloc(B * M * 8), alloc(B * 3 * 8)
         return a, keep
 
     def step_dev_fetch(self, a, B):
@@ -321,7 +325,7 @@ class Context:
         src = dict(xPred=a.xPred, uPred=a.uPred, slack=a.slack, lambd=a.lambda_, sTerm=a.sTerm, ztNext=a.ztNext, ztuNext=a.ztuNext, ssSel=a.ssSel,
                    qSel=a.qSel, mu=a.mu, A=a.A, B=a.Bm, C=a.C, status=a.status, iters=a.iters, resid=a.resid)
         for k, arr in out.items():
-            if arr.nbytes:
+            if arr.nbytes and src[k]:                      # (diagnostic outputs that were not requested stay zero)
                 self.dev_download(src[k], arr)
         return out
 
