@@ -116,7 +116,8 @@ def run_config(g, N, B, device, steps, warmup, laps=None, query_lap=None, **kw):
     ctx.dev_download(a.status, status); ctx.dev_download(a.iters, iters)
     out = dict(batch=B, N=N, solves_per_s=B * steps / dt, ms_per_step=dt / steps * 1e3, solved_ok=int(np.sum(status == 0)),
                ipm_iters_mean=float(iters.mean()), ipm_iters_max=int(iters.max()), waves_per_qp=ctx.solver_waves(B),
-               kernel_ms={"lmpc_solve_kernel": st.ms_solve / max(st.n_solve, 1), "lmpc_regress_kernel": st.ms_regress / max(st.n_regress, 1)})
+               kernel_ms={"lmpc_solve_kernel": st.ms_solve / max(st.n_solve, 1), "lmpc_regress_kernel": st.ms_regress / st.n_regress if st.n_regress else None},
+               fused_step=st.n_regress == 0)
     for p in keep:
         ctx.dev_free(p)
     ctx.close()
@@ -275,7 +276,7 @@ def main():
 
     out = None
     if rank == 0:
-        ms_solve = st.ms_solve / max(st.n_solve, 1); ms_reg = st.ms_regress / max(st.n_regress, 1)
+        ms_solve = st.ms_solve / max(st.n_solve, 1); ms_reg = st.ms_regress / st.n_regress if st.n_regress else None      # (None: fused step, no regression kernel)
         bytes_per_solve = 8 * (18 * N + 92)                     # SURVEY 8(d) B_solve: compulsory in+out per full step
         achieved = B * bytes_per_solve / (ms_solve * 1e-3) / 1e9
         nw = ctx.solver_waves(B)
@@ -299,7 +300,7 @@ def main():
                        "ranks": world, "collective_backend": "rccl" if comm_info[2] else "none", "rccl_ranks": comm_info[1] if comm_info[2] else 0},
             "solved_ok": n_ok, "solved_of": world * B, "ipm_iters_mean": float(iters.mean()), "ipm_iters_max": int(iters.max()),
             "kernel_ms": {"lmpc_solve_kernel": ms_solve, "lmpc_regress_kernel": ms_reg},
-            "solver_only_solves_per_s": B / (ms_solve * 1e-3), "regression_only_solves_per_s": B / (ms_reg * 1e-3),
+            "solver_only_solves_per_s": B / (ms_solve * 1e-3), "regression_only_solves_per_s": B / (ms_reg * 1e-3) if ms_reg else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": kname, "algorithmic_bytes_per_launch": B * bytes_per_solve,
                          # the other fraction SURVEY 8(d) asks for: FP64 work per launch from the rocprofv3 instruction-mix pass

@@ -142,7 +142,11 @@ int lmpc_dev_free(lmpc_ctx *, void *dptr);
 int lmpc_dev_upload(lmpc_ctx *, void *dptr, const void *host, long long bytes);
 int lmpc_dev_download(lmpc_ctx *, void *host, const void *dptr, long long bytes);
 int lmpc_dev_sync(lmpc_ctx *);
-typedef struct {          /* all device pointers, layouts as in lmpc_step_batch */
+typedef struct {          /* all device pointers, layouts as in lmpc_step_batch.  Optional (NULL = not wanted): slack, lambda, sTerm, ztNext, ztuNext,
+                             ssSel, A, Bm, C, mu, resid, qSel.  With LMPC_FUSE=1 in the environment, batches that run one wavefront per QP take
+                             the step as ONE kernel: each wave first runs the regression (MPC.computeLTVdynamics, :140-145) of its own QP,
+                             A_i / B_i / C_i stay in LDS and are copied out only if A / Bm / C are given (bit-identical results; measured
+                             slower than the two-kernel step, hence off by default). */
     const double *x0, *xLin, *uLin, *uOld, *zt, *xPredPrev; const int *hasPred, *timeStep;
     double *xPred, *uPred, *slack, *lambda, *sTerm, *ztNext, *ztuNext, *ssSel, *A, *Bm, *C, *mu, *resid;
     int *status, *iters;

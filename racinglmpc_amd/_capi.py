@@ -290,7 +290,7 @@ class Context:
     def step_dev_buffers(self, inp, diagnostics=True):
         """HBM-resident inputs/outputs of lmpc_step_batch_dev for a batch given as host arrays (keys x0, xLin, uLin, uOld, zt,
         xPredPrev, hasPred, timeStep).  Returns (StepDevArgs, device pointers to free with dev_free).  diagnostics=False leaves out what
-        the reference's solve() does not produce (inequality multipliers mu, residual triple, the Q-function values of the selection):
+        the hot path does not need downstream (copies of A_i / B_i / C_i, inequality multipliers mu, residual triple, Q-function values of the selection):
         those pointers stay NULL and the kernels skip the stores."""
         N, S, M = self.N, self.S, self.M
         B = np.asarray(inp["x0"]).shape[0]
@@ -308,9 +308,10 @@ class Context:
         a.timeStep = up(inp["timeStep"] if inp.get("timeStep") is not None else np.zeros(B), np.int32)
         a.xPred, a.uPred, a.slack = alloc(B * (N + 1) * 6 * 8), alloc(B * N * 2 * 8), alloc(B * N * 2 * 8)
         a.lambda_, a.sTerm, a.ztNext, a.ztuNext = alloc(B * S * 8), alloc(B * 6 * 8), alloc(B * 6 * 8), alloc(B * 2 * 8)
-        a.ssSel, a.A, a.Bm, a.C = alloc(B * S * 6 * 8), alloc(B * N * 36 * 8), alloc(B * N * 12 * 8), alloc(B * N * 6 * 8)
+        a.ssSel = alloc(B * S * 6 * 8)
         a.status, a.iters = alloc(B * 4), alloc(B * 4)
         if diagnostics:
+            a.A, a.Bm, a.C = alloc(B * N * 36 * 8), alloc(B * N * 12 * 8), alloc(B * N * 6 * 8)      # (copies of the LTV model: MPC.A / B / C lists of the reference)
             a.qSel, a.mu, a.resid = alloc(B * S * 8), alloc(B * M * 8), alloc(B * 3 * 8)
         return a, keep
 

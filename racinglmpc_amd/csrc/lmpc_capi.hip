@@ -37,6 +37,7 @@ struct lmpc_ctx {
     lmpc_variant_api var;                    // launchers of the (N, numSS_points) instantiation of the solve kernels in use
     void *var_dl;                            // dlopen handle when that instantiation lives in its own shared object (lmpc_variant.hip)
     int mw_max_batch, n_cu;
+    int fuse_k1;                             // fused step for one-wave batches (LMPC_FUSE=0 turns it off)
     int profiling; std::vector<evpair> events; lmpc_stats stats;
     struct lmpc_rollout_session *ro;
     void *comm; int comm_rank, comm_world;   // RCCL communicator of this rank (lmpc_comm.hip.h); null = single process
@@ -133,6 +134,11 @@ static int create_body(lmpc_ctx *c) {
     // a variant whose LDS footprint leaves room for one QP per CU (N = 40) keeps three SIMDs idle in the 1-wave kernel at any
     // batch size: always run it with four waves per QP (measured at N=40, B=1024: 2.80 vs 3.52 ms; N=20 and N=14 prefer 1 wave)
     if (!getenv("LMPC_MW_MAX_BATCH") && 2 * c->var.lds_1w > 160 * 1024) c->mw_max_batch = 1 << 30;
+    // Fused step (regression inside the one-wave solve kernel): bit-identical results, 42 MB less HBM traffic per step at batch 4096, but
+    // MEASURED SLOWER -- 1.37 vs 1.01 + 0.23 ms at batch 4096, 2.48 vs 1.81 + 0.44 ms at batch 8192: the regression's short dependent chains
+    // (DPP minima, 5 x 5 Cholesky, scattered L2 reads) want the four waves per SIMD its own kernel gets, and the solve's LDS footprint leaves
+    // the fused kernel 1.5.  Off unless LMPC_FUSE=1.
+    { const char *e = getenv("LMPC_FUSE"); c->fuse_k1 = e ? atoi(e) : 0; }
     HIPCHK(hipStreamCreate(&c->stream));
     const size_t store_elems = (size_t)cfg->max_laps * LMPC_COLS * cfg->max_lap_len;
     HIPCHK(hipMalloc(&c->mstore, store_elems * sizeof(double)));
@@ -389,7 +395,8 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
         rc = nw == 4 ? c->var.launch_mw4(c->stream, c->dp, B, io) : nw == 2 ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     } else
 #endif
-    rc = (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->var.launch_mw4(c->stream, c->dp, B, io)
+    rc = (io.mode & 4) ? c->var.launch_1w(c->stream, c->dp, B, io)        // fused step: the one-wave kernel runs the regression itself
+       : (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->var.launch_mw4(c->stream, c->dp, B, io)
        : (B <= 4 * c->n_cu && c->mw_max_batch == c->n_cu && !io.tbuf) ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     ev_end(c);
     if (rc) return rc;
@@ -477,20 +484,27 @@ int lmpc_qp_solve_batch(lmpc_ctx *c, int B, const double *A, const double *Bm, c
 }
 
 int lmpc_step_batch_dev(lmpc_ctx *c, int B, const lmpc_step_dev_args *a) {
-    ARGCHK(c && a && B >= 1 && a->x0 && a->xLin && a->uLin && a->uOld && a->A && a->Bm && a->C && a->xPred && a->uPred && a->status && a->iters);
+    ARGCHK(c && a && B >= 1 && a->x0 && a->xLin && a->uLin && a->uOld && a->xPred && a->uPred && a->status && a->iters);
     const int N = c->cfg.N; const bool term = c->cfg.numSS_it > 0;
     if (term) ARGCHK(a->zt != nullptr);
     HIPCHK(hipSetDevice(c->cfg.device));
-    ARGCHK(B <= c->cfg.max_batch);                      // the per-point regression status buffer is sized for max_batch
-    int rc = launch_regress(c, B, a->xLin, (N + 1) * 6, a->uLin, a->A, a->Bm, a->C, c->w_rstatus);
-    if (rc) return rc;
+    ARGCHK(B <= c->cfg.max_batch);                      // the work buffers (per-point regression status, A, B, C hand-over) are sized for max_batch
     lmpc_solve_io io; memset(&io, 0, sizeof(io));
-    io.mode = term ? 3 : 2; io.A = a->A; io.Bm = a->Bm; io.C = a->C; io.x0 = a->x0; io.uOld = a->uOld;
+    // Regression kernel, then the solve kernel; A, Bm, C are optional outputs (the hand-over then uses the context's work buffers).
+    // With LMPC_FUSE=1 batches that run one wave per QP take the fused step instead: every wave runs the regression of its own QP in
+    // front of the solve and [A_k | B_k], C_k never leave LDS (see lmpc_create for the measurement that keeps it off by default).
+    const bool fused = c->fuse_k1 && lmpc_solver_waves(c, B) == 1;
+    double *dA = a->A ? a->A : c->w_A, *dB = a->Bm ? a->Bm : c->w_B, *dC = a->C ? a->C : c->w_C;
+    if (fused) { io.mode = 4; io.xLin = a->xLin; io.uLin = a->uLin; io.Aout = a->A; io.Bout = a->Bm; io.Cout = a->C; if (int rc = refresh_params(c, true, false)) return rc; }
+    else { int rc = launch_regress(c, B, a->xLin, (N + 1) * 6, a->uLin, dA, dB, dC, c->w_rstatus); if (rc) return rc; io.rstatus = c->w_rstatus; }
+    int rc = 0;
+    io.mode |= term ? 3 : 2; io.A = dA; io.Bm = dB; io.C = dC; io.x0 = a->x0; io.uOld = a->uOld;
     io.zt = a->zt; io.xPredPrev = a->xPredPrev; io.hasPred = a->hasPred; io.timeStep = a->timeStep;
     io.xPred = a->xPred; io.uPred = a->uPred; io.slack = a->slack; io.lambda = a->lambda; io.sTerm = a->sTerm; io.mu = a->mu;
     io.ztNext = a->ztNext; io.ztuNext = a->ztuNext; io.ssSelOut = a->ssSel; io.qSelOut = a->qSel; io.resid = a->resid; io.status = a->status; io.iters = a->iters;
-    io.rstatus = c->w_rstatus;                          // a singular regression / off-track linearisation point marks status[b] (the reference raises)
-    return launch_solve(c, B, io);
+    // (io.rstatus / the fused regression: a singular regression or an off-track linearisation point marks status[b]; the reference raises there)
+    rc = launch_solve(c, B, io);
+    return rc;
 }
 
 int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, const double *uLin, const double *uOld, const double *zt,

@@ -17,7 +17,7 @@
 #include "../../include/lmpc_hip.h"
 
 #define WAVE 64
-#define LMPC_VARIANT_ABI 2              // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change
+#define LMPC_VARIANT_ABI 3              // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change
 #define LMPC_COLS 9                 // lap-store columns: x0..x5, u0, u1, Qfun
 
 struct lmpc_dev_params {
@@ -79,9 +79,12 @@ __device__ __forceinline__ double track_curvature(const lmpc_dev_params &p, doub
 // every LDS offset and trip count is a compile-time constant.
 // =====================================================================================================
 struct lmpc_solve_io {
-    // mode bit 0: select the safe set on device (else read ssSel/qSel); bit 1: run the QP solve
+    // mode bit 0: select the safe set on device (else read ssSel/qSel); bit 1: run the QP solve; bit 2 (one-wave kernel only): fused step --
+    // the wave first runs the regression of its own QP from xLin / uLin (rows of N+1 / N points), [A_k | B_k] and C_k never leave LDS
+    // (Aout / Bout / Cout, if given, receive a copy)
     int mode;
     const double *A, *Bm, *C, *x0, *uOld, *ssSelIn, *qSelIn;
+    const double *xLin, *uLin; double *Aout, *Bout, *Cout;
     const double *zt, *xPredPrev; const int *hasPred, *timeStep;
     const int *rstatus;       // optional per-point status of the regression kernel (B x N): OR-ed into status[b] (the reference raises there)
     double *xPred, *uPred, *slack, *lambda, *sTerm, *mu, *ztNext, *ztuNext;
@@ -270,304 +273,388 @@ __host__ __device__ inline int k1_queries_per_block(int qg, int trToUse, int max
     return q < 1 ? 1 : q;
 }
 
-// OCC: compile for four waves per SIMD (two work-groups per CU; <= 128 VGPRs, a few spills) -- pays when the grid exceeds one work-group
-// per CU (1.47x at batch 4096); the other variant (<= 256 VGPRs, no spills) has the shorter latency when each CU runs a single group.
+// LDS work space of the regression: static arrays in the stand-alone kernel (8 waves per problem), a slice of the solve kernel's
+// dynamic LDS when one wave runs the regression of its own QP in front of the solve (lmpc_solve_kernel, fused step).
+struct k1_smem {
+    double (*qf)[5];                 // [QG]        xuLin of the queries in flight (PredictiveModel.py:54)
+    int (*cseg)[16]; int *ccnt;      // [waves QG]  prefilter survivors (row indices) per wave and query
+    double *seld; int *seli; int *nsel; int Ls;    // [QG][Ls][8], [QG][Ls][8], [QG][Ls]: running selection per query and lap
+    double (*pts)[10];               // [QF PP]     vx vy wz delta a K y_vx y_vy y_wz 1   (PredictiveModel.py:141-168)
+    double (*gram)[45];              // [QF]        Q_vx(15) b_vx(5) Q_lat(15) b_vy(5) b_wz(5)
+    double (*theta)[15];             // [QF]        three solutions of five coefficients
+    double (*outv)[54];              // [QF]        A_i (36) | B_i (12) | C_i (6)
+    int *st_s;                       // [QG]
+};
+
+// computeIndices (PredictiveModel.py:180-197) of ONE wave for lap c: the lap's prefilter image is loaded once per 1024-row chunk and scanned
+// for the wave's queries qi = sgi + s nsub, s < nqw; the running selection per (query, lap) stays in sm.seld / seli / nsel.  cs0: first
+// row of this wave in sm.cseg / ccnt.  PAIR: two queries per trip (independent reduction chains interleave; 32 registers more).
+template <bool PAIR>
+__device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_smem &sm, int c, int cs0, int sgi, int nsub, int nq, int lane, int MAXP) {
+    const double h = p.h;
+    const double *base = p.mstore + (size_t)p.mslot[c] * LMPC_COLS * p.lap_stride;
+    const int ls = p.lap_stride;
+    const int nrows = p.mlen[c] - 1;
+    for (int t0 = 0; t0 < nrows; t0 += K1_CHUNK) {
+        // Prefilter image of this lane's rows: the scaled features in 16-bit fixed point, packed (vx, vy | wz, delta | a, flag),
+        // quantised by the host when the lap was stored (lmpc_capi.hip: quantise_lap), per 1024-row chunk over the chunk's own
+        // [min, max] with ONE scale for the five features (the L1 norm weighs them equally).  Three v_sad_u16 per row give the
+        // integer L1 distance; every decision is re-made in FP64 below.  A query outside [min, max] is clamped: that shifts all
+        // of a feature's |differences| by the same amount, so the order of the rows is untouched.  Rows beyond the lap carry
+        // 0xffff in the unused half-word (the query has 0 there): farther than a full range from everything.
+        const double *qp = p.mqpar + ((size_t)p.mslot[c] * p.mq_chunks + t0 / K1_CHUNK) * 6;
+        const double qlo[5] = {qp[0], qp[1], qp[2], qp[3], qp[4]}, qsc = qp[5];
+        const unsigned *qb = p.mquant + (size_t)p.mslot[c] * 3 * ls;
+        unsigned qv[3][K1_RPL];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int j = 0; j < K1_RPL; j++) { const int t = t0 + lane + WAVE * j; qv[k][j] = qb[(size_t)k * ls + (t < nrows ? t : 0)]; }
+#pragma unroll
+        for (int j = 0; j < K1_RPL; j++) if (t0 + lane + WAVE * j >= nrows) qv[2][j] |= 0xffff0000u;
+        // ---- step A: integer prefilter, one query at a time; survivors (row indices) go to the query's 16-slot LDS segment ----
+        const int nqw = nq > sgi ? (nq - sgi + nsub - 1) / nsub : 0;                  // queries of this wave: qi = sgi + s nsub
+        for (int s = 0; s < nqw; s += PAIR ? 2 : 1) {
+            const bool two = PAIR && s + 1 < nqw;
+            const int qa = sgi + s * nsub, qb2 = two ? qa + nsub : qa;
+            unsigned ta5[5], tb5[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                ta5[k] = (unsigned)fmin(fmax((sm.qf[qa][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 65535.0);
+                tb5[k] = (unsigned)fmin(fmax((sm.qf[qb2][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 65535.0);
+            }
+            const unsigned ya[3] = {ta5[0] | (ta5[1] << 16), ta5[2] | (ta5[3] << 16), ta5[4]};
+            const unsigned yb[3] = {tb5[0] | (tb5[1] << 16), tb5[2] | (tb5[3] << 16), tb5[4]};
+            unsigned ea[K1_RPL], eb[K1_RPL], ma = 0xffffffffu, mb = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < K1_RPL; j++) {
+                unsigned a_ = 0, b_ = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { a_ = sad_u16(qv[k][j], ya[k], a_); if (PAIR) b_ = sad_u16(qv[k][j], yb[k], b_); }
+                ea[j] = a_; eb[j] = b_; ma = a_ < ma ? a_ : ma; mb = b_ < mb ? b_ : mb;
+            }
+            // MAXP-th smallest distinct lane minimum: at least MAXP rows lie at or below it (one-instruction DPP integer minima)
+            unsigned ba = 0u, bb = 0u;
+            for (int r = 0; r < MAXP; r++) {
+                ba = wminu((r == 0 || ma > ba) ? ma : 0xffffffffu);
+                if (PAIR) bb = wminu((r == 0 || mb > bb) ? mb : 0xffffffffu);
+            }
+            // Two-sided bound.  Per feature |floor(a) - floor(b)| differs from |a - b| by < 1, so over the five features the
+            // integer distance e of a row and its exact scaled distance d satisfy |e - d| < 5.  (i) At least MAXP rows have
+            // e <= T (T = ba / bb), hence d < T + 5: the MAXP-th smallest exact distance is < T + 5.  (ii) A row of the exact
+            // top MAXP therefore has d < T + 5 and e < d + 5 < T + 10, i.e. e <= T + 9.  Everything up to T + 10 survives
+            // (one unit of margin for the rounding of the host's fixed-point conversion); the survivors are re-ranked in FP64.
+            const unsigned ta = ba > 0xffffff00u ? 0xffffffffu : ba + 10u, tb = bb > 0xffffff00u ? 0xffffffffu : bb + 10u;
+            int na = 0, nb = 0;
+#pragma unroll
+            for (int j = 0; j < K1_RPL; j++) {
+                const bool ca = ea[j] <= ta, cb = PAIR && eb[j] <= tb;
+                const unsigned long long mka = __ballot(ca), mkb = PAIR ? __ballot(cb) : 0ull;
+                if (mka | mkb) {
+                    const int pa = na + __builtin_amdgcn_mbcnt_hi((unsigned)(mka >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mka, 0));
+                    const int pb = nb + __builtin_amdgcn_mbcnt_hi((unsigned)(mkb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mkb, 0));
+                    if (ca && pa < 16) sm.cseg[cs0 + s][pa] = t0 + lane + WAVE * j;
+                    if (cb && pb < 16 && two) sm.cseg[cs0 + s + 1][pb] = t0 + lane + WAVE * j;
+                    na += __popcll(mka); nb += __popcll(mkb);
+                }
+            }
+            if (lane == 0) { sm.ccnt[cs0 + s] = na; if (two) sm.ccnt[cs0 + s + 1] = nb; }
+        }
+        // ---- step B: exact FP64 distances of the survivors, four queries at a time (one per row of 16 lanes), ranked inside the
+        //      row by 15 DPP rotations; the running selection of earlier chunks rides along as extra entries ----
+        for (int s0 = 0; s0 < nqw; s0 += 4) {
+            const int s = s0 + (lane >> 4), r = lane & 15;
+            const bool live = s < nqw;
+            const int qi = live ? sgi + s * nsub : 0;
+            double *sd = sm.seld + ((size_t)qi * sm.Ls + c) * 8; int *si = sm.seli + ((size_t)qi * sm.Ls + c) * 8;
+            const int cnt = live ? sm.ccnt[cs0 + (live ? s : 0)] : 0, ns = live ? sm.nsel[qi * sm.Ls + c] : 0;
+            const bool ovf = cnt + ns > 16;
+            double dv = INFINITY; int iv = 0x7fffffff;
+            if (live && !ovf) {
+                if (r < cnt) {
+                    iv = sm.cseg[cs0 + s][r];
+                    const bool real = iv < nrows;
+                    iv = real ? iv : 0;
+                    // la.norm(diff, 1, axis=1) of (Data - x) . scaling : |.| accumulated in feature order, no contraction
+                    double nrm = fabs((base[0 * ls + iv] - sm.qf[qi][0]) * p.scaling[0]);
+                    nrm = nrm + fabs((base[1 * ls + iv] - sm.qf[qi][1]) * p.scaling[1]);
+                    nrm = nrm + fabs((base[2 * ls + iv] - sm.qf[qi][2]) * p.scaling[2]);
+                    nrm = nrm + fabs((base[6 * ls + iv] - sm.qf[qi][3]) * p.scaling[3]);
+                    nrm = nrm + fabs((base[7 * ls + iv] - sm.qf[qi][4]) * p.scaling[4]);
+                    dv = real ? nrm : INFINITY;
+                } else if (r < cnt + ns) { dv = sd[r - cnt]; iv = si[r - cnt]; }
+            }
+            const bool in_h = dv < h;
+            const double kd = in_h ? dv : INFINITY;                                   // rows outside h never outrank anything
+            int rank = 0;
+            k1_row_rank<1>(kd, iv, rank);
+            const unsigned long long mh = __ballot(in_h);
+            const int nin = __popcll((mh >> (lane & 48)) & 0xffffull);
+            if (live && !ovf) {
+                if (in_h && rank < MAXP) { sd[rank] = dv; si[rank] = iv; }
+                if (r == 0) sm.nsel[qi * sm.Ls + c] = nin < MAXP ? nin : MAXP;
+            }
+            // prefilter overflow (massive ties): MAXP rounds of exact arg-min extraction over the chunk + running selection
+            unsigned long long mo = __ballot(live && ovf && r == 0);
+            while (mo) {
+                const int sl = s0 + (__builtin_ctzll(mo) >> 4); mo &= mo - 1;
+                const int qj = sgi + sl * nsub, nsj = sm.nsel[qj * sm.Ls + c];
+                double *sdj = sm.seld + ((size_t)qj * sm.Ls + c) * 8; int *sij = sm.seli + ((size_t)qj * sm.Ls + c) * 8;
+                const double x0 = sm.qf[qj][0], x1 = sm.qf[qj][1], x2 = sm.qf[qj][2], x3 = sm.qf[qj][3], x4 = sm.qf[qj][4];
+                const double od = lane < nsj ? sdj[lane] : INFINITY; const int oi = lane < nsj ? sij[lane] : 0x7fffffff;
+                double pd = -INFINITY; int pi = -1, got = 0;
+                double outd = 0.0; int outi = 0;
+                for (int rr = 0; rr < MAXP; rr++) {
+                    double bd = INFINITY; int bi = 0x7fffffff;
+                    if (k1_less(pd, pi, od, oi)) { bd = od; bi = oi; }
+                    for (int j = 0; j < K1_RPL; j++) {
+                        const int tj = t0 + lane + WAVE * j;
+                        if (tj < nrows) {
+                            double nrm = fabs((base[0 * ls + tj] - x0) * p.scaling[0]);
+                            nrm = nrm + fabs((base[1 * ls + tj] - x1) * p.scaling[1]);
+                            nrm = nrm + fabs((base[2 * ls + tj] - x2) * p.scaling[2]);
+                            nrm = nrm + fabs((base[6 * ls + tj] - x3) * p.scaling[3]);
+                            nrm = nrm + fabs((base[7 * ls + tj] - x4) * p.scaling[4]);
+                            if (nrm < h && k1_less(pd, pi, nrm, tj) && k1_less(nrm, tj, bd, bi)) { bd = nrm; bi = tj; }
+                        }
+                    }
+                    wave_argmin(bd, bi);
+                    if (!(bd < INFINITY)) break;
+                    if (lane == rr) { outd = bd; outi = bi; }
+                    pd = bd; pi = bi; got++;
+                }
+                if (lane < got) { sdj[lane] = outd; sij[lane] = outi; }
+                if (lane == 0) sm.nsel[qj * sm.Ls + c] = got;
+            }
+        }
+    }
+}
+
+// compute_Q_M / compute_b / LMPC_LocLinReg / regressionAndLinearization (PredictiveModel.py:48-178) for the nf queries q0 .. q0 + nf - 1 of the
+// pass (selection in sm.seld / seli / nsel), by the nt threads of the work-group: A_i | B_i | C_i end up in sm.outv[0 .. nf), status bits in
+// sm.st_s[q0 ..].  xq: the problem's xLin rows (6 doubles each, row i0 = first query of the pass).  Work-group barriers inside.
+__device__ __forceinline__ void k1_fit(const lmpc_dev_params &p, const k1_smem &sm, int q0, int nf, int tid, int nt, const double *xq_pass, int MAXP) {
+    const int L = p.trToUse, PP = L * MAXP;
+    const double h = p.h;
+    // ---- stage the selected points: slot = lap * MAXP + rank; empty slots carry weight K = 0 (they add exact zeros) ----
+    for (int e = tid; e < nf * PP; e += nt) {
+        const int ql = e / PP, qi = q0 + ql, sl = e % PP, c = sl / MAXP, r = sl % MAXP;
+        const int ns = sm.nsel[qi * sm.Ls + c];
+        const double *sd = sm.seld + ((size_t)qi * sm.Ls + c) * 8; const int *si = sm.seli + ((size_t)qi * sm.Ls + c) * 8;
+        double *pt = sm.pts[ql * PP + sl];
+        if (r < ns) {
+            int pick = r;
+            if (ns < MAXP) {                                           // fewer than MaxNumPoint inside h: np.where order = ascending row index
+                for (int a_ = 0; a_ < ns; a_++) {
+                    int rk = 0;
+                    for (int m2 = 0; m2 < ns; m2++) rk += si[m2] < si[a_] ? 1 : 0;
+                    if (rk == r) pick = a_;
+                }
+            }
+            const double dd = sd[pick]; const int ii = si[pick];
+            const double *base = p.mstore + (size_t)p.mslot[c] * LMPC_COLS * p.lap_stride;
+            double q = dd / h; q = q * q;
+            pt[0] = base[0 * p.lap_stride + ii]; pt[1] = base[1 * p.lap_stride + ii]; pt[2] = base[2 * p.lap_stride + ii];
+            pt[3] = base[6 * p.lap_stride + ii]; pt[4] = base[7 * p.lap_stride + ii]; pt[5] = (1.0 - q) * 3.0 / 4.0;        // :193
+            pt[6] = base[0 * p.lap_stride + ii + 1]; pt[7] = base[1 * p.lap_stride + ii + 1]; pt[8] = base[2 * p.lap_stride + ii + 1]; pt[9] = 1.0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 10; k++) pt[k] = 0.0;
+        }
+    }
+    __syncthreads();
+
+    // ---- compute_Q_M / compute_b (:141-168): Q = M' diag(K) M (+ lamb I), b = -M' diag(K) y ---------------------------
+    // 35 distinct sums per query: the vx system (15 + 5), and of the lateral system only what involves delta (5) and its two
+    // right-hand sides (10); the 10 entries of Q_lat over (vx, vy, wz, 1) are the same sums as in Q_vx and are copied.
+    for (int e2 = tid; e2 < nf * 35; e2 += nt) {
+        const int ql = e2 / 35, le = e2 % 35;
+        int r, cc, sys = le < 20 ? 0 : 1, tgt = -1, e;
+        if (le < 15) { e = le; r = 0; cc = e; while (cc >= 5 - r) { cc -= 5 - r; r++; } cc += r; }            // upper-triangular (r, cc)
+        else if (le < 20) { e = le; r = le - 15; cc = 0; tgt = 0; }
+        else if (le < 25) { const int k = le - 20; r = k < 3 ? k : 3; cc = k < 4 ? 3 : 4; e = r * 5 - r * (r - 1) / 2 + (cc - r); }
+        else { const int j = le - 25; r = j % 5; cc = 0; tgt = 1 + j / 5; e = 15 + j; }
+        const int fin = sys == 0 ? 4 : 3;        // column of pts holding the input feature: a (vx system) / delta (lateral)
+        const int o1 = r < 3 ? r : (r == 3 ? fin : 9), o2 = tgt >= 0 ? 6 + tgt : (cc < 3 ? cc : (cc == 3 ? fin : 9));
+        const double (*pq)[10] = &sm.pts[ql * PP];
+        double acc = 0.0;
+#pragma unroll 4
+        for (int q = 0; q < PP; q++) acc = fma(pq[q][o1] * pq[q][5], pq[q][o2], acc);
+        if (tgt >= 0) acc = -acc; else if (r == cc) acc += p.lamb;
+        sm.gram[ql][sys * 20 + e] = acc;
+        if (le < 15 && r != 3 && cc != 3) sm.gram[ql][20 + e] = acc;
+    }
+    __syncthreads();
+
+    // ---- LMPC_LocLinReg (:170-178): unconstrained qp(Q, b)  <=>  Q theta = -b ; Cholesky 5x5, one thread per system ----
+    if (tid < nf * 3) {
+        const int ql = tid / 3, qi = q0 + ql, sy = tid % 3;
+        const double *Qv = sy == 0 ? &sm.gram[ql][0] : &sm.gram[ql][20];
+        const double *bv = sy == 0 ? &sm.gram[ql][15] : (sy == 1 ? &sm.gram[ql][35] : &sm.gram[ql][40]);
+        double Lm[5][5]; int bad = 0;
+        { int e = 0; for (int r = 0; r < 5; r++) for (int c = r; c < 5; c++) { Lm[c][r] = Qv[e]; Lm[r][c] = Qv[e]; e++; } }
+        for (int j = 0; j < 5; j++) {
+            double dj = Lm[j][j];
+            for (int k = 0; k < j; k++) dj -= Lm[j][k] * Lm[j][k];
+            if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
+            dj = sqrt(dj); Lm[j][j] = dj;
+            for (int r = j + 1; r < 5; r++) {
+                double v = Lm[r][j];
+                for (int k = 0; k < j; k++) v -= Lm[r][k] * Lm[j][k];
+                Lm[r][j] = v / dj;
+            }
+        }
+        double y[5];
+        for (int r = 0; r < 5; r++) { double v = -bv[r]; for (int k = 0; k < r; k++) v -= Lm[r][k] * y[k]; y[r] = v / Lm[r][r]; }
+        for (int r = 4; r >= 0; r--) { double v = y[r]; for (int k = r + 1; k < 5; k++) v -= Lm[k][r] * y[k]; y[r] = v / Lm[r][r]; }
+        for (int r = 0; r < 5; r++) sm.theta[ql][sy * 5 + r] = bad ? 0.0 : y[r];
+        int npts = 0;
+        for (int c = 0; c < L; c++) npts += sm.nsel[qi * sm.Ls + c];
+        if (bad || npts < 5) atomicOr(&sm.st_s[qi], LMPC_ST_REG_SINGULAR);
+    }
+    for (int e = tid; e < nf * 54; e += nt) sm.outv[e / 54][e % 54] = 0.0;
+    __syncthreads();
+
+    // ---- assemble A_i, B_i, C_i (:70-135), one thread per query ------------------------------------------------------
+    if (tid < nf) {
+        const int ql = tid, qi = q0 + ql;
+        const double *xq = xq_pass + (size_t)qi * 6;
+        const double *th_ = sm.theta[ql];
+        double *Ai = sm.outv[ql], *Bi = sm.outv[ql] + 36, *Ci = sm.outv[ql] + 48;
+        for (int r = 0; r < 3; r++) { Ai[r * 6 + 0] = th_[r * 5 + 0]; Ai[r * 6 + 1] = th_[r * 5 + 1]; Ai[r * 6 + 2] = th_[r * 5 + 2]; Ci[r] = th_[r * 5 + 4]; }
+        Bi[0 * 2 + 1] = th_[0 * 5 + 3]; Bi[1 * 2 + 0] = th_[1 * 5 + 3]; Bi[2 * 2 + 0] = th_[2 * 5 + 3];
+        const double vx = xq[0], vy = xq[1], wz = xq[2], epsi = xq[3], s = xq[4], ey = xq[5], dt = p.dt;
+        int bad = 0;
+        const double cur = track_curvature(p, s, &bad);
+        if (bad) atomicOr(&sm.st_s[qi], LMPC_ST_NO_SEGMENT);
+        const double den = 1 - cur * ey, ce = cos(epsi), se = sin(epsi);
+        const double xv[6] = {vx, vy, wz, epsi, s, ey};
+        double row[6], dot;
+        row[0] = -dt * ce / den * cur; row[1] = dt * se / den * cur; row[2] = dt;
+        row[3] = 1 - dt * (-vx * se - vy * ce) / den * cur; row[4] = 0;
+        row[5] = dt * (vx * ce - vy * se) / (den * den) * cur * (-cur);
+        dot = 0; for (int j = 0; j < 6; j++) { Ai[18 + j] = row[j]; dot += row[j] * xv[j]; }
+        Ci[3] = epsi + dt * (wz - (vx * ce - vy * se) / (1 - cur * ey) * cur) - dot;
+        row[0] = dt * (ce / den); row[1] = -dt * (se / den); row[2] = 0; row[3] = dt * (-vx * se - vy * ce) / den; row[4] = 1;
+        row[5] = -dt * (vx * ce - vy * se) / (den * den) * (-cur);
+        dot = 0; for (int j = 0; j < 6; j++) { Ai[24 + j] = row[j]; dot += row[j] * xv[j]; }
+        Ci[4] = s + dt * ((vx * ce - vy * se) / (1 - cur * ey)) - dot;
+        row[0] = dt * se; row[1] = dt * ce; row[2] = 0; row[3] = dt * (vx * ce - vy * se); row[4] = 0; row[5] = 1;
+        dot = 0; for (int j = 0; j < 6; j++) { Ai[30 + j] = row[j]; dot += row[j] * xv[j]; }
+        Ci[5] = ey + dt * (vx * se + vy * ce) - dot;
+    }
+    __syncthreads();
+}
+
+// OCC: compile for four waves per SIMD (two work-groups per CU; <= 128 VGPRs) -- pays when the grid exceeds one work-group
+// per CU (1.47x at batch 4096); the other variant has the shorter latency when each CU runs a single group.
 template <bool OCC>
 __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_dev_params p, int B, int qg, const double *__restrict__ xLin, int xstride,
                                                              const double *__restrict__ uLin, double *__restrict__ Aout,
                                                              double *__restrict__ Bout, double *__restrict__ Cout, int *__restrict__ status) {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave-uniform by construction: lap pointers, row counts and loop bounds stay in SGPRs
-    __shared__ double qf[K1_QG][5];                                        // xuLin of the queries in flight (PredictiveModel.py:54)
-    __shared__ int cseg[K1_NW][K1_QG][16]; __shared__ int ccnt[K1_NW][K1_QG];   // prefilter survivors (row indices) per wave and query
-    __shared__ double seld[K1_QG][LMPC_MAX_USED_LAPS][8]; __shared__ int seli[K1_QG][LMPC_MAX_USED_LAPS][8];
-    __shared__ int nsel[K1_QG][LMPC_MAX_USED_LAPS];
-    __shared__ double pts[K1_PTS][10];           // vx vy wz delta a K y_vx y_vy y_wz 1   (PredictiveModel.py:141-168)
-    __shared__ double gram[K1_QG][45];           // Q_vx(15) b_vx(5) Q_lat(15) b_vy(5) b_wz(5)
-    __shared__ double theta[K1_QG][3][5];
+    __shared__ double qf[K1_QG][5];
+    __shared__ int cseg[K1_NW * K1_QG][16]; __shared__ int ccnt[K1_NW * K1_QG];
+    __shared__ double seld[K1_QG * LMPC_MAX_USED_LAPS * 8]; __shared__ int seli[K1_QG * LMPC_MAX_USED_LAPS * 8];
+    __shared__ int nsel[K1_QG * LMPC_MAX_USED_LAPS];
+    __shared__ double pts[K1_PTS][10];
+    __shared__ double gram[K1_QG][45];
+    __shared__ double theta[K1_QG][15];
     __shared__ double outv[K1_QG][54];
     __shared__ int st_s[K1_QG];
+    k1_smem sm; sm.qf = qf; sm.cseg = cseg; sm.ccnt = ccnt; sm.seld = seld; sm.seli = seli; sm.nsel = nsel; sm.Ls = LMPC_MAX_USED_LAPS;
+    sm.pts = pts; sm.gram = gram; sm.theta = theta; sm.outv = outv; sm.st_s = st_s;
 
     const int N = p.N, L = p.trToUse;
     const int MAXP = p.maxNumPoint > 8 ? 8 : p.maxNumPoint;
-    const int PP = L * MAXP;                                               // point slots per query (lap-major, rank-minor)
     const int QGe = k1_queries_per_block(qg, L, p.maxNumPoint);            // queries of this block
     const int npass = (N + QGe - 1) / QGe;
     const int b = blockIdx.x / npass;
     if (b >= B) return;
     const int nsub = K1_NW / L > 0 ? K1_NW / L : 1;                        // waves sharing one lap split its queries
     const int myc = wave % L, sgi = wave / L;
-    const double h = p.h;
+    const int i0 = (blockIdx.x % npass) * QGe;
+    const int nq = N - i0 < QGe ? N - i0 : QGe;
+    if (tid < nq * 5) {
+        const int qi = tid / 5, f = tid % 5;
+        qf[qi][f] = f < 3 ? xLin[(size_t)b * xstride + (size_t)(i0 + qi) * 6 + f] : uLin[((size_t)b * N + i0 + qi) * 2 + (f - 3)];
+    }
+    if (tid < nq * LMPC_MAX_USED_LAPS) nsel[tid] = 0;
+    if (tid < nq) st_s[tid] = 0;
+    __syncthreads();
+    // (two queries per trip in the low-occupancy build.  The occupancy build takes one per trip: with four waves per SIMD the other waves
+    //  fill the chain's latency, and the second query's 16 distances cost registers it does not have -- spilled registers are scratch
+    //  WRITES: 134 MB per launch at batch 4096 before this)
+    for (int c = myc; c < L && sgi < nsub; c += K1_NW)                    // (c += K1_NW: only when trToUse > 8 waves, never here)
+        k1_scan_lap<!OCC>(p, sm, c, wave * K1_QG, sgi, nsub, nq, lane, MAXP);
+    __syncthreads();
+    k1_fit(p, sm, 0, nq, tid, K1_NT, xLin + (size_t)b * xstride + (size_t)i0 * 6, MAXP);
+    for (int e = tid; e < nq * 54; e += K1_NT) {
+        const int qi = e / 54, le = e % 54; const size_t item = (size_t)b * N + i0 + qi;
+        if (le < 36) Aout[item * 36 + le] = outv[qi][le];
+        else if (le < 48) Bout[item * 12 + (le - 36)] = outv[qi][le];
+        else Cout[item * 6 + (le - 48)] = outv[qi][le];
+    }
+    if (tid < nq) status[(size_t)b * N + i0 + tid] = st_s[tid];
+}
 
-    {
-        const int i0 = (blockIdx.x % npass) * QGe;
-        const int nq = N - i0 < QGe ? N - i0 : QGe;
-        if (tid < nq * 5) {
-            const int qi = tid / 5, f = tid % 5;
-            qf[qi][f] = f < 3 ? xLin[(size_t)b * xstride + (size_t)(i0 + qi) * 6 + f] : uLin[((size_t)b * N + i0 + qi) * 2 + (f - 3)];
+// LDS doubles the regression of one QP by ONE wave needs behind [A_k | B_k] and C_k (fused step of lmpc_solve_kernel): the scan state of
+// up to K1_QG queries and the fit state of K1F_QF queries.  Host and device use the same rule.
+#define K1F_QF 2
+__host__ __device__ constexpr inline int k1_fused_doubles(int N, int L, int maxNumPoint) {
+    const int QG = N < K1_QG ? N : K1_QG, MAXP = maxNumPoint > 8 ? 8 : maxNumPoint, PP = L * MAXP;
+    const int ints = QG * 16 + QG + QG * L * 8 + QG * L + QG;                                  // cseg, ccnt, seli, nsel, st_s
+    return QG * 5 + QG * L * 8 + (ints + 1) / 2 + K1F_QF * (PP * 10 + 45 + 15 + 54);
+}
+// PredictiveModel.regressionAndLinearization for the N horizon points of problem b by the calling wave (block of one wave): results go to
+// AB / C in LDS in the solve kernel's layout (and to global memory if the pointers are given); returns the OR of the points' status bits.
+__device__ __forceinline__ int k1_wave_problem(const lmpc_dev_params &p, int b, int lane, const double *xLin_b, const double *uLin_b, double *wk,
+                                               double *AB, double *Cl, double *Aout, double *Bout, double *Cout) {
+    const int N = p.N, L = p.trToUse;
+    const int MAXP = p.maxNumPoint > 8 ? 8 : p.maxNumPoint, PP = L * MAXP;
+    const int QG = N < K1_QG ? N : K1_QG;
+    k1_smem sm; sm.Ls = L;
+    double *w = wk;
+    sm.qf = (double (*)[5])w; w += QG * 5;
+    sm.seld = w; w += QG * L * 8;
+    sm.pts = (double (*)[10])w; w += K1F_QF * PP * 10;
+    sm.gram = (double (*)[45])w; w += K1F_QF * 45;
+    sm.theta = (double (*)[15])w; w += K1F_QF * 15;
+    sm.outv = (double (*)[54])w; w += K1F_QF * 54;
+    int *wi = (int *)w;
+    sm.cseg = (int (*)[16])wi; wi += QG * 16;
+    sm.ccnt = wi; wi += QG;
+    sm.seli = wi; wi += QG * L * 8;
+    sm.nsel = wi; wi += QG * L;
+    sm.st_s = wi;
+    int st_all = 0;
+    for (int i0 = 0; i0 < N; i0 += QG) {
+        const int nq = N - i0 < QG ? N - i0 : QG;
+        for (int e = lane; e < nq * 5; e += WAVE) {
+            const int qi = e / 5, f = e % 5;
+            sm.qf[qi][f] = f < 3 ? xLin_b[(size_t)(i0 + qi) * 6 + f] : uLin_b[(size_t)(i0 + qi) * 2 + (f - 3)];
         }
-        if (tid < nq * LMPC_MAX_USED_LAPS) nsel[tid / LMPC_MAX_USED_LAPS][tid % LMPC_MAX_USED_LAPS] = 0;
-        if (tid < nq) st_s[tid] = 0;
+        for (int e = lane; e < nq * L; e += WAVE) sm.nsel[e] = 0;
+        if (lane < nq) sm.st_s[lane] = 0;
         __syncthreads();
-
-        // ---- computeIndices (PredictiveModel.py:180-197): wave (lap c, query share sgi) -------------------------------
-        for (int c = myc; c < L && sgi < nsub; c += K1_NW) {               // (c += K1_NW: only when trToUse > 8 waves, never here)
-            const double *base = p.mstore + (size_t)p.mslot[c] * LMPC_COLS * p.lap_stride;
-            const int ls = p.lap_stride;
-            const int nrows = p.mlen[c] - 1;
-            for (int t0 = 0; t0 < nrows; t0 += K1_CHUNK) {
-                // Prefilter image of this lane's rows: the scaled features in 16-bit fixed point, packed (vx, vy | wz, delta | a, flag),
-                // quantised by the host when the lap was stored (lmpc_capi.hip: quantise_lap), per 1024-row chunk over the chunk's own
-                // [min, max] with ONE scale for the five features (the L1 norm weighs them equally).  Three v_sad_u16 per row give the
-                // integer L1 distance; every decision is re-made in FP64 below.  A query outside [min, max] is clamped: that shifts all
-                // of a feature's |differences| by the same amount, so the order of the rows is untouched.  Rows beyond the lap carry
-                // 0xffff in the unused half-word (the query has 0 there): farther than a full range from everything.
-                const double *qp = p.mqpar + ((size_t)p.mslot[c] * p.mq_chunks + t0 / K1_CHUNK) * 6;
-                const double qlo[5] = {qp[0], qp[1], qp[2], qp[3], qp[4]}, qsc = qp[5];
-                const unsigned *qb = p.mquant + (size_t)p.mslot[c] * 3 * ls;
-                unsigned qv[3][K1_RPL];
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-#pragma unroll
-                    for (int j = 0; j < K1_RPL; j++) { const int t = t0 + lane + WAVE * j; qv[k][j] = qb[(size_t)k * ls + (t < nrows ? t : 0)]; }
-#pragma unroll
-                for (int j = 0; j < K1_RPL; j++) if (t0 + lane + WAVE * j >= nrows) qv[2][j] |= 0xffff0000u;
-                // ---- step A: integer prefilter, one query at a time; survivors (row indices) go to the query's 16-slot LDS segment ----
-                const int nqw = nq > sgi ? (nq - sgi + nsub - 1) / nsub : 0;                  // queries of this wave: qi = sgi + s nsub
-                // (two queries per trip: their reduction chains are independent and interleave.  The occupancy build takes one per trip:
-                //  with four waves per SIMD the other waves fill the chain's latency, and the second query's 16 distances cost registers
-                //  it does not have -- spilled registers are scratch WRITES: 134 MB per launch at batch 4096 before this)
-                constexpr bool PAIR = !OCC;
-                for (int s = 0; s < nqw; s += PAIR ? 2 : 1) {
-                    const bool two = PAIR && s + 1 < nqw;
-                    const int qa = sgi + s * nsub, qb2 = two ? qa + nsub : qa;
-                    unsigned ta5[5], tb5[5];
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        ta5[k] = (unsigned)fmin(fmax((qf[qa][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 65535.0);
-                        tb5[k] = (unsigned)fmin(fmax((qf[qb2][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 65535.0);
-                    }
-                    const unsigned ya[3] = {ta5[0] | (ta5[1] << 16), ta5[2] | (ta5[3] << 16), ta5[4]};
-                    const unsigned yb[3] = {tb5[0] | (tb5[1] << 16), tb5[2] | (tb5[3] << 16), tb5[4]};
-                    unsigned ea[K1_RPL], eb[K1_RPL], ma = 0xffffffffu, mb = 0xffffffffu;
-#pragma unroll
-                    for (int j = 0; j < K1_RPL; j++) {
-                        unsigned a_ = 0, b_ = 0;
-#pragma unroll
-                        for (int k = 0; k < 3; k++) { a_ = sad_u16(qv[k][j], ya[k], a_); if (PAIR) b_ = sad_u16(qv[k][j], yb[k], b_); }
-                        ea[j] = a_; eb[j] = b_; ma = a_ < ma ? a_ : ma; mb = b_ < mb ? b_ : mb;
-                    }
-                    // MAXP-th smallest distinct lane minimum: at least MAXP rows lie at or below it (one-instruction DPP integer minima)
-                    unsigned ba = 0u, bb = 0u;
-                    for (int r = 0; r < MAXP; r++) {
-                        ba = wminu((r == 0 || ma > ba) ? ma : 0xffffffffu);
-                        if (PAIR) bb = wminu((r == 0 || mb > bb) ? mb : 0xffffffffu);
-                    }
-                    // Two-sided bound.  Per feature |floor(a) - floor(b)| differs from |a - b| by < 1, so over the five features the
-                    // integer distance e of a row and its exact scaled distance d satisfy |e - d| < 5.  (i) At least MAXP rows have
-                    // e <= T (T = ba / bb), hence d < T + 5: the MAXP-th smallest exact distance is < T + 5.  (ii) A row of the exact
-                    // top MAXP therefore has d < T + 5 and e < d + 5 < T + 10, i.e. e <= T + 9.  Everything up to T + 10 survives
-                    // (one unit of margin for the rounding of the host's fixed-point conversion); the survivors are re-ranked in FP64.
-                    const unsigned ta = ba > 0xffffff00u ? 0xffffffffu : ba + 10u, tb = bb > 0xffffff00u ? 0xffffffffu : bb + 10u;
-                    int na = 0, nb = 0;
-#pragma unroll
-                    for (int j = 0; j < K1_RPL; j++) {
-                        const bool ca = ea[j] <= ta, cb = PAIR && eb[j] <= tb;
-                        const unsigned long long mka = __ballot(ca), mkb = PAIR ? __ballot(cb) : 0ull;
-                        if (mka | mkb) {
-                            const int pa = na + __builtin_amdgcn_mbcnt_hi((unsigned)(mka >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mka, 0));
-                            const int pb = nb + __builtin_amdgcn_mbcnt_hi((unsigned)(mkb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mkb, 0));
-                            if (ca && pa < 16) cseg[wave][s][pa] = t0 + lane + WAVE * j;
-                            if (cb && pb < 16 && two) cseg[wave][s + 1][pb] = t0 + lane + WAVE * j;
-                            na += __popcll(mka); nb += __popcll(mkb);
-                        }
-                    }
-                    if (lane == 0) { ccnt[wave][s] = na; if (two) ccnt[wave][s + 1] = nb; }
-                }
-                // ---- step B: exact FP64 distances of the survivors, four queries at a time (one per row of 16 lanes), ranked inside the
-                //      row by 15 DPP rotations; the running selection of earlier chunks rides along as extra entries ----
-                for (int s0 = 0; s0 < nqw; s0 += 4) {
-                    const int s = s0 + (lane >> 4), r = lane & 15;
-                    const bool live = s < nqw;
-                    const int qi = live ? sgi + s * nsub : 0;
-                    const int cnt = live ? ccnt[wave][live ? s : 0] : 0, ns = live ? nsel[qi][c] : 0;
-                    const bool ovf = cnt + ns > 16;
-                    double dv = INFINITY; int iv = 0x7fffffff;
-                    if (live && !ovf) {
-                        if (r < cnt) {
-                            iv = cseg[wave][s][r];
-                            const bool real = iv < nrows;
-                            iv = real ? iv : 0;
-                            // la.norm(diff, 1, axis=1) of (Data - x) . scaling : |.| accumulated in feature order, no contraction
-                            double nrm = fabs((base[0 * ls + iv] - qf[qi][0]) * p.scaling[0]);
-                            nrm = nrm + fabs((base[1 * ls + iv] - qf[qi][1]) * p.scaling[1]);
-                            nrm = nrm + fabs((base[2 * ls + iv] - qf[qi][2]) * p.scaling[2]);
-                            nrm = nrm + fabs((base[6 * ls + iv] - qf[qi][3]) * p.scaling[3]);
-                            nrm = nrm + fabs((base[7 * ls + iv] - qf[qi][4]) * p.scaling[4]);
-                            dv = real ? nrm : INFINITY;
-                        } else if (r < cnt + ns) { dv = seld[qi][c][r - cnt]; iv = seli[qi][c][r - cnt]; }
-                    }
-                    const bool in_h = dv < h;
-                    const double kd = in_h ? dv : INFINITY;                                   // rows outside h never outrank anything
-                    int rank = 0;
-                    k1_row_rank<1>(kd, iv, rank);
-                    const unsigned long long mh = __ballot(in_h);
-                    const int nin = __popcll((mh >> (lane & 48)) & 0xffffull);
-                    if (live && !ovf) {
-                        if (in_h && rank < MAXP) { seld[qi][c][rank] = dv; seli[qi][c][rank] = iv; }
-                        if (r == 0) nsel[qi][c] = nin < MAXP ? nin : MAXP;
-                    }
-                    // prefilter overflow (massive ties): MAXP rounds of exact arg-min extraction over the chunk + running selection
-                    unsigned long long mo = __ballot(live && ovf && r == 0);
-                    while (mo) {
-                        const int sl = s0 + (__builtin_ctzll(mo) >> 4); mo &= mo - 1;
-                        const int qj = sgi + sl * nsub, nsj = nsel[qj][c];
-                        const double x0 = qf[qj][0], x1 = qf[qj][1], x2 = qf[qj][2], x3 = qf[qj][3], x4 = qf[qj][4];
-                        const double od = lane < nsj ? seld[qj][c][lane] : INFINITY; const int oi = lane < nsj ? seli[qj][c][lane] : 0x7fffffff;
-                        double pd = -INFINITY; int pi = -1, got = 0;
-                        double outd = 0.0; int outi = 0;
-                        for (int rr = 0; rr < MAXP; rr++) {
-                            double bd = INFINITY; int bi = 0x7fffffff;
-                            if (k1_less(pd, pi, od, oi)) { bd = od; bi = oi; }
-                            for (int j = 0; j < K1_RPL; j++) {
-                                const int tj = t0 + lane + WAVE * j;
-                                if (tj < nrows) {
-                                    double nrm = fabs((base[0 * ls + tj] - x0) * p.scaling[0]);
-                                    nrm = nrm + fabs((base[1 * ls + tj] - x1) * p.scaling[1]);
-                                    nrm = nrm + fabs((base[2 * ls + tj] - x2) * p.scaling[2]);
-                                    nrm = nrm + fabs((base[6 * ls + tj] - x3) * p.scaling[3]);
-                                    nrm = nrm + fabs((base[7 * ls + tj] - x4) * p.scaling[4]);
-                                    if (nrm < h && k1_less(pd, pi, nrm, tj) && k1_less(nrm, tj, bd, bi)) { bd = nrm; bi = tj; }
-                                }
-                            }
-                            wave_argmin(bd, bi);
-                            if (!(bd < INFINITY)) break;
-                            if (lane == rr) { outd = bd; outi = bi; }
-                            pd = bd; pi = bi; got++;
-                        }
-                        if (lane < got) { seld[qj][c][lane] = outd; seli[qj][c][lane] = outi; }
-                        if (lane == 0) nsel[qj][c] = got;
-                    }
-                }
+        for (int c = 0; c < L; c++) k1_scan_lap<true>(p, sm, c, 0, 0, 1, nq, lane, MAXP);
+        __syncthreads();
+        for (int q0 = 0; q0 < nq; q0 += K1F_QF) {
+            const int nf = nq - q0 < K1F_QF ? nq - q0 : K1F_QF;
+            k1_fit(p, sm, q0, nf, lane, WAVE, xLin_b + (size_t)i0 * 6, MAXP);
+            for (int e = lane; e < nf * 54; e += WAVE) {
+                const int ql = e / 54, le = e % 54, k = i0 + q0 + ql; const double v = sm.outv[ql][le];
+                if (le < 36) { AB[k * 48 + (le / 6) * 8 + le % 6] = v; if (Aout) Aout[((size_t)b * N + k) * 36 + le] = v; }
+                else if (le < 48) { AB[k * 48 + ((le - 36) >> 1) * 8 + 6 + ((le - 36) & 1)] = v; if (Bout) Bout[((size_t)b * N + k) * 12 + (le - 36)] = v; }
+                else { Cl[k * 6 + (le - 48)] = v; if (Cout) Cout[((size_t)b * N + k) * 6 + (le - 48)] = v; }
             }
+            __syncthreads();
         }
-        __syncthreads();
-
-        // ---- stage the selected points: slot = lap * MAXP + rank; empty slots carry weight K = 0 (they add exact zeros) ----
-        for (int e = tid; e < nq * PP; e += K1_NT) {
-            const int qi = e / PP, sl = e % PP, c = sl / MAXP, r = sl % MAXP;
-            const int ns = nsel[qi][c];
-            double *pt = pts[qi * PP + sl];
-            if (r < ns) {
-                int pick = r;
-                if (ns < MAXP) {                                           // fewer than MaxNumPoint inside h: np.where order = ascending row index
-                    for (int a_ = 0; a_ < ns; a_++) {
-                        int rk = 0;
-                        for (int m2 = 0; m2 < ns; m2++) rk += seli[qi][c][m2] < seli[qi][c][a_] ? 1 : 0;
-                        if (rk == r) pick = a_;
-                    }
-                }
-                const double dd = seld[qi][c][pick]; const int ii = seli[qi][c][pick];
-                const double *base = p.mstore + (size_t)p.mslot[c] * LMPC_COLS * p.lap_stride;
-                double q = dd / h; q = q * q;
-                pt[0] = base[0 * p.lap_stride + ii]; pt[1] = base[1 * p.lap_stride + ii]; pt[2] = base[2 * p.lap_stride + ii];
-                pt[3] = base[6 * p.lap_stride + ii]; pt[4] = base[7 * p.lap_stride + ii]; pt[5] = (1.0 - q) * 3.0 / 4.0;        // :193
-                pt[6] = base[0 * p.lap_stride + ii + 1]; pt[7] = base[1 * p.lap_stride + ii + 1]; pt[8] = base[2 * p.lap_stride + ii + 1]; pt[9] = 1.0;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 10; k++) pt[k] = 0.0;
-            }
-        }
-        __syncthreads();
-
-        // ---- compute_Q_M / compute_b (:141-168): Q = M' diag(K) M (+ lamb I), b = -M' diag(K) y ---------------------------
-        // 35 distinct sums per query: the vx system (15 + 5), and of the lateral system only what involves delta (5) and its two
-        // right-hand sides (10); the 10 entries of Q_lat over (vx, vy, wz, 1) are the same sums as in Q_vx and are copied.
-        for (int e2 = tid; e2 < nq * 35; e2 += K1_NT) {
-            const int qi = e2 / 35, le = e2 % 35;
-            int r, cc, sys = le < 20 ? 0 : 1, tgt = -1, e;
-            if (le < 15) { e = le; r = 0; cc = e; while (cc >= 5 - r) { cc -= 5 - r; r++; } cc += r; }            // upper-triangular (r, cc)
-            else if (le < 20) { e = le; r = le - 15; cc = 0; tgt = 0; }
-            else if (le < 25) { const int k = le - 20; r = k < 3 ? k : 3; cc = k < 4 ? 3 : 4; e = r * 5 - r * (r - 1) / 2 + (cc - r); }
-            else { const int j = le - 25; r = j % 5; cc = 0; tgt = 1 + j / 5; e = 15 + j; }
-            const int fin = sys == 0 ? 4 : 3;        // column of pts holding the input feature: a (vx system) / delta (lateral)
-            const int o1 = r < 3 ? r : (r == 3 ? fin : 9), o2 = tgt >= 0 ? 6 + tgt : (cc < 3 ? cc : (cc == 3 ? fin : 9));
-            const double (*pq)[10] = &pts[qi * PP];
-            double acc = 0.0;
-#pragma unroll 4
-            for (int q = 0; q < PP; q++) acc = fma(pq[q][o1] * pq[q][5], pq[q][o2], acc);
-            if (tgt >= 0) acc = -acc; else if (r == cc) acc += p.lamb;
-            gram[qi][sys * 20 + e] = acc;
-            if (le < 15 && r != 3 && cc != 3) gram[qi][20 + e] = acc;
-        }
-        __syncthreads();
-
-        // ---- LMPC_LocLinReg (:170-178): unconstrained qp(Q, b)  <=>  Q theta = -b ; Cholesky 5x5, one thread per system ----
-        if (tid < nq * 3) {
-            const int qi = tid / 3, sy = tid % 3;
-            const double *Qv = sy == 0 ? &gram[qi][0] : &gram[qi][20];
-            const double *bv = sy == 0 ? &gram[qi][15] : (sy == 1 ? &gram[qi][35] : &gram[qi][40]);
-            double Lm[5][5]; int bad = 0;
-            { int e = 0; for (int r = 0; r < 5; r++) for (int c = r; c < 5; c++) { Lm[c][r] = Qv[e]; Lm[r][c] = Qv[e]; e++; } }
-            for (int j = 0; j < 5; j++) {
-                double dj = Lm[j][j];
-                for (int k = 0; k < j; k++) dj -= Lm[j][k] * Lm[j][k];
-                if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
-                dj = sqrt(dj); Lm[j][j] = dj;
-                for (int r = j + 1; r < 5; r++) {
-                    double v = Lm[r][j];
-                    for (int k = 0; k < j; k++) v -= Lm[r][k] * Lm[j][k];
-                    Lm[r][j] = v / dj;
-                }
-            }
-            double y[5];
-            for (int r = 0; r < 5; r++) { double v = -bv[r]; for (int k = 0; k < r; k++) v -= Lm[r][k] * y[k]; y[r] = v / Lm[r][r]; }
-            for (int r = 4; r >= 0; r--) { double v = y[r]; for (int k = r + 1; k < 5; k++) v -= Lm[k][r] * y[k]; y[r] = v / Lm[r][r]; }
-            for (int r = 0; r < 5; r++) theta[qi][sy][r] = bad ? 0.0 : y[r];
-            int npts = 0;
-            for (int c = 0; c < L; c++) npts += nsel[qi][c];
-            if (bad || npts < 5) atomicOr(&st_s[qi], LMPC_ST_REG_SINGULAR);
-        }
-        for (int e = tid; e < nq * 54; e += K1_NT) outv[e / 54][e % 54] = 0.0;
-        __syncthreads();
-
-        // ---- assemble A_i, B_i, C_i (:70-135), one thread per query ------------------------------------------------------
-        if (tid < nq) {
-            const int qi = tid;
-            const double *xq = xLin + (size_t)b * xstride + (size_t)(i0 + qi) * 6;
-            double *Ai = outv[qi], *Bi = outv[qi] + 36, *Ci = outv[qi] + 48;
-            for (int r = 0; r < 3; r++) { Ai[r * 6 + 0] = theta[qi][r][0]; Ai[r * 6 + 1] = theta[qi][r][1]; Ai[r * 6 + 2] = theta[qi][r][2]; Ci[r] = theta[qi][r][4]; }
-            Bi[0 * 2 + 1] = theta[qi][0][3]; Bi[1 * 2 + 0] = theta[qi][1][3]; Bi[2 * 2 + 0] = theta[qi][2][3];
-            const double vx = xq[0], vy = xq[1], wz = xq[2], epsi = xq[3], s = xq[4], ey = xq[5], dt = p.dt;
-            int bad = 0;
-            const double cur = track_curvature(p, s, &bad);
-            if (bad) atomicOr(&st_s[qi], LMPC_ST_NO_SEGMENT);
-            const double den = 1 - cur * ey, ce = cos(epsi), se = sin(epsi);
-            const double xv[6] = {vx, vy, wz, epsi, s, ey};
-            double row[6], dot;
-            row[0] = -dt * ce / den * cur; row[1] = dt * se / den * cur; row[2] = dt;
-            row[3] = 1 - dt * (-vx * se - vy * ce) / den * cur; row[4] = 0;
-            row[5] = dt * (vx * ce - vy * se) / (den * den) * cur * (-cur);
-            dot = 0; for (int j = 0; j < 6; j++) { Ai[18 + j] = row[j]; dot += row[j] * xv[j]; }
-            Ci[3] = epsi + dt * (wz - (vx * ce - vy * se) / (1 - cur * ey) * cur) - dot;
-            row[0] = dt * (ce / den); row[1] = -dt * (se / den); row[2] = 0; row[3] = dt * (-vx * se - vy * ce) / den; row[4] = 1;
-            row[5] = -dt * (vx * ce - vy * se) / (den * den) * (-cur);
-            dot = 0; for (int j = 0; j < 6; j++) { Ai[24 + j] = row[j]; dot += row[j] * xv[j]; }
-            Ci[4] = s + dt * ((vx * ce - vy * se) / (1 - cur * ey)) - dot;
-            row[0] = dt * se; row[1] = dt * ce; row[2] = 0; row[3] = dt * (vx * ce - vy * se); row[4] = 0; row[5] = 1;
-            dot = 0; for (int j = 0; j < 6; j++) { Ai[30 + j] = row[j]; dot += row[j] * xv[j]; }
-            Ci[5] = ey + dt * (vx * se + vy * ce) - dot;
-        }
-        __syncthreads();
-        for (int e = tid; e < nq * 54; e += K1_NT) {
-            const int qi = e / 54, le = e % 54; const size_t item = (size_t)b * N + i0 + qi;
-            if (le < 36) Aout[item * 36 + le] = outv[qi][le];
-            else if (le < 48) Bout[item * 12 + (le - 36)] = outv[qi][le];
-            else Cout[item * 6 + (le - 48)] = outv[qi][le];
-        }
-        if (tid < nq) status[(size_t)b * N + i0 + tid] = st_s[tid];
+        if (lane < nq) st_all |= sm.st_s[lane];
         __syncthreads();
     }
+    return st_all;                     // per-lane partial OR (the caller folds it into the work-group's status word)
 }
 
 // parameter block staged in LDS (lane-dependent indexing of kernel arguments would go through global memory)
@@ -893,6 +980,14 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
     int tcnt = 0; (void)tcnt;
     TSTAMP(0);
     if (lane == 0) st_sh = 0;
+    if (io.mode & 4) {
+        // K1 (fused step): LTV regression of this QP's N points by this wave, in the LDS behind AB / C that the solve needs only later
+        __syncthreads();
+        const int rst = k1_wave_problem(p, b, lane, io.xLin + (size_t)b * (N + 1) * 6, io.uLin + (size_t)b * N * 2, sm + LL::oC + 6 * N, AB, C,
+                                        io.Aout, io.Bout, io.Cout);
+        if (rst) atomicOr(&st_sh, rst);
+        __syncthreads();
+    }
     // stage the parameter block
     if (lane < 12) par[PAR_FX + lane] = p.Fx[lane];
     if (lane < 8) par[PAR_FU + lane] = p.Fu[lane];
@@ -915,9 +1010,12 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
     // LMPC.unpackSolution (:364-375); inequality rows in the reference's order (buildIneqConstr :166-198,
     // addSafeSetIneqConstr :340-343).  s_T is eliminated (s_T = SS lambda - x_N).
     // ------------------------------------------------------------------------------------------------
-    FOR_LANES(i, 36 * N) { const int k = i / 36, r = (i % 36) / 6, c = i % 6; AB[k * 48 + r * 8 + c] = io.A[(size_t)b * 36 * N + i]; }
-    FOR_LANES(i, 12 * N) { const int k = i / 12, r = (i % 12) >> 1, c = i & 1; AB[k * 48 + r * 8 + 6 + c] = io.Bm[(size_t)b * 12 * N + i]; }
-    FOR_LANES(i, 6 * N) { C[i] = io.C[(size_t)b * 6 * N + i]; nu[i] = 0.0; }
+    if (!(io.mode & 4)) {
+        FOR_LANES(i, 36 * N) { const int k = i / 36, r = (i % 36) / 6, c = i % 6; AB[k * 48 + r * 8 + c] = io.A[(size_t)b * 36 * N + i]; }
+        FOR_LANES(i, 12 * N) { const int k = i / 12, r = (i % 12) >> 1, c = i & 1; AB[k * 48 + r * 8 + 6 + c] = io.Bm[(size_t)b * 12 * N + i]; }
+        FOR_LANES(i, 6 * N) C[i] = io.C[(size_t)b * 6 * N + i];
+    }
+    FOR_LANES(i, 6 * N) nu[i] = 0.0;
     if (lane < 6) x[lane] = io.x0[(size_t)b * 6 + lane];
     FOR_LANES(i, 2 * N) u[i] = 0.0;
     const double uOld0 = io.uOld[(size_t)b * 2 + 0], uOld1 = io.uOld[(size_t)b * 2 + 1];

@@ -20,10 +20,17 @@ struct lmpc_variant_api {
 
 template <int N, int S> struct lmpc_variant_launchers {
     static constexpr size_t lds1 = (size_t)solve_lds1<N, S>::tot * sizeof(double), ldsm = (size_t)solve_lds<N, S>::tot * sizeof(double);
+    // fused step (io.mode & 4): the regression's work space sits behind [A_k | B_k], C_k; it fits the solve's footprint at the reference's
+    // settings (4 laps x 7 points) and grows it a little beyond
+    static size_t lds_for(const lmpc_dev_params &p, const lmpc_solve_io &io) {
+        const size_t f = (io.mode & 4) ? (size_t)(54 * N + k1_fused_doubles(N, p.trToUse, p.maxNumPoint)) * sizeof(double) : 0;
+        return f > lds1 ? f : lds1;
+    }
+    static constexpr size_t lds1_max() { const size_t f = (size_t)(54 * N + k1_fused_doubles(N, LMPC_MAX_USED_LAPS, 8)) * sizeof(double); return f > lds1 ? f : lds1; }
     static int l1(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
-        hipLaunchKernelGGL((lmpc_solve_kernel<N, S>), dim3(B), dim3(WAVE), lds1, st, p, B, io); return 0; }
+        hipLaunchKernelGGL((lmpc_solve_kernel<N, S>), dim3(B), dim3(WAVE), lds_for(p, io), st, p, B, io); return 0; }
     static int lr(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
-        hipLaunchKernelGGL((lmpc_solve_kernel<N, S, true>), dim3(B), dim3(WAVE), lds1, st, p, B, io); return 0; }
+        hipLaunchKernelGGL((lmpc_solve_kernel<N, S, true>), dim3(B), dim3(WAVE), lds_for(p, io), st, p, B, io); return 0; }
     static int l4(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
         hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 4>), dim3(B), dim3(WAVE * 4), ldsm, st, p, B, io); return 0; }
     static int l2(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
@@ -36,8 +43,8 @@ template <int N, int S> static bool lmpc_variant_fill(lmpc_variant_api *v) {
     using L = lmpc_variant_launchers<N, S>;
     v->N = N; v->S = S;
     v->lds_mw = (size_t)solve_lds<N, S>::tot * sizeof(double); v->lds_1w = (size_t)solve_lds1<N, S>::tot * sizeof(double);
-    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_1w) != hipSuccess) return false;
-    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_1w) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::lds1_max()) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::lds1_max()) != hipSuccess) return false;
     if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_mw) != hipSuccess) return false;
     if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_mw) != hipSuccess) return false;
     v->launch_1w = &L::l1; v->launch_retry = &L::lr; v->launch_mw4 = &L::l4; v->launch_mw2 = &L::l2;

@@ -272,3 +272,34 @@ def test_inexact_status_is_usable(built):
                 seen += 1
     print("inexact problems checked:", seen)
     ctx.close()
+
+
+def test_fused_step_matches_two_kernel_step(built):
+    """With LMPC_FUSE=1 batches that run one wavefront per QP take the fused step (the wave runs the LTV regression of its own QP in front
+    of the solve, A_i / B_i / C_i stay in LDS); the default is the regression kernel + solve kernel pair.  Same arithmetic in the same order:
+    every output is bitwise identical, including the optional copies of A, B, C and the per-problem status of an off-track point."""
+    import os
+    from racinglmpc_amd import _capi
+    import bench
+    g = bench.load_seed()
+    N, B = 12, 2048
+    inp = bench.synth_batch(g, B, N, seed=77)
+    inp["xLin"][5, 3, 4] = -3.0                                   # off-track linearisation point: the reference raises, here a status bit
+    outs = []
+    for fuse in ("0", "1"):
+        os.environ["LMPC_FUSE"] = fuse
+        try:
+            ctx = bench.make_ctx(g, N, B, 0)
+        finally:
+            del os.environ["LMPC_FUSE"]
+        assert ctx.solver_waves(B) == 1
+        ctx.reset_stats(); ctx.set_profiling(True)
+        outs.append(ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"]))
+        st = ctx.stats(); ctx.set_profiling(False)
+        assert (st.n_regress == 0) == (fuse == "1")               # the fused step launches no regression kernel
+        ctx.close()
+    a, b = outs
+    assert a["status"][5] & _capi.ST_NO_SEGMENT and b["status"][5] & _capi.ST_NO_SEGMENT
+    assert int(np.sum(a["status"] != 0)) == 1
+    for k in ("A", "B", "C", "xPred", "uPred", "slack", "lambd", "sTerm", "ztNext", "ztuNext", "ssSel", "qSel", "mu", "status", "iters"):
+        assert np.array_equal(a[k], b[k]), k
