@@ -67,6 +67,9 @@ typedef struct {
     int max_laps, max_lap_len;  /* lap-store capacity (rows per lap include addPoint extensions) */
     /* solver: structure-exploiting primal-dual interior point on the block-banded KKT system */
     double tol_gap, tol_res, reg_lambda; int max_iter;
+    int slacks;                 /* MPCParams.slacks (:184-198, 218-221, 248-254): 1 = lane rows softened by slack variables (main.py always);
+                                   0 = hard lane rows Fx x_k <= bx, no slack variables in the QP (plain MPC only: numSS_it = 0).  Solved with an internal
+                                   quadratic slack weight of 1e12: a hard row may be exceeded by mu / 2e12 ~ 1e-11; the `slack` output holds that excess. */
 } lmpc_config;
 
 typedef struct {

@@ -350,8 +350,9 @@ def block_diag(*mats):
 class QPParams:
     """Numeric content of MPCParams (PredictiveControllers.py:24-51) + LMPC ctor args (:293)."""
 
-    def __init__(self, N, Q, R, Qf, dR, Qslack, Fx, bx, Fu, bu, xRef, QterminalSlack=None, numSS_Points=0, numSS_it=0):
+    def __init__(self, N, Q, R, Qf, dR, Qslack, Fx, bx, Fu, bu, xRef, QterminalSlack=None, numSS_Points=0, numSS_it=0, slacks=True):
         self.n, self.d, self.N = 6, 2, N
+        self.slacks = bool(slacks)
         self.Q = np.asarray(Q, float); self.R = np.asarray(R, float); self.Qf = np.asarray(Qf, float)
         self.dR = np.asarray(dR, float).reshape(-1); self.Qslack = np.asarray(Qslack, float).reshape(-1)
         self.Fx = np.asarray(Fx, float); self.bx = np.squeeze(np.asarray(bx, float)).reshape(-1)
@@ -379,7 +380,7 @@ class QPParams:
 
 
 def build_ineq(p):
-    """MPC.buildIneqConstr, :166-198 (slacks=True)."""
+    """MPC.buildIneqConstr, :166-198 (both branches of `self.slacks`, :184-198)."""
     N = p.N
     Mat = block_diag(*([p.Fx] * N))
     Fxtot = np.hstack((Mat, np.zeros((Mat.shape[0], p.n))))
@@ -387,6 +388,8 @@ def build_ineq(p):
     Futot = block_diag(*([p.Fu] * N))
     butot = np.tile(p.bu, N)
     F_hard = block_diag(Fxtot, Futot)
+    if not p.slacks:                                   # :196-198
+        return F_hard, np.hstack((bxtot, butot))
     nc_x = p.Fx.shape[0]
     addSlack = np.zeros((F_hard.shape[0], nc_x * N))
     addSlack[0:nc_x * N, 0:nc_x * N] = -np.eye(nc_x * N)
@@ -397,7 +400,7 @@ def build_ineq(p):
 
 
 def build_cost(p, OldInput):
-    """MPC.buildCost, :228-257 (slacks=True)."""
+    """MPC.buildCost, :228-257 (both branches of `self.slacks`, :248-254)."""
     N, d = p.N, p.d
     Hx = block_diag(*([p.Q] * N))
     Hu = block_diag(*([p.R + 2 * np.diag(p.dR)] * N))
@@ -408,6 +411,8 @@ def build_cost(p, OldInput):
     np.fill_diagonal(Hu[:, d:], OffDiaf)
     q = -2 * np.dot(np.append(np.tile(p.xRef, N + 1), np.zeros(p.R.shape[0] * N)), block_diag(Hx, p.Qf, Hu))
     q[p.n * (N + 1):p.n * (N + 1) + d] = -2 * np.dot(np.reshape(OldInput, (-1,))[0:d], np.diag(p.dR))
+    if not p.slacks:                                   # :252-254
+        return 2 * block_diag(Hx, p.Qf, Hu), q
     nc_x = p.Fx.shape[0]
     H = block_diag(Hx, p.Qf, Hu, p.Qslack[0] * np.eye(nc_x * N))
     q = np.append(q, p.Qslack[1] * np.ones(nc_x * N))
@@ -426,7 +431,7 @@ def build_eq(p, A, B, C):
         Gu[(n + i * n):(n + i * n + n), (i * d):(i * d + d)] = -(B[i] if ltv else B)
         if ltv:
             L[(n + i * n):(n + i * n + n)] = C[i]
-    G = np.hstack((Gx, Gu, np.zeros((Gx.shape[0], p.Fx.shape[0] * N))))
+    G = np.hstack((Gx, Gu, np.zeros((Gx.shape[0], p.Fx.shape[0] * N)))) if p.slacks else np.hstack((Gx, Gu))     # :218-221
     return G, E, L
 
 

@@ -12,7 +12,8 @@ Differences to the reference that a caller can observe
     eps = 1e-3 iterate whenever OSQP's polish step fails;
   * the dense matrices H, q, F, b, G, E, L are not kept as attributes (they are never materialised); use
     qp_matrices() to get the reference-form H_FTOCP, q_FTOCP, [F;G], l, u of the current step for inspection;
-  * slacks=False is not supported (the reference's main.py always uses slacks=True).
+  * slacks=False: MPC only (hard lane rows, PredictiveControllers.py:184-198); LMPC(slacks=False) fails inside the reference itself (unpackSolution
+    mis-slices the solution without slack variables), so the drop-in refuses it.
 """
 import datetime
 from dataclasses import dataclass, field
@@ -77,8 +78,11 @@ class MPC():
         self.predictiveModel = predictiveModel
         if self.n != 6 or self.d != 2:
             raise _capi.LmpcError("the GPU path is built for the racing model: n = 6 states, d = 2 inputs")
-        if not self.slacks:
-            raise NotImplementedError("slacks=False is not supported by the GPU solver")
+        if not self.slacks and self._numSS_it > 0:
+            # PredictiveControllers.py:364-375: LMPC.unpackSolution computes the offsets of lambda and of the terminal slack as if the 2N slack
+            # variables were there; without them lambd is read 2N entries late (and too short), and feasibleStateInput (:382-384) then fails on
+            # the shapes.  There is no reference behaviour to reproduce.
+            raise NotImplementedError("LMPC with slacks=False: the reference's own LMPC.unpackSolution / feasibleStateInput fail on this combination")
         self._ctx = None
         self._make_context()
         if self.timeVarying == True:
@@ -102,7 +106,7 @@ class MPC():
         TL = pm.map.TrackLength if has_model else 0.0
         cfg = _capi.config_from(self.N, self.Q, self.R, self.Qf, self.dR, self.Qslack, self.Fx, self.bx, self.Fu, self.bu, self.xRef,
                                 QterminalSlack=self._QterminalSlack, numSS_Points=self._numSS_Points, numSS_it=self._numSS_it,
-                                trToUse=len(pm.usedIt) if has_model else 0, track=track, trackLength=TL, max_batch=1)
+                                trToUse=len(pm.usedIt) if has_model else 0, track=track, trackLength=TL, max_batch=1, slacks=bool(self.slacks))
         if has_model:
             cfg.maxNumPoint = int(pm.MaxNumPoint); cfg.h = float(pm.h); cfg.lamb = float(pm.lamb); cfg.dt = float(pm.dt)
             for i in range(5):
@@ -152,7 +156,7 @@ class MPC():
         out = self._out
         self.xPred = out["xPred"][0].copy()
         self.uPred = out["uPred"][0].copy()
-        self.slack = out["slack"][0].copy()
+        self.slack = out["slack"][0].copy() if self.slacks else np.zeros(0)            # slacks=False: z = [x, u] only (:218-221)
         self.Solution = np.concatenate([self.xPred.ravel(), self.uPred.ravel(), self.slack])
 
     def _raise_on_status(self, st, x0):

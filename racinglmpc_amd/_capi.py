@@ -28,7 +28,7 @@ class LmpcConfig(C.Structure):
         ("Fx", C.c_double * 12), ("bx", C.c_double * 2), ("Fu", C.c_double * 8), ("bu", C.c_double * 4),
         ("track", C.c_double * (MAX_TRACK_ROWS * 6)), ("track_rows", C.c_int), ("trackLength", C.c_double),
         ("device", C.c_int), ("max_batch", C.c_int), ("max_laps", C.c_int), ("max_lap_len", C.c_int),
-        ("tol_gap", C.c_double), ("tol_res", C.c_double), ("reg_lambda", C.c_double), ("max_iter", C.c_int),
+        ("tol_gap", C.c_double), ("tol_res", C.c_double), ("reg_lambda", C.c_double), ("max_iter", C.c_int), ("slacks", C.c_int),
     ]
 
 
@@ -426,7 +426,7 @@ class Context:
 
 
 def config_from(N, Q, R, Qf, dR, Qslack, Fx, bx, Fu, bu, xRef, QterminalSlack=None, numSS_Points=0, numSS_it=0, trToUse=0,
-                track=None, trackLength=0.0, max_batch=256, max_laps=64, max_lap_len=2048, device=0, **solver):
+                track=None, trackLength=0.0, max_batch=256, max_laps=64, max_lap_len=2048, device=0, slacks=True, **solver):
     """Build an LmpcConfig from the numeric content of MPCParams / LMPC ctor args / Map."""
     cfg = default_config()
     cfg.N = int(N); cfg.numSS_it = int(numSS_it); cfg.numSS_points = int(numSS_Points) if numSS_it else 0; cfg.trToUse = int(trToUse)
@@ -448,6 +448,7 @@ def config_from(N, Q, R, Qf, dR, Qslack, Fx, bx, Fu, bu, xRef, QterminalSlack=No
         cfg.track_rows = track.shape[0]
     cfg.trackLength = float(trackLength)
     cfg.max_batch, cfg.max_laps, cfg.max_lap_len, cfg.device = int(max_batch), int(max_laps), int(max_lap_len), int(device)
+    cfg.slacks = 1 if slacks else 0
     for k, v in solver.items():
         setattr(cfg, k, v)
     return cfg

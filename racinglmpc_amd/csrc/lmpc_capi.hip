@@ -97,7 +97,7 @@ int lmpc_config_default(lmpc_config *c) {
     c->bu[0] = c->bu[1] = 0.5; c->bu[2] = c->bu[3] = 10.0;
     c->track_rows = 0; c->trackLength = 0.0;
     c->device = 0; c->max_batch = 256; c->max_laps = 64; c->max_lap_len = 2048;
-    c->tol_gap = 1e-11; c->tol_res = 1e-9; c->reg_lambda = 1e-6; c->max_iter = 40;
+    c->tol_gap = 1e-11; c->tol_res = 1e-9; c->reg_lambda = 1e-6; c->max_iter = 40; c->slacks = 1;
     return LMPC_OK;
 }
 
@@ -113,7 +113,14 @@ static void fill_params(lmpc_ctx *c) {
     for (int i = 0; i < 6; i++) { p.T2[i] = 2 * f.QtermSlack[i * 7]; p.xRef[i] = f.xRef[i]; }
     memcpy(p.Fx, f.Fx, sizeof(p.Fx)); memcpy(p.bx, f.bx, sizeof(p.bx)); memcpy(p.Fu, f.Fu, sizeof(p.Fu)); memcpy(p.bu, f.bu, sizeof(p.bu));
     memcpy(p.track, f.track, sizeof(double) * 6 * f.track_rows); p.track_rows = f.track_rows; p.TL = f.trackLength;
-    p.tol_gap = f.tol_gap; p.tol_res = f.tol_res; p.reg = f.reg_lambda; p.max_iter = f.max_iter;
+    p.tol_gap = f.tol_gap; p.tol_res = f.tol_res; p.reg = f.reg_lambda; p.max_iter = f.max_iter; p.slacks = f.slacks ? 1 : 0;
+    if (!f.slacks) {
+        // MPCParams.slacks = False (PredictiveControllers.py:184-198): hard lane rows.  The solve kernels keep their slack variables with a quadratic
+        // weight of 1e12 and no linear term: a lane row can then be exceeded by mu / 2e12 ~ 1e-11 m, a thousand times below the solver's own tolerance,
+        // and the stage Hessians stay bounded -- a hard row's barrier weight mu^2 / gap enters them directly and costs the Riccati recursion
+        // the dual residual below gap ~ 1e-9 (NumPy model: |x - x*| stalls at 1e-7 .. 1e-5 on the fixture; with the penalty 2e-9 in <= 10 iterations).
+        p.a_s = 2.0e12; p.c_s = 0.0;
+    }
     p.lap_stride = f.max_lap_len; p.mstore = c->mstore; p.sstore = c->sstore;
     p.mquant = c->mquant; p.mqpar = c->mqpar; p.mq_chunks = c->mq_chunks;
 }
@@ -175,6 +182,7 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
         for (int i = 0; i < 6; i++) ARGCHK(cfg->QtermSlack[i * 7] > 0.0);
     }
     ARGCHK(cfg->track_rows >= 0 && cfg->track_rows <= LMPC_MAX_TRACK_ROWS);
+    ARGCHK(cfg->slacks || cfg->numSS_it == 0);          // hard lane rows: plain MPC only (the reference's LMPC.unpackSolution mis-slices without slack variables)
     ARGCHK(cfg->max_batch >= 1 && cfg->max_laps >= 1 && cfg->max_lap_len >= 8);
     lmpc_ctx *c = new lmpc_ctx();                      // value-initialised: every pointer starts as nullptr, so lmpc_destroy is safe at any point
     c->cfg = *cfg; c->profiling = 0; c->ro = nullptr; c->var_dl = nullptr; c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
@@ -540,8 +548,9 @@ int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, co
 int lmpc_qp_dims(lmpc_ctx *c, int *nz, int *m_ineq, int *m_eq) {
     ARGCHK(c);
     const int N = c->cfg.N, S = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0;
-    if (nz) *nz = 6 * (N + 1) + 4 * N + (S > 0 ? S + 6 : 0);
-    if (m_ineq) *m_ineq = 8 * N + S;
+    const int ns = c->cfg.slacks ? 2 * N : 0;
+    if (nz) *nz = 6 * (N + 1) + 2 * N + ns + (S > 0 ? S + 6 : 0);
+    if (m_ineq) *m_ineq = 6 * N + ns + S;
     if (m_eq) *m_eq = 6 * (N + 1) + (S > 0 ? 7 : 0);
     return LMPC_OK;
 }

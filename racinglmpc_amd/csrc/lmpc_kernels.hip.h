@@ -17,7 +17,7 @@
 #include "../../include/lmpc_hip.h"
 
 #define WAVE 64
-#define LMPC_VARIANT_ABI 3              // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change
+#define LMPC_VARIANT_ABI 4              // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change
 #define LMPC_COLS 9                 // lap-store columns: x0..x5, u0, u1, Qfun
 
 struct lmpc_dev_params {
@@ -28,6 +28,7 @@ struct lmpc_dev_params {
     double Fx[12], bx[2], Fu[8], bu[4];
     double track[LMPC_MAX_TRACK_ROWS * 6]; int track_rows; double TL;
     double tol_gap, tol_res, reg; int max_iter;
+    int slacks;                     // MPCParams.slacks; 0: the explicit matrices have no slack columns / rows; the solve kernels see a_s = 2e12, c_s = 0 (see fill_params)
     int lap_stride;                 // rows per column (max_lap_len)
     const double *mstore; int mslot[LMPC_MAX_USED_LAPS]; int mlen[LMPC_MAX_USED_LAPS];
     const unsigned *mquant; const double *mqpar; int mq_chunks;   // K1 prefilter image of the model store (16-bit fixed point, three packed words per row) and its per-chunk (lo[5], scale)
@@ -1783,8 +1784,9 @@ __global__ __launch_bounds__(256) void lmpc_assemble_kernel(lmpc_dev_params p, i
                                                             double *__restrict__ l, double *__restrict__ u) {
     const int b = blockIdx.x; if (b >= B) return;
     const int N = p.N, S = p.S, n = 6, d = 2;
-    const int ox = 0, ou = n * (N + 1), os = ou + d * N, ol = os + 2 * N, ot = ol + S, nz = S > 0 ? ot + n : ol;
-    const int mi = 8 * N + S, me = n * (N + 1) + (S > 0 ? n + 1 : 0), mm = mi + me;
+    const int ns = p.slacks ? 2 * N : 0;                 // slack variables and their positivity rows (MPCParams.slacks, :184-198)
+    const int ox = 0, ou = n * (N + 1), os = ou + d * N, ol = os + ns, ot = ol + S, nz = S > 0 ? ot + n : ol;
+    const int mi = 6 * N + ns + S, me = n * (N + 1) + (S > 0 ? n + 1 : 0), mm = mi + me;
     double *Pb = Pd + (size_t)b * nz * nz, *Ab = Ad + (size_t)b * mm * nz, *qb = q + (size_t)b * nz, *lb = l + (size_t)b * mm, *ub = u + (size_t)b * mm;
     const double *Ab_ = A + (size_t)b * 36 * N, *Bb_ = Bm + (size_t)b * 12 * N, *Cb_ = C + (size_t)b * 6 * N;
     for (size_t i = threadIdx.x; i < (size_t)nz * nz; i += blockDim.x) Pb[i] = 0.0;
@@ -1806,15 +1808,15 @@ __global__ __launch_bounds__(256) void lmpc_assemble_kernel(lmpc_dev_params p, i
         Pb[(size_t)(ou + k * 2 + r) * nz + ou + k * 2 + c] = v;
         if (r == c && k < N - 1) { Pb[(size_t)(ou + k * 2 + r) * nz + ou + (k + 1) * 2 + r] = -p.dR2[r]; Pb[(size_t)(ou + (k + 1) * 2 + r) * nz + ou + k * 2 + r] = -p.dR2[r]; }
     }
-    for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) Pb[(size_t)(os + i) * nz + os + i] = p.a_s;
+    for (int i = threadIdx.x; i < ns; i += blockDim.x) Pb[(size_t)(os + i) * nz + os + i] = p.a_s;
     if (S > 0) for (int i = threadIdx.x; i < 6; i += blockDim.x) Pb[(size_t)(ot + i) * nz + ot + i] = p.T2[i];
     // inequality rows
     for (int r = threadIdx.x; r < mi; r += blockDim.x) {
         double *row = Ab + (size_t)r * nz; double bb = 0.0;
-        if (r < 2 * N) { const int k = r >> 1, j = r & 1; for (int c = 0; c < 6; c++) row[ox + k * 6 + c] = p.Fx[j * 6 + c]; row[os + r] = -1.0; bb = p.bx[j]; }
+        if (r < 2 * N) { const int k = r >> 1, j = r & 1; for (int c = 0; c < 6; c++) row[ox + k * 6 + c] = p.Fx[j * 6 + c]; if (ns) row[os + r] = -1.0; bb = p.bx[j]; }
         else if (r < 6 * N) { const int qd = r - 2 * N, k = qd >> 2, j = qd & 3; row[ou + k * 2] = p.Fu[j * 2]; row[ou + k * 2 + 1] = p.Fu[j * 2 + 1]; bb = p.bu[j]; }
-        else if (r < 8 * N) row[os + (r - 6 * N)] = -1.0;
-        else row[ol + (r - 8 * N)] = -1.0;
+        else if (r < 6 * N + ns) row[os + (r - 6 * N)] = -1.0;
+        else row[ol + (r - 6 * N - ns)] = -1.0;
         lb[r] = -INFINITY; ub[r] = bb;
     }
     // equality rows

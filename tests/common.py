@@ -34,10 +34,13 @@ def lmpc_config(g, N=12, max_batch=64, numSS_it=4, numSS_Points=None, **kw):
     return cfg, par
 
 
-def mpc_config(g, N=12, max_batch=64, **kw):
+def mpc_config(g, N=12, max_batch=64, bx=None, **kw):
     from oracle import lmpc_oracle as orc
     from racinglmpc_amd import _capi
     par = orc.QPParams.mpc_default(N, 0.8)
+    if bx is not None:
+        par.bx = np.array([float(bx), float(bx)])
+    par.slacks = bool(kw.get("slacks", True))
     cfg = _capi.config_from(N, par.Q, par.R, par.Qf, par.dR, par.Qslack, par.Fx, par.bx, par.Fu, par.bu, par.xRef,
                             numSS_it=0, trToUse=1, track=g["track"], trackLength=float(g["trackLength"]), max_batch=max_batch, **kw)
     return cfg, par

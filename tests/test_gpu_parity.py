@@ -1,5 +1,7 @@
 """-m gpu: parity of the HIP path (through the C ABI) against the reference-executed golden fixtures and the
 certified optimum.  Needs a real MI355X; nothing here reads /root/reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -116,6 +118,44 @@ def test_ltv_mpc_variant(built):
     assert err < common.TOL_XU
     # zt / zt_u of the plain MPC are the last predicted state / input (MPC.feasibleStateInput)
     assert np.array_equal(out["ztNext"], out["xPred"][:, -1, :]) and np.array_equal(out["ztuNext"], out["uPred"][:, -1, :])
+    ctx.close()
+
+
+def test_mpc_hard_lane_constraints(built):
+    """MPCParams(slacks=False) (PredictiveControllers.py:184-198, 218-221, 248-254): no slack variables, hard lane rows.  Fixture recorded from the
+    executed reference class (tests/golden/make_noslack_golden.py; lane half-width 1 cm so that up to five hard rows are active):
+    explicit matrices bit-exact, solution at the certified optimum of the reference's own QP, multipliers certify it, every kernel variant.
+    (The solve kernels impose the hard rows through slack variables with a quadratic weight of 1e12, see fill_params in lmpc_capi.hip.)"""
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    g = np.load(os.path.join(common.GOLDEN, "ltvmpc_noslack_n12.npz"))
+    N, n = 12, len(g["x0"])
+    cfg, par = common.mpc_config(g, N, max_batch=1200, bx=float(g["bx"]), slacks=False)
+    ctx = _capi.Context(cfg)
+    assert ctx.qp_dims() == (6 * (N + 1) + 2 * N, 6 * N, 6 * (N + 1))
+    ctx.model_add_trajectory(g["xPID"], g["uPID"])
+    # a10-a12 without slacks: the explicit matrices are the reference's, bit for bit
+    P, q, Ad, l, u = ctx.assemble_batch(g["A"], g["B"], g["C"], g["x0"], g["OldInput"])
+    for r in range(n):
+        Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="")
+        assert np.array_equal(P[r], Pr) and np.array_equal(q[r], qr) and np.array_equal(Ad[r], Ar) and np.array_equal(l[r], lr) and np.array_equal(u[r], ur)
+    worst = wcert = 0.0
+    for reps in (1, 40, 80):                                     # 14 / 560 / 1120 problems: four, two and one wave(s) per QP
+        rep = lambda a: np.tile(a, (reps,) + (1,) * (a.ndim - 1))
+        out = ctx.step_batch(rep(g["x0"]), rep(g["xLin"]), rep(g["uLin"]), rep(g["OldInput"]))
+        assert np.all(out["status"] == 0), (reps, np.unique(out["status"], return_counts=True))
+        assert np.abs(out["slack"]).max() < 1e-9                                       # excess over a hard row: mu / 2e12
+        for b in range(n * reps):
+            r = b % n
+            w = np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()])
+            worst = max(worst, np.abs(w - g["sol_opt"][r]).max())
+            if b < n:
+                Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="")
+                wcert = max(wcert, max(common.certificate(Pr, qr, Ar, lr, ur, w, out["mu"][b][:6 * N], 6 * N).values()))
+        assert len({ctx.solver_waves(n * k) for k in (1, 40, 80)}) == 3
+    nact = int(np.sum(np.abs((Ad[:, :2 * N] @ g["sol_opt"][..., None])[..., 0] - u[:, :2 * N]) < 1e-7))
+    print("slacks=False: worst |xu - opt| %.2e, certificate %.2e, active hard lane rows in the fixture %d" % (worst, wcert, nact))
+    assert worst < common.TOL_XU and wcert < common.TOL_KKT and nact >= 20
     ctx.close()
 
 
@@ -257,6 +297,22 @@ def test_dropin_mpc_variants(built):
     # LTI: A, B from the fixture's first stage, no model
     p2 = MPCParams(n=6, d=2, N=N, A=gl["A"][0][0], B=gl["B"][0][0], Q=par.Q, R=par.R, Fx=par.Fx, bx=(np.array([[2.], [2.]]),), Fu=par.Fu,
                    bu=np.array([[0.5], [0.5], [10.0], [10.0]]), xRef=par.xRef, slacks=True, Qslack=par.Qslack)
+    # slacks=False (hard lane rows, here 1 cm wide): first closed-loop step of the reference-executed fixture
+    gn = np.load(os.path.join(common.GOLDEN, "ltvmpc_noslack_n12.npz"))
+    bxn = float(gn["bx"])
+    p3 = MPCParams(n=6, d=2, N=N, Q=par.Q, R=par.R, Fx=par.Fx, bx=(np.array([[bxn], [bxn]]),), Fu=par.Fu, bu=np.array([[0.5], [0.5], [10.0], [10.0]]),
+                   xRef=par.xRef, slacks=False, Qslack=par.Qslack, timeVarying=True)
+    pm3 = PredictiveModel(6, 2, mp, 1)
+    pm3.addTrajectory(gn["xPID"].copy(), gn["uPID"].copy())
+    hard = MPC(p3, pm3)
+    hard.solve(gn["x0"][0])
+    assert hard.feasible == 1 and hard.Solution.shape == (6 * (N + 1) + 2 * N,)                 # z = [x, u]: no slack entries (:218-221)
+    assert np.abs(hard.Solution - gn["sol_opt"][0]).max() < common.TOL_XU
+    Ph, qh, Ah, lh, uh = hard.qp_matrices()
+    Pr, qr, Ar, lr, ur = common.dense_from_csc(gn, 0, prefix="")
+    assert Ph.shape == Pr.shape and Ah.shape == Ar.shape and np.array_equal(Ph, Pr) and np.array_equal(qh, qr)
+    assert np.array_equal(Ah[:6 * N], Ar[:6 * N]) and np.array_equal(uh[:6 * N], ur[:6 * N])     # F, b: exact; G carries the regression's A_i, B_i (1e-9 parity)
+    assert np.allclose(Ah, Ar, rtol=0, atol=1e-8) and np.allclose(uh, ur, rtol=0, atol=1e-8)
     lti = MPC(p2)
     lti.solve(gl["x0"][0])
     P, q, A, l, u = orc.assemble_mpc_qp(par, gl["A"][0][0], gl["B"][0][0], None, gl["x0"][0], np.zeros(2))

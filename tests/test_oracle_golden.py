@@ -120,3 +120,17 @@ def test_lti_regression_restatement_matches_reference():
     for name, x, u, lamb, A, B, E, cond in _regression_cases():
         A2, B2, E2 = orc.lti_regression(x, u, lamb)
         assert np.array_equal(A2, A) and np.array_equal(B2, B) and np.array_equal(E2, E), name
+
+
+def test_oracle_noslack_assembly_matches_reference():
+    """MPCParams(slacks=False): the restated buildIneqConstr / buildCost / buildEqConstr branches (PredictiveControllers.py:184-198, 218-221,
+    248-254) reproduce the matrices the executed reference built (tests/golden/make_noslack_golden.py), bit for bit; the recorded optimum is certified."""
+    import os
+    g = np.load(os.path.join(common.GOLDEN, "ltvmpc_noslack_n12.npz"))
+    par = orc.QPParams.mpc_default(12, 0.8); par.slacks = False; par.bx = np.array([float(g["bx"])] * 2)
+    for r in range(len(g["x0"])):
+        P, q, A, l, u = common.dense_from_csc(g, r, prefix="")
+        P2, q2, A2, l2, u2 = orc.assemble_mpc_qp(par, g["A"][r], g["B"][r], g["C"][r], g["x0"][r], g["OldInput"][r])
+        assert np.array_equal(P, P2) and np.array_equal(q, q2) and np.array_equal(A, A2) and np.array_equal(l, l2) and np.array_equal(u, u2)
+        assert P.shape == (102, 102) and A.shape == (72 + 78, 102)
+        assert max(orc.kkt_certificate(P, q, A, l, u, g["sol_opt"][r], g["y_opt"][r]).values()) < 1e-9
