@@ -336,8 +336,13 @@ def main():
     comm.barrier()
     comm.close()
     ctx.close()
+    try:    # librccl announces its version through C stdio; drain that buffer now, so that the JSON line is the LAST thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

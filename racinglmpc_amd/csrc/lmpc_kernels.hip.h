@@ -768,9 +768,17 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
         // Rounding leaves Pi slightly unsymmetric, the A form of the next stage reads Pi', and U above takes rows for columns:
         // unsymmetrised, that asymmetry feeds back into the symmetric part at first order (it cost definiteness near convergence
         // at N = 40).  One cross-lane transpose per stage removes it.
+#ifdef RICC_VAR_NOSYM                  // (tools/microbench_ricc.hip: what the transpose costs -- 80 of 934 cycles per stage)
+        Piq = Piu;
+#else
         Piq = 0.5 * (Piu + lane_gather(Piu, c.qT));
+#endif
+#ifndef RICC_VAR_NOSTORE              // (tools/microbench_ricc.hip: what the LDS stores cost -- 90 cycles per stage)
         Phi[k * 64 + c.qR * 8 + c.qC] = Phq; if (PiAll) PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
         if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 3 ? i11 : i01);
+#else
+        if (k == 0) { Phi[c.qR * 8 + c.qC] = Phq; if (lane < 4) Mi[lane] = i00 + i01 + i11; }
+#endif
         if constexpr (STEP) { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     }
     return bad;

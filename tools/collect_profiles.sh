@@ -30,3 +30,7 @@ for B in $BATCHES; do
 done
 cd $ROOT
 ls -la $OUT | grep $TAG
+# phase timings of one QP (developer build with cycle stamps) and the RCCL branch on one rank
+LMPC_TIMING_MW=1 python tools/phase_timing.py > $OUT/${TAG}_phase_timing_mw4.txt 2>&1
+python tools/phase_timing.py > $OUT/${TAG}_phase_timing_1w.txt 2>&1
+LMPC_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --rollouts-per-gpu 256 > $OUT/${TAG}_bench_rccl_1rank.json 2> $OUT/${TAG}_bench_rccl_1rank.err

@@ -34,7 +34,7 @@ ids, cyc = ids[:n], cyc[:n]
 names = {(0, 1): "prologue+select", (1, 10): "init (load, rollout)", (10, 11): "residuals", (11, 12): "factor: terminal (MGS2, Ri, PiT)",
          (12, 13): "factor: stages", (13, 30): "solve A: pre", (30, 31): "solve: backward sweep", (31, 32): "solve: k0/phi", (32, 33): "solve: forward sweep",
          (33, 14): "solve A: post", (14, 15): "predictor post (steps, sigma, h)", (15, 30): "solve B: pre", (33, 16): "solve B: post",
-         (10, 12): "mw phase 1: terminal factor || residuals + predictor rhs", (12, 13): "mw phase 2: Riccati stages || predictor back-sweep + phi followers",
+         (10, 12): "mw phase 1: terminal factor || residuals + predictor rhs", (12, 19): "mw phase 2: Riccati stages || predictor back-sweep + phi one stage behind", (19, 13): "mw phase 2: last pipeline step",
          (13, 33): "mw solve A: forward sweep", (16, 17): "corrector post (dm, alpha)", (17, 18): "costates", (12, 13): "factor: stages", (11, 12): "kappa + terminal factor", (18, 10): "update", (18, 20): "update(last)", (10, 20): "final residual check", (20, 21): "epilogue"}
 acc = collections.OrderedDict()
 for i in range(1, n):
