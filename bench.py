@@ -91,12 +91,15 @@ def pid_laps(ctx, g, n_laps, max_steps=600):
     return [(X[i, :min(done[i] + 20, X.shape[1])], U[i, :min(done[i] + 20, X.shape[1])]) for i in range(n_laps)]
 
 
+PROFILE_EVERY = 5      # HIP events around every 5th launch of each kernel inside the timed region (an event record costs ~4 us of stream time)
+
+
 def time_steps(ctx, B, a, steps, warmup, sync=None):
     """W untimed + K timed full steps on device-resident buffers; returns (seconds, stats of the timed launches)."""
     for _ in range(warmup):
         ctx.step_batch_dev(B, a)
     (sync or ctx.sync)()
-    ctx.reset_stats(); ctx.set_profiling(True)
+    ctx.reset_stats(); ctx.set_profiling(PROFILE_EVERY)
     t0 = time.perf_counter()
     for _ in range(steps):
         ctx.step_batch_dev(B, a)
@@ -116,7 +119,7 @@ def run_config(g, N, B, device, steps, warmup, laps=None, query_lap=None, **kw):
     ctx.dev_download(a.status, status); ctx.dev_download(a.iters, iters)
     out = dict(batch=B, N=N, solves_per_s=B * steps / dt, ms_per_step=dt / steps * 1e3, solved_ok=int(np.sum(status == 0)),
                ipm_iters_mean=float(iters.mean()), ipm_iters_max=int(iters.max()), waves_per_qp=ctx.solver_waves(B),
-               kernel_ms={"lmpc_solve_kernel": st.ms_solve / max(st.n_solve, 1), "lmpc_regress_kernel": st.ms_regress / st.n_regress if st.n_regress else None},
+               kernel_ms={"lmpc_solve_kernel": st.ms_solve / max(st.n_solve_timed, 1), "lmpc_regress_kernel": st.ms_regress / st.n_regress_timed if st.n_regress_timed else None},
                fused_step=st.n_regress == 0)
     for p in keep:
         ctx.dev_free(p)
@@ -276,7 +279,7 @@ def main():
 
     out = None
     if rank == 0:
-        ms_solve = st.ms_solve / max(st.n_solve, 1); ms_reg = st.ms_regress / st.n_regress if st.n_regress else None      # (None: fused step, no regression kernel)
+        ms_solve = st.ms_solve / max(st.n_solve_timed, 1); ms_reg = st.ms_regress / st.n_regress_timed if st.n_regress_timed else None      # (None: fused step, no regression kernel)
         bytes_per_solve = 8 * (18 * N + 92)                     # SURVEY 8(d) B_solve: compulsory in+out per full step
         achieved = B * bytes_per_solve / (ms_solve * 1e-3) / 1e9
         nw = ctx.solver_waves(B)
@@ -299,7 +302,8 @@ def main():
                        "solver": "Riccati-structured primal-dual interior point to certified optimum (gap<1e-11, res<1e-9)",
                        "ranks": world, "collective_backend": "rccl" if comm_info[2] else "none", "rccl_ranks": comm_info[1] if comm_info[2] else 0},
             "solved_ok": n_ok, "solved_of": world * B, "ipm_iters_mean": float(iters.mean()), "ipm_iters_max": int(iters.max()),
-            "kernel_ms": {"lmpc_solve_kernel": ms_solve, "lmpc_regress_kernel": ms_reg},
+            "kernel_ms": {"lmpc_solve_kernel": ms_solve, "lmpc_regress_kernel": ms_reg, "timed_launches": int(st.n_solve_timed),
+                          "how": "HIP events on the launch stream around every %d-th launch of each kernel inside the timed region" % PROFILE_EVERY},
             "solver_only_solves_per_s": B / (ms_solve * 1e-3), "regression_only_solves_per_s": B / (ms_reg * 1e-3) if ms_reg else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": kname, "algorithmic_bytes_per_launch": B * bytes_per_solve,

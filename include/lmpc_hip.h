@@ -77,6 +77,7 @@ typedef struct {
     long long n_regress, n_solve;     /* launches accumulated */
     long long qp_solved;              /* problems passed through the solve kernel */
     long long ipm_iters;              /* interior-point iterations accumulated by the host-buffer entry points (lmpc_step_batch, lmpc_qp_solve_batch) */
+    long long n_regress_timed, n_solve_timed;   /* launches that carried events: ms_regress / n_regress_timed is the average kernel duration */
 } lmpc_stats;
 
 int lmpc_config_default(lmpc_config *cfg);                       /* reference defaults, N = 12 */
@@ -201,7 +202,8 @@ int lmpc_selftest(lmpc_ctx *);                   /* device self test of the cros
 /* Developer switch (environment, read at lmpc_create): LMPC_MW_MAX_BATCH=<n> overrides the largest batch that runs four waves per
  * QP (default: the number of CUs; 0 forces the one-wave kernel everywhere).  Results do not depend on it beyond summation order. */
 int lmpc_solver_waves(lmpc_ctx *, int B);         /* wavefronts per QP the solve kernel uses for a batch of B (4 or 2: lmpc_solve_kernel_mw, 1: lmpc_solve_kernel) */
-int lmpc_set_profiling(lmpc_ctx *, int on);       /* HIP events around each kernel launch */
+int lmpc_set_profiling(lmpc_ctx *, int every);    /* 0: off; k > 0: HIP events on the launch stream around every k-th launch of each kernel (an event
+                                                     record costs ~4 us of stream time: k = 1 adds 15 us to a two-kernel step) */
 int lmpc_get_stats(lmpc_ctx *, lmpc_stats *out);  /* drains pending events */
 int lmpc_reset_stats(lmpc_ctx *);
 

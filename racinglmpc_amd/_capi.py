@@ -34,7 +34,7 @@ class LmpcConfig(C.Structure):
 
 class LmpcStats(C.Structure):
     _fields_ = [("ms_regress", C.c_double), ("ms_solve", C.c_double), ("n_regress", C.c_longlong), ("n_solve", C.c_longlong),
-                ("qp_solved", C.c_longlong), ("ipm_iters", C.c_longlong)]
+                ("qp_solved", C.c_longlong), ("ipm_iters", C.c_longlong), ("n_regress_timed", C.c_longlong), ("n_solve_timed", C.c_longlong)]
 
 
 class StepDevArgs(C.Structure):
@@ -413,8 +413,9 @@ class Context:
     def selftest(self):
         _chk(self.lib.lmpc_selftest(self._h))
 
-    def set_profiling(self, on):
-        _chk(self.lib.lmpc_set_profiling(self._h, C.c_int(1 if on else 0)))
+    def set_profiling(self, every):
+        """False / 0: off; True / 1: events around every kernel launch; k: around every k-th launch of each kernel (see lmpc_set_profiling)."""
+        _chk(self.lib.lmpc_set_profiling(self._h, C.c_int(int(every))))
 
     def stats(self):
         s = LmpcStats()

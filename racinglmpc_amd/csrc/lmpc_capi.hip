@@ -38,7 +38,7 @@ struct lmpc_ctx {
     void *var_dl;                            // dlopen handle when that instantiation lives in its own shared object (lmpc_variant.hip)
     int mw_max_batch, n_cu;
     int fuse_k1;                             // fused step for one-wave batches (LMPC_FUSE=0 turns it off)
-    int profiling; std::vector<evpair> events; lmpc_stats stats;
+    int profiling; bool ev_open; std::vector<evpair> events; lmpc_stats stats;
     struct lmpc_rollout_session *ro;
     void *comm; int comm_rank, comm_world;   // RCCL communicator of this rank (lmpc_comm.hip.h); null = single process
 };
@@ -364,11 +364,16 @@ static int refresh_params(lmpc_ctx *c, bool need_model, bool need_ss) {
     return LMPC_OK;
 }
 
+// HIP events around a kernel launch (profiling on).  An event record costs ~4 us on the launch stream -- 15 us per step for the two kernels,
+// 5 % of a batch-256 step -- so profiling = k times every k-th launch of a kind only: the average duration is sampled over the run.
 static void ev_begin(lmpc_ctx *c, int kind) {
+    c->ev_open = false;
     if (!c->profiling) return;
-    evpair e; hipEventCreate(&e.a); hipEventCreate(&e.b); e.kind = kind; hipEventRecord(e.a, c->stream); c->events.push_back(e);
+    const long long idx = kind == 0 ? c->stats.n_regress : c->stats.n_solve;
+    if (idx % c->profiling) return;
+    evpair e; hipEventCreate(&e.a); hipEventCreate(&e.b); e.kind = kind; hipEventRecord(e.a, c->stream); c->events.push_back(e); c->ev_open = true;
 }
-static void ev_end(lmpc_ctx *c) { if (c->profiling) hipEventRecord(c->events.back().b, c->stream); }
+static void ev_end(lmpc_ctx *c) { if (c->ev_open) hipEventRecord(c->events.back().b, c->stream); c->ev_open = false; }
 
 // K1 launch shape: queries per work-group shrink (12 -> 6 -> 4 -> ... -> 1) until the grid covers the chip (one work-group per CU is resident)
 static void k1_grid(lmpc_ctx *c, int B, int *qg, int *nblk) {
@@ -811,12 +816,12 @@ int lmpc_selftest(lmpc_ctx *c) {
 
 int lmpc_solver_waves(lmpc_ctx *c, int B) { if (!c) return LMPC_E_ARG; return B <= c->mw_max_batch ? 4 : (B <= 4 * c->n_cu && c->mw_max_batch == c->n_cu) ? 2 : 1; }
 
-int lmpc_set_profiling(lmpc_ctx *c, int on) { ARGCHK(c); c->profiling = on ? 1 : 0; return LMPC_OK; }
+int lmpc_set_profiling(lmpc_ctx *c, int every) { ARGCHK(c); c->profiling = every > 0 ? every : 0; return LMPC_OK; }
 static int drain_events(lmpc_ctx *c) {
     HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
     for (auto &e : c->events) {
         float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
-        if (e.kind == 0) c->stats.ms_regress += ms; else c->stats.ms_solve += ms;
+        if (e.kind == 0) { c->stats.ms_regress += ms; c->stats.n_regress_timed++; } else { c->stats.ms_solve += ms; c->stats.n_solve_timed++; }
         hipEventDestroy(e.a); hipEventDestroy(e.b);
     }
     c->events.clear();
