@@ -721,24 +721,31 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
     const int qr = c.qr;
     int bad = 0;
     double Piq = c.w_xx ? Qf2[c.qR * 6 + c.qC] + (term ? PiT[c.qR * 6 + c.qC] : 0.0) : 0.0;   // Pi_N = [[2Qf + Pi_term, 0], [0, 0]]
-    // stage operands are fetched one stage ahead: the loads and the W arithmetic of stage k - 1 fill the latency of stage k's chain
+    // Stage operands are fetched one stage ahead.  The twelve LDS reads of stage k - 1 are ISSUED at the top of stage k (a compiler fence
+    // pins them there) and their arithmetic -- the six-term sum that builds the stage Hessian W -- runs at the bottom, behind the chain of
+    // matrix-core instructions: left to itself the compiler put reads and sum together on the loop's back edge, one s_waitcnt per pair of
+    // reads, ~350 stalled cycles at the start of every stage.
     double lB0, lA0, lB1, lA1, lBe, lTop, Wq;
-    auto stage_operands = [&](int k) {
+    double wk0, wk1, wt0, wt1, wt2, wt3;
+    auto stage_loads = [&](int k) {
         const double *ABk = AB + k * 48;
         lB0 = ABk[c.oB0]; lA0 = ABk[c.oA0]; lB1 = ABk[c.oB1]; lA1 = ABk[c.oA1]; lBe = ABk[c.oBe]; lTop = ABk[c.oTop];
-        double w = fma(kap[2 * k + 1], c.wf1, fma(kap[2 * k], c.wf0, c.wq));
-#pragma unroll
-        for (int j = 0; j < 4; j++) w = fma(th[2 * N + 4 * k + j], c.wfu[j], w);
+        wk0 = kap[2 * k]; wk1 = kap[2 * k + 1]; wt0 = th[2 * N + 4 * k]; wt1 = th[2 * N + 4 * k + 1]; wt2 = th[2 * N + 4 * k + 2]; wt3 = th[2 * N + 4 * k + 3];
+        asm volatile("" ::: "memory");
+    };
+    auto stage_hessian = [&]() {
+        double w = fma(wk1, c.wf1, fma(wk0, c.wf0, c.wq));
+        w = fma(wt0, c.wfu[0], w); w = fma(wt1, c.wfu[1], w); w = fma(wt2, c.wfu[2], w); w = fma(wt3, c.wfu[3], w);
         Wq = w;
     };
-    stage_operands(N - 1);
+    stage_loads(N - 1); stage_hessian();
 #pragma unroll 1
     for (int k = N - 1; k >= 0; k--) {
         const double cB0 = lB0, cA0 = lA0, cW = Wq;
         const double arB1 = qr < 2 ? lB1 : c.idB1, arA1 = qr < 2 ? lA1 : c.idA1;           // Ar (B form) and Ar' (A form), K = 1
         const double be = c.cA < 6 ? lBe : c.idBe;                                         // [B; I] as A operand; its K >= 2 lanes meet K = 0
         const double top = c.w_xx ? lTop : 0.0;
-        if (k > 0) stage_operands(k - 1);
+        stage_loads(k > 0 ? k - 1 : 0);                                                    // (stage 0 re-reads itself: no branch in the loop body)
         // T = Pi Ar: A form of the symmetric Pi = in-row block copies [0,0,1,1] (K = 0) and [2,2,3,3] (K = 1) of its quad form
         const double pA0 = dpp_blk<0x118, 0x8>(dpp_blk<0x114, 0x6>(Piq, Piq), Piq);       // row_shr:4 -> banks 1, 2; row_shr:8 -> bank 3
         const double pA1 = dpp_blk<0x108, 0x1>(dpp_blk<0x104, 0x6>(Piq, Piq), Piq);       // row_shl:4 -> banks 1, 2; row_shl:8 -> bank 0
@@ -768,6 +775,7 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
         // Rounding leaves Pi slightly unsymmetric, the A form of the next stage reads Pi', and U above takes rows for columns:
         // unsymmetrised, that asymmetry feeds back into the symmetric part at first order (it cost definiteness near convergence
         // at N = 40).  One cross-lane transpose per stage removes it.
+        stage_hessian();                                                                   // W of the next stage, behind the chain above
 #ifdef RICC_VAR_NOSYM                  // (tools/microbench_ricc.hip: what the transpose costs -- 80 of 934 cycles per stage)
         Piq = Piu;
 #else

@@ -13,6 +13,9 @@
 #include "lmpc_kernels.hip.h"
 
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// Compiler fence behind a group of LDS reads into locals: all of them are issued before the first use (one latency for the group).  With the
+// register file full the compiler otherwise interleaves read pairs with their arithmetic, one s_waitcnt and one LDS round trip per pair.
+#define LDS_GROUP() asm volatile("" ::: "memory")
 // barrier of one pipeline step (phase 2 of the Newton iteration): every wave of the work-group executes the same number of them
 #define STEP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #ifdef LMPC_TIMING
@@ -174,9 +177,14 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 ct[lane] = c_t;
                 WSYNC();
                 double acc = 0.0;                               // M c~ : lane (j, part) adds 8 of the 64 columns
-                if (lg < 7) {
+                {
+                    double mq[8], cq[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) acc = fma(Mt[lc * 8 + lg + 64 * q], ct[lc + 8 * q], acc);
+                    for (int q = 0; q < 8; q++) { mq[q] = Mt[lc * 8 + (lg < 7 ? lg : 0) + 64 * q]; cq[q] = ct[lc + 8 * q]; }
+                    LDS_GROUP();
+#pragma unroll
+                    for (int q = 0; q < 8; q++) acc = fma(mq[q], cq[q], acc);
+                    acc = lg < 7 ? acc : 0.0;
                 }
                 acc = sum_over_c(acc);
                 if (lg < 7 && lc == 0) McL[lg] = acc;
@@ -218,6 +226,7 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
 #pragma unroll
                 for (int k = 0; k < N; k++) gm[k] = (k & 1) ? gam[k * 8 + lg] : gam[k * 8 + lc];
                 double pv = ((N - 1) & 1) ? pst[N * 8 + lc] : pst[N * 8 + lg];
+                LDS_GROUP();
 #pragma unroll
                 for (int k = N - 1; k >= 0; k--) {
                     double pr = ph[k] * pv;
@@ -234,6 +243,7 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 const double bq0 = lc < 6 ? AB[kk * 48 + lc * 8 + 6] : (lc == 6 ? 1.0 : 0.0), bq1 = lc < 6 ? AB[kk * 48 + lc * 8 + 7] : (lc == 7 ? 1.0 : 0.0);
                 const double pq = pst[(kk + 1) * 8 + lc], gq = lc >= 6 ? gup[2 * kk + lc - 6] : 0.0;
                 const double m00 = Mi[kk * 4], m01 = Mi[kk * 4 + 1], m10 = Mi[kk * 4 + 2], m11 = Mi[kk * 4 + 3];
+                LDS_GROUP();
                 const double w0_ = sum_over_c(fma(bq0, pq, lc == 6 ? gq : 0.0)), w1_ = sum_over_c(fma(bq1, pq, lc == 7 ? gq : 0.0));
                 const double k00 = m00 * w0_ + m01 * w1_, k01 = m10 * w0_ + m11 * w1_;
                 if (on) phi[k * 8 + lc] = -(bq0 * k00 + bq1 * k01);
@@ -244,6 +254,7 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 double fm[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
+                LDS_GROUP();
                 double xi = 0.0;
 #pragma unroll
                 for (int k = 0; k < N; k++) {
@@ -278,9 +289,14 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                     WSYNC();
                 }
                 double v = -c_t;                                // v = -c~ + M' omega'
+                double wq[7];
 #pragma unroll
-                for (int j = 0; j < 7; j++) v = fma(mcol[j], w7[j], v);
-                if (lane < S) dl[lane] = v * rsq[lane];
+                for (int j = 0; j < 7; j++) wq[j] = w7[j];
+                const double rq = rsq[lane];
+                LDS_GROUP();
+#pragma unroll
+                for (int j = 0; j < 7; j++) v = fma(mcol[j], wq[j], v);
+                if (lane < S) dl[lane] = v * rq;
             }
         }
         __syncthreads();                                        // C3
@@ -336,6 +352,7 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                 for (int i = 0; i < 7; i++)
 #pragma unroll
                     for (int j = i; j < 7; j++) Rr[i][j] = Wl[i * 8 + j];
+                LDS_GROUP();
 #pragma unroll
                 for (int i = 0; i < 7; i++) {                                                 // Cholesky, row by row
                     double d_ = Rr[i][i];
@@ -367,9 +384,14 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                     }
                 }
                 WSYNC();
-                if (lane < 36) {                                 // Pi_term = (Ri Ri')[0:6,0:6]
+                if (lane < 36) {                                 // Pi_term = (Ri Ri')[0:6,0:6]  (Ri is zero below the diagonal: all seven terms, same sum)
                     const int i = lane / 6, j = lane % 6; double v = 0.0;
-                    for (int k = (i > j ? i : j); k < 7; k++) v = fma(Ri[i * 7 + k], Ri[j * 7 + k], v);
+                    double ra[7], rb[7];
+#pragma unroll
+                    for (int k = 0; k < 7; k++) { ra[k] = Ri[i * 7 + k]; rb[k] = Ri[j * 7 + k]; }
+                    LDS_GROUP();
+#pragma unroll
+                    for (int k = 0; k < 7; k++) v = (k >= i && k >= j) ? fma(ra[k], rb[k], v) : v;
                     PiT[lane] = v;
                 }
             }
@@ -475,9 +497,14 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                     ct[lane] = c_t;
                     WSYNC();
                     double acc = 0.0;                               // M c~ : lane (j, part) adds 8 of the 64 columns
-                    if (lg < 7) {
+                    {
+                        double mq[8], cq[8];
 #pragma unroll
-                        for (int q = 0; q < 8; q++) acc = fma(Mt[lc * 8 + lg + 64 * q], ct[lc + 8 * q], acc);
+                        for (int q = 0; q < 8; q++) { mq[q] = Mt[lc * 8 + (lg < 7 ? lg : 0) + 64 * q]; cq[q] = ct[lc + 8 * q]; }
+                        LDS_GROUP();
+#pragma unroll
+                        for (int q = 0; q < 8; q++) acc = fma(mq[q], cq[q], acc);
+                        acc = lg < 7 ? acc : 0.0;
                     }
                     acc = sum_over_c(acc);
                     if (lg < 7 && lc == 0) McL[lg] = acc;
@@ -530,6 +557,7 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
             double fm[N];
 #pragma unroll
             for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
+            LDS_GROUP();
             double xi = 0.0;
 #pragma unroll
             for (int k = 0; k < N; k++) {
@@ -563,9 +591,14 @@ __global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_m
                     WSYNC();
                 }
                 double v = -ct[lane];                           // v = -c~ + M' omega'
+                double wq[7];
 #pragma unroll
-                for (int j = 0; j < 7; j++) v = fma(mcol[j], w7[j], v);
-                if (lane < S) dl[lane] = v * rsq[lane];
+                for (int j = 0; j < 7; j++) wq[j] = w7[j];
+                const double rq = rsq[lane];
+                LDS_GROUP();
+#pragma unroll
+                for (int j = 0; j < 7; j++) v = fma(mcol[j], wq[j], v);
+                if (lane < S) dl[lane] = v * rq;
             }
         }
         __syncthreads();
