@@ -381,7 +381,7 @@ static void k1_grid(lmpc_ctx *c, int B, int *qg, int *nblk) {
     int q = 1, np = N;
     for (int k = 0; k < 6; k++) {
         q = k1_queries_per_block(cands[k], c->cfg.trToUse, c->cfg.maxNumPoint); np = (N + q - 1) / q;
-        if ((long long)B * np >= (long long)c->n_cu) break;
+        if ((long long)B * np >= (long long)c->n_cu) break;      // (two or more groups per CU measured no faster: 26-35 us against 27 us at batch 256)
     }
     *qg = q; *nblk = B * np;
 }
@@ -606,6 +606,23 @@ int lmpc_debug_timing(lmpc_ctx *c, const double *A, const double *Bm, const doub
     HIPCHK(hipStreamSynchronize(c->stream)); hipFree(dt);
     return LMPC_OK;
 }
+
+#ifdef LMPC_TIMING
+// (developer build only) phase stamps of work-group 0 of one regression launch: tbuf_host[0..7] = cycle counter at K1STAMP(id)
+int lmpc_debug_k1_timing(lmpc_ctx *c, int B, const double *xLin, const double *uLin, long long *tbuf_host) {
+    ARGCHK(c && xLin && uLin && tbuf_host && B >= 1 && B <= c->cfg.max_batch);
+    const int N = c->cfg.N;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    H2D(c->w_xLin, xLin, (size_t)B * (N + 1) * 6); H2D(c->w_uLin, uLin, (size_t)B * N * 2);
+    long long *dt; HIPCHK(hipMalloc(&dt, sizeof(long long) * 8)); HIPCHK(hipMemsetAsync(dt, 0, sizeof(long long) * 8, c->stream));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_k1_tbuf), &dt, sizeof(dt)));
+    for (int rep = 0; rep < 2; rep++) { int rc = launch_regress(c, B, c->w_xLin, (N + 1) * 6, c->w_uLin, c->w_A, c->w_B, c->w_C, c->w_rstatus); if (rc) return rc; }
+    HIPCHK(hipMemcpyAsync(tbuf_host, dt, sizeof(long long) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    long long *nul = nullptr; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_k1_tbuf), &nul, sizeof(nul))); hipFree(dt);
+    return LMPC_OK;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------- plant / rollouts
 int lmpc_plant_step_batch(lmpc_ctx *c, int B, const double *x, const double *xg, const double *u, const double *noise, double *xn, double *xgn, int *status) {

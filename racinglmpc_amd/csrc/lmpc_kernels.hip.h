@@ -274,6 +274,14 @@ __host__ __device__ inline int k1_queries_per_block(int qg, int trToUse, int max
     return q < 1 ? 1 : q;
 }
 
+#ifdef LMPC_TIMING
+// (developer build) cycle stamps of work-group 0 of the regression kernel: g_k1_tbuf[id] = cycle counter at stamp id (lmpc_debug_k1_timing)
+static __device__ long long *g_k1_tbuf;
+#define K1STAMP(id) do { if (g_k1_tbuf && blockIdx.x == 0 && threadIdx.x == 0) g_k1_tbuf[id] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define K1STAMP(id) do { } while (0)
+#endif
+
 // LDS work space of the regression: static arrays in the stand-alone kernel (8 waves per problem), a slice of the solve kernel's
 // dynamic LDS when one wave runs the regression of its own QP in front of the solve (lmpc_solve_kernel, fused step).
 struct k1_smem {
@@ -464,6 +472,7 @@ __device__ __forceinline__ void k1_fit(const lmpc_dev_params &p, const k1_smem &
         }
     }
     __syncthreads();
+    K1STAMP(3);
 
     // ---- compute_Q_M / compute_b (:141-168): Q = M' diag(K) M (+ lamb I), b = -M' diag(K) y ---------------------------
     // 35 distinct sums per query: the vx system (15 + 5), and of the lateral system only what involves delta (5) and its two
@@ -486,6 +495,7 @@ __device__ __forceinline__ void k1_fit(const lmpc_dev_params &p, const k1_smem &
         if (le < 15 && r != 3 && cc != 3) sm.gram[ql][20 + e] = acc;
     }
     __syncthreads();
+    K1STAMP(4);
 
     // ---- LMPC_LocLinReg (:170-178): unconstrained qp(Q, b)  <=>  Q theta = -b ; Cholesky 5x5, one thread per system ----
     if (tid < nf * 3) {
@@ -515,6 +525,7 @@ __device__ __forceinline__ void k1_fit(const lmpc_dev_params &p, const k1_smem &
     }
     for (int e = tid; e < nf * 54; e += nt) sm.outv[e / 54][e % 54] = 0.0;
     __syncthreads();
+    K1STAMP(5);
 
     // ---- assemble A_i, B_i, C_i (:70-135), one thread per query ------------------------------------------------------
     if (tid < nf) {
@@ -545,6 +556,7 @@ __device__ __forceinline__ void k1_fit(const lmpc_dev_params &p, const k1_smem &
         Ci[5] = ey + dt * (vx * se + vy * ce) - dot;
     }
     __syncthreads();
+    K1STAMP(6);
 }
 
 // OCC: compile for four waves per SIMD (two work-groups per CU; <= 128 VGPRs) -- pays when the grid exceeds one work-group
@@ -583,13 +595,16 @@ __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_d
     }
     if (tid < nq * LMPC_MAX_USED_LAPS) nsel[tid] = 0;
     if (tid < nq) st_s[tid] = 0;
+    K1STAMP(0);
     __syncthreads();
+    K1STAMP(1);
     // (two queries per trip in the low-occupancy build.  The occupancy build takes one per trip: with four waves per SIMD the other waves
     //  fill the chain's latency, and the second query's 16 distances cost registers it does not have -- spilled registers are scratch
     //  WRITES: 134 MB per launch at batch 4096 before this)
     for (int c = myc; c < L && sgi < nsub; c += K1_NW)                    // (c += K1_NW: only when trToUse > 8 waves, never here)
         k1_scan_lap<!OCC>(p, sm, c, wave * K1_QG, sgi, nsub, nq, lane, MAXP);
     __syncthreads();
+    K1STAMP(2);
     k1_fit(p, sm, 0, nq, tid, K1_NT, xLin + (size_t)b * xstride + (size_t)i0 * 6, MAXP);
     for (int e = tid; e < nq * 54; e += K1_NT) {
         const int qi = e / 54, le = e % 54; const size_t item = (size_t)b * N + i0 + qi;
@@ -598,6 +613,7 @@ __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_d
         else Cout[item * 6 + (le - 48)] = outv[qi][le];
     }
     if (tid < nq) status[(size_t)b * N + i0 + tid] = st_s[tid];
+    K1STAMP(7);
 }
 
 // LDS doubles the regression of one QP by ONE wave needs behind [A_k | B_k] and C_k (fused step of lmpc_solve_kernel): the scan state of
