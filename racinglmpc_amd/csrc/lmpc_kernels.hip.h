@@ -247,6 +247,16 @@ __device__ __forceinline__ unsigned wminu(unsigned v) {                       //
     auto r1 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
     return r1[0] < r1[1] ? r1[0] : r1[1];
 }
+// inclusive prefix sum over the 64 lanes (gfx9 DPP: four shifts inside a row of 16, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ int wave_incl_scan_i32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1, out-of-row lanes read 0
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return x;
+}
 __device__ __forceinline__ bool k1_less(double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); }
 // rank of (d, i) among the 16 entries of its row of lanes, lexicographic: every other lane's entry passes by once
 template <int ROT> __device__ __forceinline__ void k1_row_rank(double d, int i, int &rank) {
@@ -354,19 +364,19 @@ __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_s
             // top MAXP therefore has d < T + 5 and e < d + 5 < T + 10, i.e. e <= T + 9.  Everything up to T + 10 survives
             // (one unit of margin for the rounding of the host's fixed-point conversion); the survivors are re-ranked in FP64.
             const unsigned ta = ba > 0xffffff00u ? 0xffffffffu : ba + 10u, tb = bb > 0xffffff00u ? 0xffffffffu : bb + 10u;
-            int na = 0, nb = 0;
+            // Survivors (a handful of the 1024 rows) are compacted into the query's 16-slot segment: every lane builds a 16-bit mask of its
+            // surviving rows, a wave prefix sum of the per-lane counts (six DPP steps) gives each lane its first slot, and the lane writes
+            // its own rows.  (The first version ran a ballot / mbcnt round per row slot: 16 rounds, most of this kernel's 550 VALU
+            // instructions per (query, lap).  The order inside the segment changes; the exact re-rank below does not depend on it.)
+            unsigned mska = 0u, mskb = 0u;
 #pragma unroll
-            for (int j = 0; j < K1_RPL; j++) {
-                const bool ca = ea[j] <= ta, cb = PAIR && eb[j] <= tb;
-                const unsigned long long mka = __ballot(ca), mkb = PAIR ? __ballot(cb) : 0ull;
-                if (mka | mkb) {
-                    const int pa = na + __builtin_amdgcn_mbcnt_hi((unsigned)(mka >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mka, 0));
-                    const int pb = nb + __builtin_amdgcn_mbcnt_hi((unsigned)(mkb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mkb, 0));
-                    if (ca && pa < 16) sm.cseg[cs0 + s][pa] = t0 + lane + WAVE * j;
-                    if (cb && pb < 16 && two) sm.cseg[cs0 + s + 1][pb] = t0 + lane + WAVE * j;
-                    na += __popcll(mka); nb += __popcll(mkb);
-                }
-            }
+            for (int j = 0; j < K1_RPL; j++) { mska |= (ea[j] <= ta ? 1u : 0u) << j; if (PAIR) mskb |= (eb[j] <= tb ? 1u : 0u) << j; }
+            const int ca_ = __popc(mska), cb_ = PAIR ? __popc(mskb) : 0;
+            const int ia = wave_incl_scan_i32(ca_), ib = PAIR ? wave_incl_scan_i32(cb_) : 0;
+            const int na = __builtin_amdgcn_readlane(ia, 63), nb = PAIR ? __builtin_amdgcn_readlane(ib, 63) : 0;
+            int pa = ia - ca_, pb = ib - cb_;
+            while (mska) { const int j = __builtin_ctz(mska); mska &= mska - 1u; if (pa < 16) sm.cseg[cs0 + s][pa] = t0 + lane + WAVE * j; pa++; }
+            if (two) { while (mskb) { const int j = __builtin_ctz(mskb); mskb &= mskb - 1u; if (pb < 16) sm.cseg[cs0 + s + 1][pb] = t0 + lane + WAVE * j; pb++; } }
             if (lane == 0) { sm.ccnt[cs0 + s] = na; if (two) sm.ccnt[cs0 + s + 1] = nb; }
         }
         // ---- step B: exact FP64 distances of the survivors, four queries at a time (one per row of 16 lanes), ranked inside the
