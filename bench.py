@@ -331,6 +331,10 @@ def main():
             laps30 = pid_laps(ctx, g, 30)
             out["config_batch4096_30laps"] = dict(run_config(g, N, 4096, local, steps=8, warmup=2, laps=laps30, query_lap=laps30[29], max_laps=40, max_lap_len=1024),
                                                   note="BASELINE configs[2]: 30 PID laps (vt = 0.6 + 0.02 i) in both stores, reference semantics = the 4 fastest are used")
+            out["config_batch4096_30laps_wide"] = dict(
+                run_config(g, N, 4096, local, steps=5, warmup=2, laps=laps30, query_lap=laps30[29], max_laps=40, max_lap_len=1024, numSS_it=8, numSS_points=96, trToUse=8),
+                note="SURVEY 8(d) scan-heavy variant within the library's limits (8 laps used by regression and safe set, 96 safe-set points, 30 laps stored); "
+                     "more than 58 safe-set points run on the one-wave kernel with several terminal-block columns per lane")
             out["config_N40_batch1024"] = dict(run_config(g, 40, 1024, local, steps=5, warmup=2), note="BASELINE configs[4]")
         leg = rollout_leg(g, comm, ctx, args.rollouts_per_gpu)
         if rank == 0:

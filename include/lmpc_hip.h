@@ -25,6 +25,7 @@ extern "C" {
 #define LMPC_MAX_TRACK_ROWS 16
 #define LMPC_MAX_USED_LAPS 8       /* trToUse / numSS_it upper bound */
 #define LMPC_MAX_N 64
+#define LMPC_MAX_SS_POINTS 250     /* numSS_points upper bound (up to 58 every kernel; beyond that the one-wave solve kernel only) */
 
 /* error codes (function return values) */
 #define LMPC_OK 0
@@ -54,7 +55,7 @@ typedef struct lmpc_ctx lmpc_ctx;
 typedef struct {
     int N;                      /* horizon (reference main.py:43 uses 14; BASELINE metric uses 12) */
     int numSS_it;               /* laps in the safe set per solve; 0 => plain MPC/LTV-MPC, no terminal set */
-    int numSS_points;           /* total safe-set columns (reference: 12 * numSS_it = 48); any multiple of numSS_it up to 58 */
+    int numSS_points;           /* total safe-set columns (reference: 12 * numSS_it = 48); any multiple of numSS_it up to LMPC_MAX_SS_POINTS, at most 63 per lap */
     int trToUse;                /* laps used by the regression (PredictiveModel usedIt) */
     int maxNumPoint;            /* 7   (PredictiveModel.py:18) */
     double h, lamb, dt;         /* 5, 0.0, 0.1 (PredictiveModel.py:19-21) */

@@ -141,6 +141,8 @@ static int create_body(lmpc_ctx *c) {
     // a variant whose LDS footprint leaves room for one QP per CU (N = 40) keeps three SIMDs idle in the 1-wave kernel at any
     // batch size: always run it with four waves per QP (measured at N=40, B=1024: 2.80 vs 3.52 ms; N=20 and N=14 prefer 1 wave)
     if (!getenv("LMPC_MW_MAX_BATCH") && 2 * c->var.lds_1w > 160 * 1024) c->mw_max_batch = 1 << 30;
+    // safe sets wider than 58 points (numSS_points + 6 terminal columns > one per lane) exist as one-wave kernels only
+    if (c->var.lds_mw == 0) c->mw_max_batch = 0;
     // Fused step (regression inside the one-wave solve kernel): bit-identical results, 42 MB less HBM traffic per step at batch 4096, but
     // MEASURED SLOWER -- 1.37 vs 1.01 + 0.23 ms at batch 4096, 2.48 vs 1.81 + 0.44 ms at batch 8192: the regression's short dependent chains
     // (DPP minima, 5 x 5 Cholesky, scattered L2 reads) want the four waves per SIMD its own kernel gets, and the solve's LDS footprint leaves
@@ -177,7 +179,7 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     ARGCHK(cfg->numSS_it >= 0 && cfg->numSS_it <= LMPC_MAX_USED_LAPS && cfg->trToUse >= 0 && cfg->trToUse <= LMPC_MAX_USED_LAPS);
     ARGCHK(cfg->maxNumPoint >= 1 && cfg->maxNumPoint <= 8);
     if (cfg->numSS_it > 0) {
-        ARGCHK(cfg->numSS_points % cfg->numSS_it == 0 && cfg->numSS_points + 6 <= WAVE && cfg->numSS_points / cfg->numSS_it + 1 <= WAVE);
+        ARGCHK(cfg->numSS_points % cfg->numSS_it == 0 && cfg->numSS_points <= LMPC_MAX_SS_POINTS && cfg->numSS_points / cfg->numSS_it + 1 <= WAVE);
         for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) if (i != j) ARGCHK(cfg->QtermSlack[i * 6 + j] == 0.0);   // diagonal terminal-slack weight
         for (int i = 0; i < 6; i++) ARGCHK(cfg->QtermSlack[i * 7] > 0.0);
     }

@@ -844,18 +844,19 @@ template <int N, int S> struct solve_lds {
 // N = 12, S = 48: 24.5 KB per QP = 6 QPs per CU (the multi-wave layout above: 39.1 KB = 4).
 template <int N, int S> struct solve_lds1 {
     static constexpr int M = 8 * N + S;
+    static constexpr int CH = (S + 6 + WAVE - 1) / WAVE, CW = CH * WAVE;       // the terminal block's S + 6 columns: CH per lane (column = lane + 64 ch)
     static constexpr int oAB = 0, oC = oAB + 48 * N;
     static constexpr int ox = oC + 6 * N, ou = ox + 6 * (N + 1), os = ou + 2 * N, olam = os + 2 * N, onu = olam + S;
     static constexpr int om = onu + 6 * N, oth = om + M;
     static constexpr int orx = oth + M, oru = orx + 6 * (N + 1), ors = oru + 2 * N, orl = ors + 2 * N;
     static constexpr int oPhiK = orl + S, oMi = oPhiK + 16 * N, okap = oMi + 4 * N, orDs = okap + 2 * N;
-    static constexpr int oRi = orDs + 2 * N, orsq = oRi + 56, oMc = orsq + WAVE;
+    static constexpr int oRi = orDs + 2 * N, orsq = oRi + 56, oMc = orsq + CW;
     static constexpr int oSS = oMc + 8, oQsel = oSS + 6 * S, oy7 = oQsel + S, oz7 = oy7 + 8, ow7 = oz7 + 8, oPiT = ow7 + 8, osT = oPiT + 36;
     static constexpr int opar = osT + 8, oscr = opar + PAR_TOT;
     // scratch region, by phase
-    static constexpr int oMt = oscr, oWl = oMt + 8 * WAVE;                                     // t1
+    static constexpr int oMt = oscr, oWl = oMt + 8 * CW;                                       // t1
 #ifdef LMPC_DBG_NOALIAS
-    static constexpr int oPhi = oscr + 8 * WAVE + 64;
+    static constexpr int oPhi = oscr + 8 * CW + 64;
     static constexpr int oh = oPhi + 64 * N;
 #else
     static constexpr int oPhi = oscr;                                                          // t2
@@ -863,8 +864,8 @@ template <int N, int S> struct solve_lds1 {
 #endif
     static constexpr int odm = oh, odx = oh + M, odu = odx + 6 * (N + 1), ods = odu + 2 * N, odl = ods + 2 * N;   // t3+
     static constexpr int ogam = odl + S, odnu = ogam, ogup = ogam + 8 * N, opst = ogup + 2 * N, ok0 = opst + 8 * (N + 1);
-    static constexpr int oeta = ok0 + 2 * N, oe = oeta + 2 * N, oct = oe + 2 * N, ott = oct + WAVE, oend3 = ott + 6 * N;
-    static constexpr int scr1 = S > 0 ? 8 * WAVE + 64 : 0, scr2 = 64 * N, scr3 = oend3 - oscr;
+    static constexpr int oeta = ok0 + 2 * N, oe = oeta + 2 * N, oct = oe + 2 * N, ott = oct + CW, oend3 = ott + 6 * N;
+    static constexpr int scr1 = S > 0 ? 8 * CW + 64 : 0, scr2 = 64 * N, scr3 = oend3 - oscr;
     static constexpr int scr = scr1 > scr2 ? (scr1 > scr3 ? scr1 : scr3) : (scr2 > scr3 ? scr2 : scr3);
 #ifdef LMPC_DBG_NOALIAS
     static constexpr int tot = oend3;
@@ -991,13 +992,15 @@ __device__ __forceinline__ void k2_select(const lmpc_dev_params &p, const lmpc_s
 }
 
 template <int N, int S, bool EQ = false>
-// (two waves per SIMD -- at most 256 registers -- only where the LDS footprint lets more than four QPs share a CU)
-__global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024) ? 2 : 1) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
+// (two waves per SIMD -- at most 256 registers -- only where the LDS footprint lets more than four QPs share a CU and the terminal
+// block keeps one column per lane)
+__global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 && solve_lds1<N, S>::CH == 1) ? 2 : 1) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
     extern __shared__ double sm[];
     using LL = solve_lds1<N, S>;
     constexpr int M = LL::M;
     constexpr bool term = S > 0;
     constexpr int RPL = (M + WAVE - 1) / WAVE;              // inequality rows per lane
+    constexpr int CH = LL::CH;                              // terminal-block columns per lane (1 for numSS_points <= 58)
     const int b = blockIdx.x;
     if (b >= B) return;
     // retry variant (EQ): only problems that hit the iteration limit (or broke down numerically far from the optimum) run again,
@@ -1112,10 +1115,15 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
     }
     const ricc_consts rc = ricc_setup(lane, Q2, Fx, R2, dR2, Fu);
     double ph[N];                                          // Phi_k entry this lane multiplies with in the register sweeps
-    double mcol[7];                                        // this lane's column of M = [E D^-1/2 | T7^-1/2]
-    const double tsq_lane = (term && lane >= S && lane < S + 6) ? frsqrt(T2p[lane - S]) : 0.0;   // T^-1/2 entry of this lane's slack column of M (loop invariant)
+    double mcol[CH][7];                                    // this lane's columns of M = [E D^-1/2 | T7^-1/2] (column lane + 64 ch)
+    double tsq_lane[CH];                                   // T^-1/2 entry of a slack column of M (loop invariant)
 #pragma unroll
-    for (int j = 0; j < 7; j++) mcol[j] = 0.0;
+    for (int ch = 0; ch < CH; ch++) {
+        const int col = lane + WAVE * ch;
+        tsq_lane[ch] = (term && col >= S && col < S + 6) ? frsqrt(T2p[col - S]) : 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) mcol[ch][j] = 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < N; k++) ph[k] = 0.0;
     __syncthreads();
@@ -1133,10 +1141,15 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
             for (int j = 0; j < 4; j++) v -= Fu[j * 2 + c] * h[2 * N + 4 * k + j];
             gup[i] = v;
         }
-        double c_t = 0.0;
+        double c_t[CH];
         if constexpr (term) {
-            if (lane < S) c_t = (rl[lane] + h[8 * N + lane]) * rsq[lane];
-            ct[lane] = lane < S ? c_t * rsq[lane] : 0.0;       // D^-1/2 c~ (the slack columns of M meet zeros of c~)
+#pragma unroll
+            for (int ch = 0; ch < CH; ch++) {
+                const int col = lane + WAVE * ch;
+                c_t[ch] = 0.0;
+                if (col < S) c_t[ch] = (rl[col] + h[8 * N + col]) * rsq[col];
+                ct[col] = col < S ? c_t[ch] * rsq[col] : 0.0;  // D^-1/2 c~ (the slack columns of M meet zeros of c~)
+            }
         }
         __syncthreads();
         if constexpr (term) {
@@ -1239,10 +1252,14 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
                 if (lc == 0 && lg < 7) w7[lg] = wv;
                 __syncthreads();
             }
-            double v = -c_t;                                    // v = -c~ + M' omega'
 #pragma unroll
-            for (int j = 0; j < 7; j++) v = fma(mcol[j], w7[j], v);
-            if (lane < S) dl[lane] = v * rsq[lane];
+            for (int ch = 0; ch < CH; ch++) {
+                const int col = lane + WAVE * ch;
+                double v = -c_t[ch];                            // v = -c~ + M' omega'
+#pragma unroll
+                for (int j = 0; j < 7; j++) v = fma(mcol[ch][j], w7[j], v);
+                if (col < S) dl[col] = v * rsq[col];
+            }
         }
         __syncthreads();
     };
@@ -1333,24 +1350,31 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
             // terminal block: M = [E D^-1/2 | T7^-1/2] (7 x (S+6)), one column per lane; W = M M' by wave reductions,
             // R'R = W (Cholesky) and Ri = R^-1 in registers (uniform across lanes); all later uses apply Ri / Ri' in factored form
 #pragma unroll
-            for (int j = 0; j < 7; j++) mcol[j] = 0.0;
-            if (lane < S) {
-                const double rs_ = frsqrt(th[8 * N + lane] + p.reg); rsq[lane] = rs_;
+            for (int ch = 0; ch < CH; ch++) {
+                const int col = lane + WAVE * ch;
 #pragma unroll
-                for (int j = 0; j < 6; j++) mcol[j] = SS[j * S + lane] * rs_;
-                mcol[6] = rs_;
-            } else {
-                rsq[lane] = 1.0;
+                for (int j = 0; j < 7; j++) mcol[ch][j] = 0.0;
+                if (col < S) {
+                    const double rs_ = frsqrt(th[8 * N + col] + p.reg); rsq[col] = rs_;
 #pragma unroll
-                for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = tsq_lane;
+                    for (int j = 0; j < 6; j++) mcol[ch][j] = SS[j * S + col] * rs_;
+                    mcol[ch][6] = rs_;
+                } else {
+                    rsq[col] = 1.0;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) if (col - S == j) mcol[ch][j] = tsq_lane[ch];
+                }
             }
             double Rr[7][7], rinv[7];
-            // Gram matrix W = M M' (7 x 7, K = 64 columns) on the matrix cores: v_mfma_f64_16x16x4 over 16 K-chunks.
+            // Gram matrix W = M M' (7 x 7, K = 64 CH columns) on the matrix cores: v_mfma_f64_16x16x4 over 16 CH K-chunks.
             // operand layout: lane = 16 k + i holds M[i][4 s + k] for both A and B (W is M times its own transpose);
             // accumulator: lane l, register r holds W[4 r + l / 16][l % 16].
 #pragma unroll
-            for (int j = 0; j < 7; j++) Mt[lane * 8 + j] = mcol[j];
-            Mt[lane * 8 + 7] = 0.0;
+            for (int ch = 0; ch < CH; ch++) {
+#pragma unroll
+                for (int j = 0; j < 7; j++) Mt[(lane + WAVE * ch) * 8 + j] = mcol[ch][j];
+                Mt[(lane + WAVE * ch) * 8 + 7] = 0.0;
+            }
             __syncthreads();
             {
                 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -1358,7 +1382,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
                 const int kk = lane >> 4, ii = lane & 15;
                 const bool live = ii < 8;
 #pragma unroll
-                for (int s_ = 0; s_ < 16; s_ += 4) {
+                for (int s_ = 0; s_ < 16 * CH; s_ += 4) {
                     double a0 = Mt[(4 * s_ + kk) * 8 + (ii & 7)], a1 = Mt[(4 * (s_ + 1) + kk) * 8 + (ii & 7)], a2 = Mt[(4 * (s_ + 2) + kk) * 8 + (ii & 7)], a3 = Mt[(4 * (s_ + 3) + kk) * 8 + (ii & 7)];
                     a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0; a2 = live ? a2 : 0.0; a3 = live ? a3 : 0.0;
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
@@ -1547,9 +1571,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
         double deta = 0.0;
         if constexpr (term) {
             double v = 0.0;
-            if (lane < S) { v = -rl[lane] + dm[8 * N + lane];
+            FOR_LANES(c, S) { v += -rl[c] + dm[8 * N + c];
 #pragma unroll
-                for (int j = 0; j < 6; j++) v -= SS[j * S + lane] * T2p[j] * w7[j]; }
+                for (int j = 0; j < 6; j++) v -= SS[j * S + c] * T2p[j] * w7[j]; }
             deta = wsum(v) / (double)S;
         }
         __syncthreads();
@@ -1580,13 +1604,13 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024)
             double acc[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[j] = 0.0;
-            if (lane < S) {
-                const int l = lane / p.ppl, cc = lane % p.ppl;
+            FOR_LANES(c, S) {
+                const int l = c / p.ppl, cc = c % p.ppl;
                 const double *base = p.sstore + (size_t)p.sslot[l] * LMPC_COLS * p.lap_stride;
                 int r1 = sel_start[l] + cc + 1; r1 = r1 > p.sslen[l] - 1 ? p.sslen[l] - 1 : r1;
-                const double lv = lam[lane];
+                const double lv = lam[c];
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc[j] = base[j * p.lap_stride + r1] * lv;
+                for (int j = 0; j < 8; j++) acc[j] = fma(base[j * p.lap_stride + r1], lv, acc[j]);
             }
             // reference order of np.dot(Succ, lambd): sequential over columns; a tree sum differs by rounding only
 #pragma unroll

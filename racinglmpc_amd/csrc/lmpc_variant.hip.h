@@ -19,7 +19,8 @@ struct lmpc_variant_api {
 };
 
 template <int N, int S> struct lmpc_variant_launchers {
-    static constexpr size_t lds1 = (size_t)solve_lds1<N, S>::tot * sizeof(double), ldsm = (size_t)solve_lds<N, S>::tot * sizeof(double);
+    static constexpr bool has_mw = S + 6 <= WAVE;      // the multi-wave kernels keep one terminal-block column per lane; wider safe sets run on the one-wave kernel
+    static constexpr size_t lds1 = (size_t)solve_lds1<N, S>::tot * sizeof(double), ldsm = has_mw ? (size_t)solve_lds<N, S>::tot * sizeof(double) : 0;
     // fused step (io.mode & 4): the regression's work space sits behind [A_k | B_k], C_k; it fits the solve's footprint at the reference's
     // settings (4 laps x 7 points) and grows it a little beyond
     static size_t lds_for(const lmpc_dev_params &p, const lmpc_solve_io &io) {
@@ -32,21 +33,23 @@ template <int N, int S> struct lmpc_variant_launchers {
     static int lr(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
         hipLaunchKernelGGL((lmpc_solve_kernel<N, S, true>), dim3(B), dim3(WAVE), lds_for(p, io), st, p, B, io); return 0; }
     static int l4(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
-        hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 4>), dim3(B), dim3(WAVE * 4), ldsm, st, p, B, io); return 0; }
+        if constexpr (has_mw) { hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 4>), dim3(B), dim3(WAVE * 4), ldsm, st, p, B, io); return 0; } else return l1(st, p, B, io); }
     static int l2(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
-        hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 2>), dim3(B), dim3(WAVE * 2), ldsm, st, p, B, io); return 0; }
+        if constexpr (has_mw) { hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 2>), dim3(B), dim3(WAVE * 2), ldsm, st, p, B, io); return 0; } else return l1(st, p, B, io); }
 };
 
 // fills the table and raises the kernels' dynamic-LDS limit; false if the device refuses (footprint beyond 160 KB)
 template <int N, int S> static bool lmpc_variant_fill(lmpc_variant_api *v) {
-    static_assert(N >= 2 && N <= LMPC_MAX_N && S >= 0 && S + 6 <= WAVE, "unsupported variant");
+    static_assert(N >= 2 && N <= LMPC_MAX_N && S >= 0 && S <= LMPC_MAX_SS_POINTS, "unsupported variant");
     using L = lmpc_variant_launchers<N, S>;
     v->N = N; v->S = S;
-    v->lds_mw = (size_t)solve_lds<N, S>::tot * sizeof(double); v->lds_1w = (size_t)solve_lds1<N, S>::tot * sizeof(double);
+    v->lds_mw = L::ldsm; v->lds_1w = (size_t)solve_lds1<N, S>::tot * sizeof(double);      // lds_mw == 0: no multi-wave kernels for this S
     if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::lds1_max()) != hipSuccess) return false;
     if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::lds1_max()) != hipSuccess) return false;
-    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_mw) != hipSuccess) return false;
-    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_mw) != hipSuccess) return false;
+    if constexpr (L::has_mw) {
+        if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_mw) != hipSuccess) return false;
+        if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_mw) != hipSuccess) return false;
+    }
     v->launch_1w = &L::l1; v->launch_retry = &L::lr; v->launch_mw4 = &L::l4; v->launch_mw2 = &L::l2;
     return true;
 }

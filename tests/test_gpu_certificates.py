@@ -240,33 +240,38 @@ def test_regression_status_reaches_device_paths(built):
     ctx.close()
 
 
-@pytest.mark.parametrize("N,numSS_it", [(10, 4), (16, 4), (24, 4), (30, 4), (12, 2), (12, 3), (16, 3)])
-def test_general_horizon_and_safe_set_size(built, N, numSS_it):
+@pytest.mark.parametrize("N,numSS_it,ppl", [(10, 4, 12), (16, 4, 12), (24, 4, 12), (30, 4, 12), (12, 2, 12), (12, 3, 12), (16, 3, 12),
+                                            (12, 5, 12), (12, 8, 12), (14, 4, 40)])
+def test_general_horizon_and_safe_set_size(built, N, numSS_it, ppl):
     """(N, numSS_Points) outside the reference's own configurations (main.py:43 takes any N, initControllerParameters.py:43-44 sets
     numSS_Points = 12 numSS_it): the solve kernels come from liblmpc_var_N<N>_S<S>.so (built by build() / on demand by Context).
     Every problem of a batch that touches all three kernel routes is certified; two problems are compared with the oracle's optimum of
-    the reference-form QP and the selection with the oracle's selectPoints."""
+    the reference-form QP and the selection with the oracle's selectPoints.  The last three cases have more than 58 safe-set points
+    (60, 96, 160): more terminal-block columns than lanes of a wave, the one-wave kernel carries several per lane and serves every batch size."""
     from oracle import lmpc_oracle as orc
     from racinglmpc_amd import _capi
     g = common.load_lmpc_golden()
-    S = 12 * numSS_it
+    S = ppl * numSS_it
     xP, uP = g["xPID"], g["uPID"]
     track = np.array(g["track"]); TL = float(g["trackLength"])
     par = orc.QPParams.lmpc_default(N)
     par.numSS_Points, par.numSS_it = S, numSS_it
     for B in (48, 700, 1300):
-        cfg, _ = common.lmpc_config(g, N, max_batch=B, numSS_it=numSS_it)
+        cfg, _ = common.lmpc_config(g, N, max_batch=B, numSS_it=numSS_it, numSS_Points=S)
         ctx = _capi.Context(cfg)
         assert ctx.S == S
-        for _ in range(4):
-            ctx.model_add_trajectory(xP, uP); ctx.ss_add_trajectory(xP, uP)
+        assert ctx.solver_waves(B) == 1 or S + 6 <= 64
+        for i in range(max(4, numSS_it)):
+            if i < 4:
+                ctx.model_add_trajectory(xP, uP)
+            ctx.ss_add_trajectory(xP, uP)
         tb = (37 * np.arange(B)) % 900
         rng = np.random.default_rng(99)
         inp = dict(x0=xP[tb] + rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02]),
                    xLin=np.stack([xP[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uP[t + 1:t + N + 1] for t in tb]),
                    uOld=uP[tb].copy(), zt=xP[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
         out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
-        _certify(par, out, inp, what="N=%d numSS_it=%d B=%d (%d wave(s) per QP)" % (N, numSS_it, B, ctx.solver_waves(B)))
+        _certify(par, out, inp, what="N=%d numSS_it=%d numSS_Points=%d B=%d (%d wave(s) per QP)" % (N, numSS_it, S, B, ctx.solver_waves(B)))
         if B == 48:
             worst = 0.0
             for b in (0, 31):
@@ -281,7 +286,7 @@ def test_general_horizon_and_safe_set_size(built, N, numSS_it):
                 ex, cert = orc.osqp_solve_exact(P, q, Ao, l, u, want=1e-8)
                 w = np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()])
                 worst = max(worst, np.abs(w - ex.x[:8 * N + 6]).max())
-            print("N=%d numSS_it=%d: worst |xu - oracle optimum| %.2e" % (N, numSS_it, worst))
+            print("N=%d numSS_it=%d numSS_Points=%d: worst |xu - oracle optimum| %.2e" % (N, numSS_it, S, worst))
             assert worst < common.TOL_XU
         ctx.close()
 

@@ -199,7 +199,7 @@ def test_more_status_flags(g):
     assert out["status"][0] & _flag("ST_NOT_INTERIOR")
     ctx.close()
     # unsupported configuration fails loudly at creation, with a message
-    cfg, par = common.lmpc_config(g, 12, max_batch=4, numSS_it=5)            # 60 safe-set columns + 6 terminal slacks > 64 lanes
+    cfg, par = common.lmpc_config(g, 12, max_batch=4, numSS_it=4, numSS_Points=252)      # beyond LMPC_MAX_SS_POINTS
     with pytest.raises(_capi.LmpcError, match="argument check failed"):
         _capi.Context(cfg)
     # calls before any lap is stored
