@@ -341,14 +341,20 @@ def main():
             out["config_rollouts"] = dict(leg, note="BASELINE configs[3]: closed-loop LMPC laps sharded over the ranks, lap stores replicated, one all-gather per lap")
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, B) if world == 1 else None
+    def drain_stdio():   # librccl announces its version through C stdio (buffered when stdout is a pipe): push it out NOW
+        try:
+            import ctypes
+            sys.stdout.flush(); ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    # the JSON line must be the LAST thing on the job's stdout: every rank drains its buffers, THEN the ranks meet at the barrier, then rank 0 prints
+    drain_stdio()
     comm.barrier()
     comm.close()
     ctx.close()
-    try:    # librccl announces its version through C stdio; drain that buffer now, so that the JSON line is the LAST thing on stdout
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
+    drain_stdio()
+    if rank == 0 and world > 1:
+        time.sleep(0.2)                             # the other ranks' exit paths (their stdout is the same pipe)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

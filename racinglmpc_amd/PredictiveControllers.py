@@ -251,7 +251,25 @@ class LMPC(MPC):
         self.zt_u = self._out["ztuNext"][0].copy()
 
     def addTerminalComponents(self, x0):
-        raise NotImplementedError("fused into solve(): selection and terminal blocks are built on the GPU")
+        """Reference :386-416 as a call of its own (solve() does the same inside the fused step): wrap of zt[4] (:392-394, with its write
+        through xLin), the numSS_it fastest laps, one window of numSS_Points / numSS_it + 1 rows per lap around the row nearest to zt.  Sets
+        SS_PointSelectedTot (6, numSS_Points), Succ_SS_PointSelectedTot, Succ_uSS_PointSelectedTot (2, numSS_Points), Qfun_SelectedTot.
+        The terminal equality rows and cost the reference then appends (:345-362) are what qp_matrices() returns after a solve."""
+        x0 = np.asarray(x0, dtype=float)
+        TL = self.predictiveModel.map.TrackLength
+        if (self.zt[4] - x0[4] > TL / 2):
+            self.zt[4] = np.max([self.zt[4] - TL, 0])
+            self.xLin[4, -1] = self.xLin[4, -1] - TL
+            self._resync_aliased_laps()
+        self._ctx.ss_set_selected(np.argsort(np.array(self.LapTime))[0:self.numSS_it])
+        has_pred = 0 if isinstance(self.xPred, list) else 1
+        xpp = np.zeros((self.N + 1, 6)) if not has_pred else self.xPred
+        o = self._ctx.select_batch(x0[None], np.array(self.zt, dtype=float)[None], xpp[None], np.array([has_pred]), np.array([self.timeStep]))
+        self._raise_on_status(o["status"][0], x0)
+        self.SS_PointSelectedTot = o["ssSel"][0].T.copy()
+        self.Succ_SS_PointSelectedTot = o["succ"][0].T.copy()
+        self.Succ_uSS_PointSelectedTot = o["succU"][0].T.copy()
+        self.Qfun_SelectedTot = o["qSel"][0].copy()
 
     def addTrajectory(self, x, u, x_glob):
         x = np.asarray(x, dtype=float); u = np.asarray(u, dtype=float)

@@ -36,7 +36,7 @@ struct lmpc_ctx {
     int *w_hasPred, *w_tstep, *w_status, *w_iters, *w_rstatus;
     lmpc_variant_api var;                    // launchers of the (N, numSS_points) instantiation of the solve kernels in use
     void *var_dl;                            // dlopen handle when that instantiation lives in its own shared object (lmpc_variant.hip)
-    int mw_max_batch, n_cu;
+    int mw_max_batch, mw2_max_batch, n_cu;   // largest batch served by the four-wave / the two-wave solve kernel
     int fuse_k1;                             // fused step for one-wave batches (LMPC_FUSE=0 turns it off)
     int profiling; bool ev_open; std::vector<evpair> events; lmpc_stats stats;
     struct lmpc_rollout_session *ro;
@@ -141,8 +141,13 @@ static int create_body(lmpc_ctx *c) {
     // a variant whose LDS footprint leaves room for one QP per CU (N = 40) keeps three SIMDs idle in the 1-wave kernel at any
     // batch size: always run it with four waves per QP (measured at N=40, B=1024: 2.80 vs 3.52 ms; N=20 and N=14 prefer 1 wave)
     if (!getenv("LMPC_MW_MAX_BATCH") && 2 * c->var.lds_1w > 160 * 1024) c->mw_max_batch = 1 << 30;
+    // Two waves per QP between the four-wave and the one-wave regime: how far up depends on the horizon -- the longer the horizon, the
+    // larger the share of the Newton step that is sequential (the helper wave only waits) and the fewer QPs of the multi-wave LDS layout fit a
+    // CU.  Measured (solve kernel, ms; two waves | one wave): N=12 B=1024 0.29 | 0.40;  N=14 B=512 0.33 | 0.42, B=1024 0.48 | 0.44;
+    // N=20 B=512 0.43 | 0.56, B=1024 0.79 | 0.63;  N=40 B=512 1.35 | 1.00, B=1024 2.33 | 1.78 (and four waves: 1.18, 2.05).
+    c->mw2_max_batch = c->mw_max_batch == c->n_cu ? (cfg->N <= 12 ? 4 : cfg->N <= 24 ? 2 : 0) * c->n_cu : 0;
     // safe sets wider than 58 points (numSS_points + 6 terminal columns > one per lane) exist as one-wave kernels only
-    if (c->var.lds_mw == 0) c->mw_max_batch = 0;
+    if (c->var.lds_mw == 0) { c->mw_max_batch = 0; c->mw2_max_batch = 0; }
     // Fused step (regression inside the one-wave solve kernel): bit-identical results, 42 MB less HBM traffic per step at batch 4096, but
     // MEASURED SLOWER -- 1.37 vs 1.01 + 0.23 ms at batch 4096, 2.48 vs 1.81 + 0.44 ms at batch 8192: the regression's short dependent chains
     // (DPP minima, 5 x 5 Cholesky, scattered L2 reads) want the four waves per SIMD its own kernel gets, and the solve's LDS footprint leaves
@@ -402,8 +407,8 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
     const bool term = c->cfg.numSS_it > 0;
     int rc = refresh_params(c, false, term && (io.mode & 1)); if (rc) return rc;
     ev_begin(c, 1);
-    // waves per QP: 4 up to one QP per CU, 2 up to four QPs per CU (what the multi-wave LDS layout holds: two waves per SIMD), beyond that
-    // the one-wave kernel, whose slim LDS layout keeps six QPs resident per CU
+    // waves per QP: 4 up to one QP per CU, 2 up to mw2_max_batch (four QPs per CU at N <= 12, see create_body), beyond that the one-wave
+    // kernel, whose slim LDS layout keeps six QPs resident per CU at N = 12
 #ifdef LMPC_DEV_FAST
     if (const char *f = getenv("LMPC_FORCE_NW")) {
         const int nw = atoi(f);
@@ -412,7 +417,7 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
 #endif
     rc = (io.mode & 4) ? c->var.launch_1w(c->stream, c->dp, B, io)        // fused step: the one-wave kernel runs the regression itself
        : (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->var.launch_mw4(c->stream, c->dp, B, io)
-       : (B <= 4 * c->n_cu && c->mw_max_batch == c->n_cu && !io.tbuf) ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
+       : (B <= c->mw2_max_batch && !io.tbuf) ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     ev_end(c);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -833,7 +838,7 @@ int lmpc_selftest(lmpc_ctx *c) {
     return LMPC_OK;
 }
 
-int lmpc_solver_waves(lmpc_ctx *c, int B) { if (!c) return LMPC_E_ARG; return B <= c->mw_max_batch ? 4 : (B <= 4 * c->n_cu && c->mw_max_batch == c->n_cu) ? 2 : 1; }
+int lmpc_solver_waves(lmpc_ctx *c, int B) { if (!c) return LMPC_E_ARG; return B <= c->mw_max_batch ? 4 : B <= c->mw2_max_batch ? 2 : 1; }
 
 int lmpc_set_profiling(lmpc_ctx *c, int every) { ARGCHK(c); c->profiling = every > 0 ? every : 0; return LMPC_OK; }
 static int drain_events(lmpc_ctx *c) {

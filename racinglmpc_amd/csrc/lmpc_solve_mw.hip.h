@@ -26,7 +26,10 @@
 #endif
 
 template <int N, int S, int NW>
-__global__ __launch_bounds__(WAVE *NW, NW == 4 ? 1 : 2) void lmpc_solve_kernel_mw(lmpc_dev_params p, int B, lmpc_solve_io io) {
+// (registers: four waves per QP = one wave per SIMD; two waves per QP = two waves per SIMD only where the LDS footprint lets three or more
+// QPs share a CU -- long horizons keep their sweep operands (3 N doubles per lane) in registers and need the full file: at N = 40 the
+// 256-register build spilled 221 VGPRs to scratch)
+__global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 > 160 * 1024) ? 1 : 2) void lmpc_solve_kernel_mw(lmpc_dev_params p, int B, lmpc_solve_io io) {
     static_assert(NW == 2 || NW == 4, "wave 0 runs the sequential recursions, waves 1 .. NW-1 everything that can run beside them");
     extern __shared__ double sm[];
     using LL = solve_lds<N, S>;

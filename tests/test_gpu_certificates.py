@@ -256,7 +256,7 @@ def test_general_horizon_and_safe_set_size(built, N, numSS_it, ppl):
     track = np.array(g["track"]); TL = float(g["trackLength"])
     par = orc.QPParams.lmpc_default(N)
     par.numSS_Points, par.numSS_it = S, numSS_it
-    for B in (48, 700, 1300):
+    for B in (48, 400, 1300):
         cfg, _ = common.lmpc_config(g, N, max_batch=B, numSS_it=numSS_it, numSS_Points=S)
         ctx = _capi.Context(cfg)
         assert ctx.S == S

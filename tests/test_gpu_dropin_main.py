@@ -127,6 +127,18 @@ def test_main_py_flow_through_dropin_modules(built):
         assert lmpc.uStoredPredTraj[it][3].shape == (N, 2)
     # lap 4 was extended by addPoint while lap 5 was driven (SysModel.py:37-38): it reaches beyond the finish line
     assert lmpc.SS[4].shape[0] == lmpc.LapTime[4] + lmpc.LapTime[5] and lmpc.SS[4][-1, 4] > TL
+    # addTerminalComponents as a call of its own (:386-416): the windows of the four fastest laps around zt, successors one row later
+    lmpc.addTerminalComponents(xS[0])
+    assert lmpc.SS_PointSelectedTot.shape == (6, numSS_Points) and lmpc.Succ_SS_PointSelectedTot.shape == (6, numSS_Points)
+    assert lmpc.Succ_uSS_PointSelectedTot.shape == (2, numSS_Points) and lmpc.Qfun_SelectedTot.shape == (numSS_Points,)
+    order = np.argsort(np.array(lmpc.LapTime))[0:numSS_it]
+    ppl = numSS_Points // numSS_it
+    for j, l in enumerate(order):
+        d = np.abs(lmpc.SS[l] - lmpc.zt).sum(axis=1); mn = int(np.argmin(d))
+        start = mn - (ppl + 1) // 2 if mn - (ppl + 1) / 2 >= 0 else mn
+        assert np.array_equal(lmpc.SS_PointSelectedTot[:, j * ppl:(j + 1) * ppl], lmpc.SS[l][start:start + ppl].T)
+        assert np.array_equal(lmpc.Succ_SS_PointSelectedTot[:, j * ppl:(j + 1) * ppl], lmpc.SS[l][start + 1:start + ppl + 1].T)
+        assert np.array_equal(lmpc.Succ_uSS_PointSelectedTot[:, j * ppl:(j + 1) * ppl], lmpc.uSS[l][start + 1:start + ppl + 1].T)
     # selectPoints return contract (:478-514)
     ss, ssu, qf = lmpc.selectPoints(5, lmpc.SS[5][40], numSS_Points / numSS_it + 1)
     assert ss.shape == (6, 13) and ssu.shape == (2, 13) and qf.shape == (13,)

@@ -10,13 +10,14 @@ sys.path.insert(0, ROOT)
 import bench
 
 g = bench.load_seed()
+NH = int(os.environ.get("EXP_N", "12"))            # horizon
 sizes = [int(a) for a in sys.argv[1:]] or [1, 256, 512, 1024, 4096, 8192]
 row = []
 for B in sizes:
-    r = bench.run_config(g, 12, B, 0, steps=20 if B <= 1024 else 6, warmup=3)
+    r = bench.run_config(g, NH, B, 0, steps=20 if B <= 1024 and NH <= 20 else 6, warmup=3)
     row.append("B=%d: %.0f/s (solve %.3f ms, K1 %.3f ms, ok %d/%d, it max %d)" % (B, r["solves_per_s"], r["kernel_ms"]["lmpc_solve_kernel"], r["kernel_ms"]["lmpc_regress_kernel"] or 0.0,
                                                                                   r["solved_ok"], B, r["ipm_iters_max"]))
-print("NW=%s  " % os.environ.get("LMPC_FORCE_NW", "auto") + " | ".join(row))
+print("N=%d NW=%s  " % (NH, os.environ.get("LMPC_FORCE_NW", "auto")) + " | ".join(row))
 if os.environ.get("EXP_CERT", "1") == "1":
     from tests import kkt_batch
     from oracle import lmpc_oracle as orc
