@@ -146,6 +146,7 @@ static int create_body(lmpc_ctx *c) {
     // CU.  Measured (solve kernel, ms; two waves | one wave): N=12 B=1024 0.29 | 0.40;  N=14 B=512 0.33 | 0.42, B=1024 0.48 | 0.44;
     // N=20 B=512 0.43 | 0.56, B=1024 0.79 | 0.63;  N=40 B=512 1.35 | 1.00, B=1024 2.33 | 1.78 (and four waves: 1.18, 2.05).
     c->mw2_max_batch = c->mw_max_batch == c->n_cu ? (cfg->N <= 12 ? 4 : cfg->N <= 24 ? 2 : 0) * c->n_cu : 0;
+    if (const char *e = getenv("LMPC_MW2_MAX_BATCH")) c->mw2_max_batch = atoi(e);        // (experiments)
     // safe sets wider than 58 points (numSS_points + 6 terminal columns > one per lane) exist as one-wave kernels only
     if (c->var.lds_mw == 0) { c->mw_max_batch = 0; c->mw2_max_batch = 0; }
     // Fused step (regression inside the one-wave solve kernel): bit-identical results, 42 MB less HBM traffic per step at batch 4096, but
@@ -403,6 +404,7 @@ static int launch_regress(lmpc_ctx *c, int B, const double *d_xLin, int xstride,
     c->stats.n_regress++;
     return LMPC_OK;
 }
+extern "C" int lmpc_solver_waves(lmpc_ctx *c, int B);
 static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
     const bool term = c->cfg.numSS_it > 0;
     int rc = refresh_params(c, false, term && (io.mode & 1)); if (rc) return rc;
@@ -417,7 +419,7 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
 #endif
     rc = (io.mode & 4) ? c->var.launch_1w(c->stream, c->dp, B, io)        // fused step: the one-wave kernel runs the regression itself
        : (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->var.launch_mw4(c->stream, c->dp, B, io)
-       : (B <= c->mw2_max_batch && !io.tbuf) ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
+       : (lmpc_solver_waves(c, B) == 2 && !io.tbuf) ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     ev_end(c);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -838,7 +840,15 @@ int lmpc_selftest(lmpc_ctx *c) {
     return LMPC_OK;
 }
 
-int lmpc_solver_waves(lmpc_ctx *c, int B) { if (!c) return LMPC_E_ARG; return B <= c->mw_max_batch ? 4 : B <= c->mw2_max_batch ? 2 : 1; }
+int lmpc_solver_waves(lmpc_ctx *c, int B) {
+    if (!c) return LMPC_E_ARG;
+    if (B <= c->mw_max_batch) return 4;
+    if (B <= c->mw2_max_batch) return 2;
+    // two full rounds of the two-wave kernel (four QPs per CU) beat one and a third rounds of the one-wave kernel (six per CU):
+    // N = 12, B = 2048: 0.565 vs 0.646 ms; at 1536 (one round of the one-wave kernel) 0.486 vs 0.447, at 3072 0.805 vs 0.788
+    if (c->mw2_max_batch == 4 * c->n_cu && B > 6 * c->n_cu && B <= 8 * c->n_cu) return 2;
+    return 1;
+}
 
 int lmpc_set_profiling(lmpc_ctx *c, int every) { ARGCHK(c); c->profiling = every > 0 ? every : 0; return LMPC_OK; }
 static int drain_events(lmpc_ctx *c) {

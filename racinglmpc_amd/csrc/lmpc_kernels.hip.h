@@ -842,17 +842,22 @@ template <int N, int S> struct solve_lds {
 //   t3+ Newton solves ... : h / dm | dx du ds dl | gamma (= phi = dnu) | gu' | costates p | k0 | eta | e | c~ | costate right-hand sides
 // and the cost-to-go Hessians Pi_k are not stored at all (the equality multipliers follow from a backward recursion with A_k').
 // N = 12, S = 48: 24.5 KB per QP = 6 QPs per CU (the multi-wave layout above: 39.1 KB = 4).
+// Arrays that only ever meet their own lane -- C_k (monitoring residual), the residual of the lambda rows, the lambda scalings D^-1/2
+// and the selected Q-function values -- live in registers (row or column = lane + 64 t), which is what brings the
+// footprint under 160 KB / 7.
 template <int N, int S> struct solve_lds1 {
     static constexpr int M = 8 * N + S;
     static constexpr int CH = (S + 6 + WAVE - 1) / WAVE, CW = CH * WAVE;       // the terminal block's S + 6 columns: CH per lane (column = lane + 64 ch)
-    static constexpr int oAB = 0, oC = oAB + 48 * N;
-    static constexpr int ox = oC + 6 * N, ou = ox + 6 * (N + 1), os = ou + 2 * N, olam = os + 2 * N, onu = olam + S;
+    static constexpr int oAB = 0;
+    static constexpr int ox = oAB + 48 * N, ou = ox + 6 * (N + 1), os = ou + 2 * N, olam = os + 2 * N, onu = olam + S;
+    static constexpr int oCk1 = ox;                                             // fused step only: the regression leaves C_k here (then its work space), before x .. exist
     static constexpr int om = onu + 6 * N, oth = om + M;
-    static constexpr int orx = oth + M, oru = orx + 6 * (N + 1), ors = oru + 2 * N, orl = ors + 2 * N;
-    static constexpr int oPhiK = orl + S, oMi = oPhiK + 16 * N, okap = oMi + 4 * N, orDs = okap + 2 * N;
-    static constexpr int oRi = orDs + 2 * N, orsq = oRi + 56, oMc = orsq + CW;
-    static constexpr int oSS = oMc + 8, oQsel = oSS + 6 * S, oy7 = oQsel + S, oz7 = oy7 + 8, ow7 = oz7 + 8, oPiT = ow7 + 8, osT = oPiT + 36;
+    static constexpr int orx = oth + M, oru = orx + 6 * (N + 1), ors = oru + 2 * N;
+    static constexpr int oPhiK = ors + 2 * N, oMi = oPhiK + 16 * N, okap = oMi + 4 * N, orDs = okap + 2 * N;
+    static constexpr int oRi = orDs + 2 * N, oMc = oRi + 56;
+    static constexpr int oSS = oMc + 8, oy7 = oSS + 6 * S, oz7 = oy7 + 8, ow7 = oz7 + 8, oPiT = ow7 + 8, osT = oPiT + 36;
     static constexpr int opar = osT + 8, oscr = opar + PAR_TOT;
+    static constexpr int oCs = oscr, oQs = oCs + 6 * N;                          // start-up only: C_k for the roll-out, Qfun_sel of the selection
     // scratch region, by phase
     static constexpr int oMt = oscr, oWl = oMt + 8 * CW;                                       // t1
 #ifdef LMPC_DBG_NOALIAS
@@ -865,7 +870,8 @@ template <int N, int S> struct solve_lds1 {
     static constexpr int odm = oh, odx = oh + M, odu = odx + 6 * (N + 1), ods = odu + 2 * N, odl = ods + 2 * N;   // t3+
     static constexpr int ogam = odl + S, odnu = ogam, ogup = ogam + 8 * N, opst = ogup + 2 * N, ok0 = opst + 8 * (N + 1);
     static constexpr int oeta = ok0 + 2 * N, oe = oeta + 2 * N, oct = oe + 2 * N, ott = oct + CW, oend3 = ott + 6 * N;
-    static constexpr int scr1 = S > 0 ? 8 * CW + 64 : 0, scr2 = 64 * N, scr3 = oend3 - oscr;
+    static constexpr int scr0 = 6 * N + S, scr1 = S > 0 ? 8 * CW + 64 : 0, scr2 = 64 * N, scr3 = oend3 - oscr;
+    static_assert(scr0 <= scr3, "start-up staging fits the Newton-solve scratch");
     static constexpr int scr = scr1 > scr2 ? (scr1 > scr3 ? scr1 : scr3) : (scr2 > scr3 ? scr2 : scr3);
 #ifdef LMPC_DBG_NOALIAS
     static constexpr int tot = oend3;
@@ -875,6 +881,8 @@ template <int N, int S> struct solve_lds1 {
 };
 
 #define FOR_LANES(idx, n) for (int idx = lane; idx < (n); idx += WAVE)
+// same trips with the trip number t as a compile-time index (register arrays: element idx = lane + 64 t lives in slot t of its lane)
+#define FOR_LANES_T(idx, t, n) _Pragma("unroll") for (int t = 0, idx = lane; t < ((n) + WAVE - 1) / WAVE; t++, idx += WAVE) if (idx < (n))
 
 // sum over the 8 lanes of a group (lane = 8 g + c, all lanes of the group receive it) / over the 8 groups (same c)
 __device__ __forceinline__ double sum_over_c(double v) {
@@ -1008,17 +1016,19 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     if constexpr (EQ) { if (!(io.status[b] & (LMPC_ST_MAXITER | LMPC_ST_NUMERIC))) return; }
     const int lane = threadIdx.x;
     const int lg = lane >> 3, lc = lane & 7;                // lane = 8 g + c  (8 x 8 tile coordinates)
-    double *AB = sm + LL::oAB, *C = sm + LL::oC, *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
+    double *AB = sm + LL::oAB, *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
     double *dx = sm + LL::odx, *du = sm + LL::odu, *ds = sm + LL::ods, *dl = sm + LL::odl, *nu = sm + LL::onu, *dnu = sm + LL::odnu;
     double *m = sm + LL::om, *th = sm + LL::oth, *h = sm + LL::oh, *dm = sm + LL::odm;
-    double *rx = sm + LL::orx, *ru = sm + LL::oru, *rs = sm + LL::ors, *rl = sm + LL::orl;
+    double *rx = sm + LL::orx, *ru = sm + LL::oru, *rs = sm + LL::ors;
     double *Phi = sm + LL::oPhi, *PhiK = sm + LL::oPhiK, *Mi = sm + LL::oMi, *gam = sm + LL::ogam, *gup = sm + LL::ogup, *pst = sm + LL::opst, *k0 = sm + LL::ok0;
     double *tt = sm + LL::ott;                             // right-hand sides of the costate recursion
     double *phi = gam;                                     // gamma is dead (kept in registers) once the backward sweep starts
     double *kap = sm + LL::okap, *rDs = sm + LL::orDs, *eta = sm + LL::oeta, *ee = sm + LL::oe;
-    double *Ri = sm + LL::oRi, *rsq = sm + LL::orsq, *ct = sm + LL::oct, *Mt = sm + LL::oMt, *Wl = sm + LL::oWl, *McL = sm + LL::oMc;
-    double *SS = sm + LL::oSS, *Qsel = sm + LL::oQsel, *y7 = sm + LL::oy7, *z7 = sm + LL::oz7, *w7 = sm + LL::ow7, *PiT = sm + LL::oPiT, *sT = sm + LL::osT;
+    double *Ri = sm + LL::oRi, *ct = sm + LL::oct, *Mt = sm + LL::oMt, *Wl = sm + LL::oWl, *McL = sm + LL::oMc;
+    double *SS = sm + LL::oSS, *Qsel = sm + LL::oQs, *y7 = sm + LL::oy7, *z7 = sm + LL::oz7, *w7 = sm + LL::ow7, *PiT = sm + LL::oPiT, *sT = sm + LL::osT;
     double *par = sm + LL::opar;
+    constexpr int T6N = (6 * N + WAVE - 1) / WAVE;
+    double c_r[T6N], rl_r[CH], qsel_r[CH];      // own-lane arrays (element lane + 64 t in slot t)
     const double *Fx = par + PAR_FX, *Fu = par + PAR_FU, *bx = par + PAR_BX, *bu = par + PAR_BU, *Q2 = par + PAR_Q2, *Qf2 = par + PAR_QF2,
                  *R2 = par + PAR_R2, *dR2 = par + PAR_DR2, *T2p = par + PAR_T2, *xRef = par + PAR_XREF;
     __shared__ int st_sh;
@@ -1029,9 +1039,11 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     if (io.mode & 4) {
         // K1 (fused step): LTV regression of this QP's N points by this wave, in the LDS behind AB / C that the solve needs only later
         __syncthreads();
-        const int rst = k1_wave_problem(p, b, lane, io.xLin + (size_t)b * (N + 1) * 6, io.uLin + (size_t)b * N * 2, sm + LL::oC + 6 * N, AB, C,
+        const int rst = k1_wave_problem(p, b, lane, io.xLin + (size_t)b * (N + 1) * 6, io.uLin + (size_t)b * N * 2, sm + LL::oCk1 + 6 * N, AB, sm + LL::oCk1,
                                         io.Aout, io.Bout, io.Cout);
         if (rst) atomicOr(&st_sh, rst);
+        __syncthreads();
+        FOR_LANES_T(i, t, 6 * N) c_r[t] = sm[LL::oCk1 + i];
         __syncthreads();
     }
     // stage the parameter block
@@ -1059,8 +1071,11 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     if (!(io.mode & 4)) {
         FOR_LANES(i, 36 * N) { const int k = i / 36, r = (i % 36) / 6, c = i % 6; AB[k * 48 + r * 8 + c] = io.A[(size_t)b * 36 * N + i]; }
         FOR_LANES(i, 12 * N) { const int k = i / 12, r = (i % 12) >> 1, c = i & 1; AB[k * 48 + r * 8 + 6 + c] = io.Bm[(size_t)b * 12 * N + i]; }
-        FOR_LANES(i, 6 * N) C[i] = io.C[(size_t)b * 6 * N + i];
+        FOR_LANES_T(i, t, 6 * N) c_r[t] = io.C[(size_t)b * 6 * N + i];
     }
+    double *Cs = sm + LL::oCs;                             // C_k for the roll-out below (scratch; afterwards C lives in c_r only)
+    FOR_LANES_T(i, t, 6 * N) Cs[i] = c_r[t];
+    if constexpr (term) { FOR_LANES_T(c, t, S) qsel_r[t] = Qsel[c]; }
     FOR_LANES(i, 6 * N) nu[i] = 0.0;
     if (lane < 6) x[lane] = io.x0[(size_t)b * 6 + lane];
     FOR_LANES(i, 2 * N) u[i] = 0.0;
@@ -1069,7 +1084,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
 #pragma unroll 1
     for (int k = 0; k < N; k++) {                          // strictly interior start: u = 0, x by roll-out
         if (lane < 6) {
-            double v = C[k * 6 + lane];
+            double v = Cs[k * 6 + lane];
 #pragma unroll
             for (int j = 0; j < 6; j++) v = fma(AB[k * 48 + lane * 8 + j], x[k * 6 + j], v);
             x[(k + 1) * 6 + lane] = v;
@@ -1088,7 +1103,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         s[i] = viol > 0.0 ? viol + 1.0 : s_init;
     }
     double qmax = 0.0;
-    if constexpr (term) { FOR_LANES(c, S) { lam[c] = 1.0 / (double)S; qmax = fmax(qmax, fabs(Qsel[c])); } qmax = wmax(qmax); }
+    if constexpr (term) { FOR_LANES_T(c, t, S) { lam[c] = 1.0 / (double)S; qmax = fmax(qmax, fabs(qsel_r[t])); } qmax = wmax(qmax); }
     const double mu0 = fmax(1.0, 0.01 * (term ? qmax : 1.0));
     if (lane < 4 && !(bu[lane] > 0.0)) atomicOr(&st_sh, LMPC_ST_NOT_INTERIOR);
     double eta_m = 0.0;
@@ -1106,21 +1121,19 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     };
     auto rowb = [&](int r) -> double { if (r < 2 * N) return bx[r & 1]; if (r < 6 * N) return bu[(r - 2 * N) & 3]; return 0.0; };
 
-    double t_r[RPL], rt_r[RPL], tp_r[RPL], dt_r[RPL];      // per-lane row state (row = lane + 64 j)
+    double t_r[RPL], tp_r[RPL], dt_r[RPL];                 // per-lane row state (row = lane + 64 j); 1 / t is recomputed where needed (registers)
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
         const int r = lane + WAVE * j;
-        t_r[j] = 1.0; rt_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
+        t_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
         if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; m[r] = mu0 / tt; }
     }
     const ricc_consts rc = ricc_setup(lane, Q2, Fx, R2, dR2, Fu);
     double ph[N];                                          // Phi_k entry this lane multiplies with in the register sweeps
-    double mcol[CH][7];                                    // this lane's columns of M = [E D^-1/2 | T7^-1/2] (column lane + 64 ch)
-    double tsq_lane[CH];                                   // T^-1/2 entry of a slack column of M (loop invariant)
+    double mcol[CH][7];                                    // this lane's columns of M = [E D^-1/2 | T7^-1/2] (column lane + 64 ch); row 6 of a
+                                                           // lambda column is its scaling D^-1/2 itself
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
-        const int col = lane + WAVE * ch;
-        tsq_lane[ch] = (term && col >= S && col < S + 6) ? frsqrt(T2p[col - S]) : 0.0;
 #pragma unroll
         for (int j = 0; j < 7; j++) mcol[ch][j] = 0.0;
     }
@@ -1130,12 +1143,12 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
 
     // one Newton-system solve for the right-hand side currently in (rx,ru,rs,rl,h); result in dx,du,ds,dl
     auto kkt_solve = [&](double re_sum) {
-        FOR_LANES(i, 2 * N) {                                   // slack elimination, per lane row (k,j)
+        FOR_LANES_T(i, t, 2 * N) {                              // slack elimination, per lane row (k,j)
             const double hl = h[i], hs = h[6 * N + i];
             const double e_ = -(rs[i] + hl + hs);
             ee[i] = e_; eta[i] = hl + th[i] * e_ * rDs[i];
         }
-        FOR_LANES(i, 2 * N) {                                   // gu' = ru - Fu' h_u
+        FOR_LANES_T(i, t, 2 * N) {                              // gu' = ru - Fu' h_u
             const int k = i >> 1, c = i & 1; double v = ru[i];
 #pragma unroll
             for (int j = 0; j < 4; j++) v -= Fu[j * 2 + c] * h[2 * N + 4 * k + j];
@@ -1147,8 +1160,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             for (int ch = 0; ch < CH; ch++) {
                 const int col = lane + WAVE * ch;
                 c_t[ch] = 0.0;
-                if (col < S) c_t[ch] = (rl[col] + h[8 * N + col]) * rsq[col];
-                ct[col] = col < S ? c_t[ch] * rsq[col] : 0.0;  // D^-1/2 c~ (the slack columns of M meet zeros of c~)
+                if (col < S) c_t[ch] = (rl_r[ch] + h[8 * N + col]) * mcol[ch][6];
+                ct[col] = col < S ? c_t[ch] * mcol[ch][6] : 0.0;  // D^-1/2 c~ (the slack columns of M meet zeros of c~)
             }
         }
         __syncthreads();
@@ -1234,7 +1247,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         }
         __syncthreads();
         TSTAMP(33);
-        FOR_LANES(i, 2 * N) {
+        FOR_LANES_T(i, t, 2 * N) {
             const int k = i >> 1, j = i & 1; double f = 0.0;
 #pragma unroll
             for (int c = 0; c < 6; c++) f = fma(Fx[j * 6 + c], dx[k * 6 + c], f);
@@ -1258,7 +1271,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
                 double v = -c_t[ch];                            // v = -c~ + M' omega'
 #pragma unroll
                 for (int j = 0; j < 7; j++) v = fma(mcol[ch][j], w7[j], v);
-                if (col < S) dl[col] = v * rsq[col];
+                if (col < S) dl[col] = v * mcol[ch][6];
             }
         }
         __syncthreads();
@@ -1275,7 +1288,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
             const int r = lane + WAVE * j;
-            if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; rt_r[j] = frcp(tt); gsum = fma(tt, m[r], gsum); }
+            if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; gsum = fma(tt, m[r], gsum); }
         }
         if constexpr (term) {
             ss_times<S>(SS, lam, x + N * 6, sT, lane);
@@ -1297,7 +1310,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             }
             rx[i] = v;
         }
-        FOR_LANES(i, 2 * N) {
+        FOR_LANES_T(i, t, 2 * N) {
             const int k = i >> 1, c = i & 1;
             const double up = k > 0 ? u[(k - 1) * 2 + c] : (c == 0 ? uOld0 : uOld1);
             double v = R2[c * 2] * u[k * 2] + R2[c * 2 + 1] * u[k * 2 + 1] + dR2[c] * (u[i] - up);
@@ -1312,16 +1325,16 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         }
         double lsum = 0.0;
         if constexpr (term) {
-            FOR_LANES(c, S) {
-                double v = Qsel[c] - m[8 * N + c] + eta_m;
+            FOR_LANES_T(c, t, S) {
+                double v = qsel_r[t] - m[8 * N + c] + eta_m;
 #pragma unroll
                 for (int j = 0; j < 6; j++) v = fma(SS[j * S + c], T2p[j] * sT[j], v);
-                rl[c] = v; rmax = fmax(rmax, fabs(v)); lsum += lam[c];
+                rl_r[t] = v; rmax = fmax(rmax, fabs(v)); lsum += lam[c];
             }
         }
-        FOR_LANES(i, 6 * N) {                                    // dynamics residual (monitoring only)
+        FOR_LANES_T(i, t, 6 * N) {                               // dynamics residual (monitoring only)
             const int k = i / 6, c = i % 6;
-            double v = x[(k + 1) * 6 + c] - C[i] - AB[k * 48 + c * 8 + 6] * u[k * 2] - AB[k * 48 + c * 8 + 7] * u[k * 2 + 1];
+            double v = x[(k + 1) * 6 + c] - c_r[t] - AB[k * 48 + c * 8 + 6] * u[k * 2] - AB[k * 48 + c * 8 + 7] * u[k * 2 + 1];
 #pragma unroll
             for (int j = 0; j < 6; j++) v -= AB[k * 48 + c * 8 + j] * x[k * 6 + j];
             remax = fmax(remax, fabs(v));
@@ -1339,9 +1352,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         TSTAMP(11);
         // ---- factorisation of the Newton (block-banded KKT) matrix -------------------------------------
 #pragma unroll
-        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) th[r] = m[r] * rt_r[j]; }
+        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) th[r] = m[r] * frcp(t_r[j]); }
         __syncthreads();
-        FOR_LANES(i, 2 * N) {
+        FOR_LANES_T(i, t, 2 * N) {
             const double d_ = frcp(a_s + th[i] + th[6 * N + i]);
             rDs[i] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
         }
@@ -1355,14 +1368,14 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
 #pragma unroll
                 for (int j = 0; j < 7; j++) mcol[ch][j] = 0.0;
                 if (col < S) {
-                    const double rs_ = frsqrt(th[8 * N + col] + p.reg); rsq[col] = rs_;
+                    const double rs_ = frsqrt(th[8 * N + col] + p.reg);
 #pragma unroll
                     for (int j = 0; j < 6; j++) mcol[ch][j] = SS[j * S + col] * rs_;
                     mcol[ch][6] = rs_;
                 } else {
-                    rsq[col] = 1.0;
+                    const double tsq = col < S + 6 ? frsqrt(T2p[col < S + 6 ? col - S : 0]) : 0.0;    // T^-1/2 entry of a slack column of M
 #pragma unroll
-                    for (int j = 0; j < 6; j++) if (col - S == j) mcol[ch][j] = tsq_lane[ch];
+                    for (int j = 0; j < 6; j++) if (col - S == j) mcol[ch][j] = tsq;
                 }
             }
             double Rr[7][7], rinv[7];
@@ -1478,7 +1491,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         // ---- corrector: h = (t mu - sigma gap + dt_aff dmu_aff) / t ----------------------------------------
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) h[r] = m[r] + (tp_r[j] - tgt) * rt_r[j]; }
+        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) h[r] = m[r] + (tp_r[j] - tgt) * frcp(t_r[j]); }
         __syncthreads();
         TSTAMP(15);
         kkt_solve(re_sum);
@@ -1571,7 +1584,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         double deta = 0.0;
         if constexpr (term) {
             double v = 0.0;
-            FOR_LANES(c, S) { v += -rl[c] + dm[8 * N + c];
+            FOR_LANES_T(c, t, S) { v += -rl_r[t] + dm[8 * N + c];
 #pragma unroll
                 for (int j = 0; j < 6; j++) v -= SS[j * S + c] * T2p[j] * w7[j]; }
             deta = wsum(v) / (double)S;
