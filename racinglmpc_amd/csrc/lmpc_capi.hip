@@ -143,7 +143,7 @@ static int create_body(lmpc_ctx *c) {
     if (!getenv("LMPC_MW_MAX_BATCH") && 2 * c->var.lds_1w > 160 * 1024) c->mw_max_batch = 1 << 30;
     // Two waves per QP between the four-wave and the one-wave regime: how far up depends on the horizon -- the longer the horizon, the
     // larger the share of the Newton step that is sequential (the helper wave only waits) and the fewer QPs of the multi-wave LDS layout fit a
-    // CU.  Measured (solve kernel, ms; two waves | one wave): N=12 B=1024 0.29 | 0.40;  N=14 B=512 0.33 | 0.42, B=1024 0.48 | 0.44;
+    // CU.  Measured (solve kernel, ms; two waves | one wave): N=12 B=1024 0.30 | 0.40, B=2048 (two rounds | one round) 0.56 | 0.47;  N=14 B=512 0.33 | 0.42, B=1024 0.48 | 0.44;
     // N=20 B=512 0.43 | 0.56, B=1024 0.79 | 0.63;  N=40 B=512 1.35 | 1.00, B=1024 2.33 | 1.78 (and four waves: 1.18, 2.05).
     c->mw2_max_batch = c->mw_max_batch == c->n_cu ? (cfg->N <= 12 ? 4 : cfg->N <= 24 ? 2 : 0) * c->n_cu : 0;
     if (const char *e = getenv("LMPC_MW2_MAX_BATCH")) c->mw2_max_batch = atoi(e);        // (experiments)
@@ -844,9 +844,6 @@ int lmpc_solver_waves(lmpc_ctx *c, int B) {
     if (!c) return LMPC_E_ARG;
     if (B <= c->mw_max_batch) return 4;
     if (B <= c->mw2_max_batch) return 2;
-    // two full rounds of the two-wave kernel (four QPs per CU) beat one and a third rounds of the one-wave kernel (six per CU):
-    // N = 12, B = 2048: 0.565 vs 0.646 ms; at 1536 (one round of the one-wave kernel) 0.486 vs 0.447, at 3072 0.805 vs 0.788
-    if (c->mw2_max_batch == 4 * c->n_cu && B > 6 * c->n_cu && B <= 8 * c->n_cu) return 2;
     return 1;
 }
 

@@ -740,9 +740,11 @@ __device__ __forceinline__ ricc_consts ricc_setup(int lane, const double *Q2, co
 // stage behind the recursion instead of after it.  LDS operations of one wave execute in issue order: a wave released by the barrier
 // finds Phi_k, Pi_k and M_uu^-1 of the stage in place, and no s_waitcnt is needed on this side.
 // (Publishing the stage through an LDS word that the followers poll, so that this wave never waits, was measured too: no difference.)
-template <int N, bool term, bool STEP = false>
+// SPLIT (one-wave kernel): rows 0..5 of Phi_k go to 6 x 8 tiles in `Phi` (scratch, read back once into the sweep registers), rows 6, 7
+// (= -K_k, needed by every Newton solve) straight to their permanent place PhiK (2 x 8 per stage).
+template <int N, bool term, bool STEP = false, bool SPLIT = false>
 __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *AB, const double *kap, const double *th, const double *Qf2,
-                                           const double *PiT, double *Phi, double *PiAll, double *Mi) {
+                                           const double *PiT, double *Phi, double *PiAll, double *Mi, double *PhiK = nullptr) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int qr = c.qr;
     int bad = 0;
@@ -808,7 +810,9 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
         Piq = 0.5 * (Piu + lane_gather(Piu, c.qT));
 #endif
 #ifndef RICC_VAR_NOSTORE              // (tools/microbench_ricc.hip: what the LDS stores cost -- 90 cycles per stage)
-        Phi[k * 64 + c.qR * 8 + c.qC] = Phq; if (PiAll) PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
+        if constexpr (SPLIT) { double *d_ = c.qR < 6 ? Phi + k * 48 + c.qR * 8 + c.qC : PhiK + k * 16 + (c.qR - 6) * 8 + c.qC; *d_ = Phq; }
+        else Phi[k * 64 + c.qR * 8 + c.qC] = Phq;
+        if (PiAll) PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
         if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 3 ? i11 : i01);
 #else
         if (k == 0) { Phi[c.qR * 8 + c.qC] = Phq; if (lane < 4) Mi[lane] = i00 + i01 + i11; }
@@ -851,26 +855,30 @@ template <int N, int S> struct solve_lds1 {
     static constexpr int oAB = 0;
     static constexpr int ox = oAB + 48 * N, ou = ox + 6 * (N + 1), os = ou + 2 * N, olam = os + 2 * N, onu = olam + S;
     static constexpr int oCk1 = ox;                                             // fused step only: the regression leaves C_k here (then its work space), before x .. exist
-    static constexpr int om = onu + 6 * N, oth = om + M;
-    static constexpr int orx = oth + M, oru = orx + 6 * (N + 1), ors = oru + 2 * N;
-    static constexpr int oPhiK = ors + 2 * N, oMi = oPhiK + 16 * N, okap = oMi + 4 * N, orDs = okap + 2 * N;
-    static constexpr int oRi = orDs + 2 * N, oMc = oRi + 56;
+    static constexpr int om = onu, oth = om + M;                               // (the equality multipliers nu live in registers; scratch copy at residual time)
+    static constexpr int orx = oth + M;
+    static constexpr int oPhiK = orx + 6 * (N + 1), oMi = oPhiK + 16 * N, okap = oMi + 4 * N;
+    static constexpr int oRi = okap + 2 * N, oMc = oRi + 56;
     static constexpr int oSS = oMc + 8, oy7 = oSS + 6 * S, oz7 = oy7 + 8, ow7 = oz7 + 8, oPiT = ow7 + 8, osT = oPiT + 36;
     static constexpr int opar = osT + 8, oscr = opar + PAR_TOT;
     static constexpr int oCs = oscr, oQs = oCs + 6 * N;                          // start-up only: C_k for the roll-out, Qfun_sel of the selection
+    static constexpr int onus = oscr;                                           // residual phase only: nu, visible to every lane
     // scratch region, by phase
     static constexpr int oMt = oscr, oWl = oMt + 8 * CW;                                       // t1
 #ifdef LMPC_DBG_NOALIAS
     static constexpr int oPhi = oscr + 8 * CW + 64;
-    static constexpr int oh = oPhi + 64 * N;
+    static constexpr int oh = oPhi + 48 * N;
 #else
     static constexpr int oPhi = oscr;                                                          // t2
     static constexpr int oh = oscr;
 #endif
     static constexpr int odm = oh, odx = oh + M, odu = odx + 6 * (N + 1), ods = odu + 2 * N, odl = ods + 2 * N;   // t3+
-    static constexpr int ogam = odl + S, odnu = ogam, ogup = ogam + 8 * N, opst = ogup + 2 * N, ok0 = opst + 8 * (N + 1);
-    static constexpr int oeta = ok0 + 2 * N, oe = oeta + 2 * N, oct = oe + 2 * N, ott = oct + CW, oend3 = ott + 6 * N;
-    static constexpr int scr0 = 6 * N + S, scr1 = S > 0 ? 8 * CW + 64 : 0, scr2 = 64 * N, scr3 = oend3 - oscr;
+    // inside a Newton solve: c~ (read once, before the costates exist) shares the costates' place, eta (dead once gamma is formed) shares k0's;
+    // after the solves the right-hand sides of the multiplier recursion take the costates' place
+    static constexpr int PSTW = 8 * (N + 1) > CW ? 8 * (N + 1) : CW;
+    static constexpr int ogam = odl + S, odnu = ogam, ogup = ogam + 8 * N, opst = ogup + 2 * N, ok0 = opst + PSTW;
+    static constexpr int oeta = ok0, oe = ok0 + 2 * N, oct = opst, ott = opst, oend3 = oe + 2 * N;
+    static constexpr int scr0 = 6 * N + S, scr1 = S > 0 ? 8 * CW + 64 : 0, scr2 = 48 * N, scr3 = oend3 - oscr;
     static_assert(scr0 <= scr3, "start-up staging fits the Newton-solve scratch");
     static constexpr int scr = scr1 > scr2 ? (scr1 > scr3 ? scr1 : scr3) : (scr2 > scr3 ? scr2 : scr3);
 #ifdef LMPC_DBG_NOALIAS
@@ -883,6 +891,13 @@ template <int N, int S> struct solve_lds1 {
 #define FOR_LANES(idx, n) for (int idx = lane; idx < (n); idx += WAVE)
 // same trips with the trip number t as a compile-time index (register arrays: element idx = lane + 64 t lives in slot t of its lane)
 #define FOR_LANES_T(idx, t, n) _Pragma("unroll") for (int t = 0, idx = lane; t < ((n) + WAVE - 1) / WAVE; t++, idx += WAVE) if (idx < (n))
+
+// A value every lane of the wave holds (a wave reduction, a broadcast read): moved to scalar registers.  The vector register file is what
+// limits the one-wave kernel (256 per wave at two waves per SIMD); a wave-uniform double kept in vector registers costs two of them.
+__device__ __forceinline__ double wave_uniform(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 
 // sum over the 8 lanes of a group (lane = 8 g + c, all lanes of the group receive it) / over the 8 groups (same c)
 __device__ __forceinline__ double sum_over_c(double v) {
@@ -1017,18 +1032,18 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     const int lane = threadIdx.x;
     const int lg = lane >> 3, lc = lane & 7;                // lane = 8 g + c  (8 x 8 tile coordinates)
     double *AB = sm + LL::oAB, *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
-    double *dx = sm + LL::odx, *du = sm + LL::odu, *ds = sm + LL::ods, *dl = sm + LL::odl, *nu = sm + LL::onu, *dnu = sm + LL::odnu;
+    double *dx = sm + LL::odx, *du = sm + LL::odu, *ds = sm + LL::ods, *dl = sm + LL::odl, *nu = sm + LL::onus, *dnu = sm + LL::odnu;
     double *m = sm + LL::om, *th = sm + LL::oth, *h = sm + LL::oh, *dm = sm + LL::odm;
-    double *rx = sm + LL::orx, *ru = sm + LL::oru, *rs = sm + LL::ors;
+    double *rx = sm + LL::orx;
     double *Phi = sm + LL::oPhi, *PhiK = sm + LL::oPhiK, *Mi = sm + LL::oMi, *gam = sm + LL::ogam, *gup = sm + LL::ogup, *pst = sm + LL::opst, *k0 = sm + LL::ok0;
     double *tt = sm + LL::ott;                             // right-hand sides of the costate recursion
     double *phi = gam;                                     // gamma is dead (kept in registers) once the backward sweep starts
-    double *kap = sm + LL::okap, *rDs = sm + LL::orDs, *eta = sm + LL::oeta, *ee = sm + LL::oe;
+    double *kap = sm + LL::okap, *eta = sm + LL::oeta, *ee = sm + LL::oe;
     double *Ri = sm + LL::oRi, *ct = sm + LL::oct, *Mt = sm + LL::oMt, *Wl = sm + LL::oWl, *McL = sm + LL::oMc;
     double *SS = sm + LL::oSS, *Qsel = sm + LL::oQs, *y7 = sm + LL::oy7, *z7 = sm + LL::oz7, *w7 = sm + LL::ow7, *PiT = sm + LL::oPiT, *sT = sm + LL::osT;
     double *par = sm + LL::opar;
-    constexpr int T6N = (6 * N + WAVE - 1) / WAVE;
-    double c_r[T6N], rl_r[CH], qsel_r[CH];      // own-lane arrays (element lane + 64 t in slot t)
+    constexpr int T2N = (2 * N + WAVE - 1) / WAVE, T6N = (6 * N + WAVE - 1) / WAVE;
+    double c_r[T6N], nu_r[T6N], ru_r[T2N], rs_r[T2N], rDs_r[T2N], rl_r[CH], qsel_r[CH];      // own-lane arrays (element lane + 64 t in slot t)
     const double *Fx = par + PAR_FX, *Fu = par + PAR_FU, *bx = par + PAR_BX, *bu = par + PAR_BU, *Q2 = par + PAR_Q2, *Qf2 = par + PAR_QF2,
                  *R2 = par + PAR_R2, *dR2 = par + PAR_DR2, *T2p = par + PAR_T2, *xRef = par + PAR_XREF;
     __shared__ int st_sh;
@@ -1055,7 +1070,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     if (lane < 6) { par[PAR_T2 + lane] = p.T2[lane]; par[PAR_XREF + lane] = p.xRef[lane]; }
     if (lane == 0) { par[PAR_AS] = p.a_s; par[PAR_CS] = p.c_s; }
     __syncthreads();
-    const double a_s = par[PAR_AS], c_s = par[PAR_CS];
+    const double a_s = wave_uniform(par[PAR_AS]), c_s = wave_uniform(par[PAR_CS]);
 
     // K2: safe-set selection (k2_select), then the regression status bits of this problem's N points
     if constexpr (term) { k2_select<N, S, 1>(p, io, b, lane, 0, SS, Qsel, sel_start, &st_sh); __syncthreads(); }
@@ -1076,10 +1091,10 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     double *Cs = sm + LL::oCs;                             // C_k for the roll-out below (scratch; afterwards C lives in c_r only)
     FOR_LANES_T(i, t, 6 * N) Cs[i] = c_r[t];
     if constexpr (term) { FOR_LANES_T(c, t, S) qsel_r[t] = Qsel[c]; }
-    FOR_LANES(i, 6 * N) nu[i] = 0.0;
+    FOR_LANES_T(i, t, 6 * N) nu_r[t] = 0.0;
     if (lane < 6) x[lane] = io.x0[(size_t)b * 6 + lane];
     FOR_LANES(i, 2 * N) u[i] = 0.0;
-    const double uOld0 = io.uOld[(size_t)b * 2 + 0], uOld1 = io.uOld[(size_t)b * 2 + 1];
+    const double uOld0 = wave_uniform(io.uOld[(size_t)b * 2 + 0]), uOld1 = wave_uniform(io.uOld[(size_t)b * 2 + 1]);
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < N; k++) {                          // strictly interior start: u = 0, x by roll-out
@@ -1128,7 +1143,6 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         t_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
         if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; m[r] = mu0 / tt; }
     }
-    const ricc_consts rc = ricc_setup(lane, Q2, Fx, R2, dR2, Fu);
     double ph[N];                                          // Phi_k entry this lane multiplies with in the register sweeps
     double mcol[CH][7];                                    // this lane's columns of M = [E D^-1/2 | T7^-1/2] (column lane + 64 ch); row 6 of a
                                                            // lambda column is its scaling D^-1/2 itself
@@ -1145,11 +1159,11 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     auto kkt_solve = [&](double re_sum) {
         FOR_LANES_T(i, t, 2 * N) {                              // slack elimination, per lane row (k,j)
             const double hl = h[i], hs = h[6 * N + i];
-            const double e_ = -(rs[i] + hl + hs);
-            ee[i] = e_; eta[i] = hl + th[i] * e_ * rDs[i];
+            const double e_ = -(rs_r[t] + hl + hs);
+            ee[i] = e_; eta[i] = hl + th[i] * e_ * rDs_r[t];
         }
         FOR_LANES_T(i, t, 2 * N) {                              // gu' = ru - Fu' h_u
-            const int k = i >> 1, c = i & 1; double v = ru[i];
+            const int k = i >> 1, c = i & 1; double v = ru_r[t];
 #pragma unroll
             for (int j = 0; j < 4; j++) v -= Fu[j * 2 + c] * h[2 * N + 4 * k + j];
             gup[i] = v;
@@ -1251,7 +1265,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             const int k = i >> 1, j = i & 1; double f = 0.0;
 #pragma unroll
             for (int c = 0; c < 6; c++) f = fma(Fx[j * 6 + c], dx[k * 6 + c], f);
-            ds[i] = (th[i] * f + ee[i]) * rDs[i];
+            ds[i] = (th[i] * f + ee[i]) * rDs_r[t];
         }
         if constexpr (term) {
             {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
@@ -1279,7 +1293,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
 
     int it = 0, converged = 0, sep = 0;                   // sep: separate primal/dual step lengths after a poor-progress iteration
     double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0;
-    const double qscale = fmax(1.0, qmax);                // dual residual tolerance is relative to the cost scale
+    const double qscale = wave_uniform(fmax(1.0, qmax));                // dual residual tolerance is relative to the cost scale
 #pragma unroll 1
     for (it = 0; it <= p.max_iter; it++) {
         TSTAMP(10);
@@ -1290,10 +1304,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             const int r = lane + WAVE * j;
             if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; gsum = fma(tt, m[r], gsum); }
         }
-        if constexpr (term) {
-            ss_times<S>(SS, lam, x + N * 6, sT, lane);
-            __syncthreads();
-        }
+        if constexpr (term) ss_times<S>(SS, lam, x + N * 6, sT, lane);
+        FOR_LANES_T(i, t, 6 * N) nu[i] = nu_r[t];               // (scratch is free between the step and the factorisation)
+        __syncthreads();
         FOR_LANES(i, 6 * (N + 1)) {
             const int k = i / 6, c = i % 6; double v = 0.0;
             if (k >= 1) {
@@ -1319,9 +1332,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             for (int j = 0; j < 4; j++) v = fma(Fu[j * 2 + c], m[2 * N + 4 * k + j], v);
 #pragma unroll
             for (int j = 0; j < 6; j++) v -= AB[k * 48 + j * 8 + 6 + c] * nu[k * 6 + j];
-            ru[i] = v; rmax = fmax(rmax, fabs(v));
+            ru_r[t] = v; rmax = fmax(rmax, fabs(v));
             const double vs = a_s * s[i] + c_s - m[i] - m[6 * N + i];
-            rs[i] = vs; rmax = fmax(rmax, fabs(vs));
+            rs_r[t] = vs; rmax = fmax(rmax, fabs(vs));
         }
         double lsum = 0.0;
         if constexpr (term) {
@@ -1339,9 +1352,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             for (int j = 0; j < 6; j++) v -= AB[k * 48 + c * 8 + j] * x[k * 6 + j];
             remax = fmax(remax, fabs(v));
         }
-        gap = wsum(gsum) / (double)M;
+        gap = wave_uniform(wsum(gsum) / (double)M);
         rdn = wmax(rmax);
-        const double re_sum = term ? wsum(lsum) - 1.0 : 0.0;
+        const double re_sum = term ? wave_uniform(wsum(lsum) - 1.0) : 0.0;
         ren = fmax(wmax(remax), fabs(re_sum));
         if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res) { converged = 1; break; }
         if (gap_prev >= 0.0) sep = !EQ && gap > LMPC_SEP_THRESHOLD * gap_prev;
@@ -1356,7 +1369,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         __syncthreads();
         FOR_LANES_T(i, t, 2 * N) {
             const double d_ = frcp(a_s + th[i] + th[6 * N + i]);
-            rDs[i] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
+            rDs_r[t] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
         }
         int numeric_bad = 0;
         if constexpr (term) {
@@ -1449,14 +1462,21 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             __syncthreads();
         }
         TSTAMP(12);
-        numeric_bad |= ricc_factor<N, term>(rc, AB, kap, th, Qf2, PiT, Phi, (double *)nullptr, Mi);
+        {   // the ~40 registers of per-lane recursion constants are rebuilt every iteration instead of being carried through the whole loop
+            // (the opaque copy of `lane` keeps the compiler from hoisting them): carried, they were spilled to scratch at the loop entry
+            int l2 = lane; asm volatile("" : "+v"(l2));
+            const ricc_consts rc = ricc_setup(l2, Q2, Fx, R2, dR2, Fu);
+            numeric_bad |= ricc_factor<N, term, false, true>(rc, AB, kap, th, Qf2, PiT, Phi, (double *)nullptr, Mi, PhiK);
+        }
         // a breakdown of the factorisation once the iterate is optimal to working accuracy (gap at its floor, residuals small: the
         // barrier weights span > 1e26 there) is reported as INEXACT, not as a failure: the iterate whose residuals were just measured is returned
         if (numeric_bad) { if (lane == 0) atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_NUMERIC); break; }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < N; k++) ph[k] = (k & 1) ? Phi[k * 64 + lc * 8 + lg] : Phi[k * 64 + lg * 8 + lc];
-        FOR_LANES(i, 16 * N) PhiK[i] = Phi[(i >> 4) * 64 + 48 + (i & 15)];       // rows 6, 7 (= -K_k) outlive the scratch tiles
+        for (int k = 0; k < N; k++) {                                            // entry (r, c_) of Phi_k: rows 0..5 in the scratch tiles, rows 6, 7 (= -K_k) in PhiK
+            const int r = (k & 1) ? lc : lg, c_ = (k & 1) ? lg : lc;
+            ph[k] = r < 6 ? Phi[k * 48 + r * 8 + c_] : PhiK[k * 16 + (r - 6) * 8 + c_];
+        }
         __syncthreads();                                                         // the tiles are dead from here on: the region is reused
 
         TSTAMP(13);
@@ -1592,8 +1612,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         __syncthreads();
         TSTAMP(18);
         // ---- step ------------------------------------------------------------------------------------------
-        FOR_LANES(i, 6 * N) nu[i] = fma(ald, dnu[i], nu[i]);
-        eta_m = fma(ald, deta, eta_m);
+        FOR_LANES_T(i, t, 6 * N) nu_r[t] = fma(ald, dnu[i], nu_r[t]);
+        eta_m = wave_uniform(fma(ald, deta, eta_m));
         __syncthreads();
     }
     TSTAMP(20);
