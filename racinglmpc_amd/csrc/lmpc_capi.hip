@@ -410,7 +410,7 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
     int rc = refresh_params(c, false, term && (io.mode & 1)); if (rc) return rc;
     ev_begin(c, 1);
     // waves per QP: 4 up to one QP per CU, 2 up to mw2_max_batch (four QPs per CU at N <= 12, see create_body), beyond that the one-wave
-    // kernel, whose slim LDS layout keeps six QPs resident per CU at N = 12
+    // kernel, whose slim LDS layout keeps eight QPs resident per CU at N = 12
 #ifdef LMPC_DEV_FAST
     if (const char *f = getenv("LMPC_FORCE_NW")) {
         const int nw = atoi(f);

@@ -845,7 +845,7 @@ template <int N, int S> struct solve_lds {
 //   t2  stage recursion   : Phi_k, full 8 x 8 tiles (read back once into the sweep registers; rows 6, 7 are kept in PhiK)
 //   t3+ Newton solves ... : h / dm | dx du ds dl | gamma (= phi = dnu) | gu' | costates p | k0 | eta | e | c~ | costate right-hand sides
 // and the cost-to-go Hessians Pi_k are not stored at all (the equality multipliers follow from a backward recursion with A_k').
-// N = 12, S = 48: 24.5 KB per QP = 6 QPs per CU (the multi-wave layout above: 39.1 KB = 4).
+// N = 12, S = 48: 20.1 KB per QP = 8 QPs per CU, two waves on every SIMD (the multi-wave layout above: 39.1 KB = 4).
 // Arrays that only ever meet their own lane -- C_k (monitoring residual), the residual of the lambda rows, the lambda scalings D^-1/2
 // and the selected Q-function values -- live in registers (row or column = lane + 64 t), which is what brings the
 // footprint under 160 KB / 7.
