@@ -150,9 +150,9 @@ static int create_body(lmpc_ctx *c) {
     // safe sets wider than 58 points (numSS_points + 6 terminal columns > one per lane) exist as one-wave kernels only
     if (c->var.lds_mw == 0) { c->mw_max_batch = 0; c->mw2_max_batch = 0; }
     // Fused step (regression inside the one-wave solve kernel): bit-identical results, 42 MB less HBM traffic per step at batch 4096, but
-    // MEASURED SLOWER -- 1.37 vs 1.01 + 0.23 ms at batch 4096, 2.48 vs 1.81 + 0.44 ms at batch 8192: the regression's short dependent chains
-    // (DPP minima, 5 x 5 Cholesky, scattered L2 reads) want the four waves per SIMD its own kernel gets, and the solve's LDS footprint leaves
-    // the fused kernel 1.5.  Off unless LMPC_FUSE=1.
+    // MEASURED SLOWER -- 1.37 vs 1.01 + 0.23 ms at batch 4096, 2.48 vs 1.81 + 0.44 ms at batch 8192 with six QPs per CU; 1.92 vs 1.45 + 0.41 ms
+    // at batch 8192 with eight: the regression's short dependent chains (DPP minima, 5 x 5 Cholesky, scattered L2 reads) want the four waves
+    // per SIMD its own kernel gets, the solve kernel runs two.  Off unless LMPC_FUSE=1.
     { const char *e = getenv("LMPC_FUSE"); c->fuse_k1 = e ? atoi(e) : 0; }
     HIPCHK(hipStreamCreate(&c->stream));
     const size_t store_elems = (size_t)cfg->max_laps * LMPC_COLS * cfg->max_lap_len;

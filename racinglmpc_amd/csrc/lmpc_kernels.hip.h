@@ -939,6 +939,24 @@ __device__ __forceinline__ double ri_times(const double *Ri, const double *b, in
     return sum_over_c(v);
 }
 
+// Terminal part of a Newton solve without LDS round trips: omega' = Ri (Ri' d7 + y7), d7 = (dx_N ; -re_sum).  The forward sweep ends (for
+// even N: its last stage sums over the groups) with every lane (lg, lc) holding xi_N[lc], which is d7[lc] for lc < 6: the product with
+// Ri' is formed from that register, z7 reaches lane (lg, lc) as element lc through the LDS crossbar (ds_bpermute from the first lane of
+// group lc), and the seven results leave as wave-uniform values (v_readlane).  Same products and the same summation order as the
+// ri_t_times / ri_times pair on LDS copies, hence bit-identical; ~0.7 k cycles less per solve on the critical wave.
+__device__ __forceinline__ void term_omega(const double *Ri, const double *y7, double xiN, double re_sum, int lg, int lc, double (&w)[7]) {
+    const double b_ = lc < 6 ? xiN : (lc == 6 ? -re_sum : 0.0);
+    const bool on1 = lg < 7 && lc <= lg;
+    const double r1 = Ri[(on1 ? lc : 0) * 7 + (on1 ? lg : 0)], yv = y7[lg < 7 ? lg : 0];
+    const double zv = sum_over_c(on1 ? r1 * b_ : 0.0) + yv;                       // z7[lg], in every lane of group lg
+    const double zt = lane_gather(zv, 32 * lc);                                   // z7[lc]
+    const bool on2 = lg < 7 && lc >= lg && lc < 7;
+    const double r2 = Ri[(on2 ? lg : 0) * 7 + (on2 ? lc : 0)];
+    const double wv = sum_over_c(on2 ? r2 * zt : 0.0);                            // omega'[lg], in every lane of group lg
+#pragma unroll
+    for (int j = 0; j < 7; j++) w[j] = rdlane(wv, 8 * j);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: safe-set selection.  LMPC.addTerminalComponents :392-412 and selectPoints :478-514.  Shared by the one-wave and the
 // multi-wave solve kernels: wave `wave` of NW handles laps wave, wave + NW, ...; results go to SS (6 x S, row-major), Qsel (S),
@@ -1168,7 +1186,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             for (int j = 0; j < 4; j++) v -= Fu[j * 2 + c] * h[2 * N + 4 * k + j];
             gup[i] = v;
         }
-        double c_t[CH];
+        double c_t[CH], xiN = 0.0;                              // xiN: last stage of the forward sweep as the lanes hold it
         if constexpr (term) {
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
@@ -1258,6 +1276,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
                 const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
                 if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
             }
+            xiN = xi;
         }
         __syncthreads();
         TSTAMP(33);
@@ -1268,7 +1287,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             ds[i] = (th[i] * f + ee[i]) * rDs_r[t];
         }
         if constexpr (term) {
-            {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
+            double wq[7];
+            if constexpr ((N - 1) & 1) term_omega(Ri, y7, xiN, re_sum, lg, lc, wq);          // (even N: every lane ends the sweep with xi_N[lc])
+            else {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
                 if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;               // d7 (w7 is free until omega' is written)
                 __syncthreads();
                 const double zv = ri_t_times(Ri, w7, lg, lc) + y7[lg < 7 ? lg : 0];
@@ -1278,13 +1299,15 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
                 const double wv = ri_times(Ri, z7, lg, lc);
                 if (lc == 0 && lg < 7) w7[lg] = wv;
                 __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 7; j++) wq[j] = w7[j];
             }
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
                 const int col = lane + WAVE * ch;
                 double v = -c_t[ch];                            // v = -c~ + M' omega'
 #pragma unroll
-                for (int j = 0; j < 7; j++) v = fma(mcol[ch][j], w7[j], v);
+                for (int j = 0; j < 7; j++) v = fma(mcol[ch][j], wq[j], v);
                 if (col < S) dl[col] = v * mcol[ch][6];
             }
         }

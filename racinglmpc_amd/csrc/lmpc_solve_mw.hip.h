@@ -173,7 +173,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     //   C2  wave 0 alone: backward sweep, feed-forward terms phi_k (lane-parallel, two passes of eight stages), forward sweep
     //   C3  slack and terminal steps
     auto kkt_solve = [&](double re_sum) {
-        double c_t = 0.0;
+        double c_t = 0.0, xiN = 0.0;                            // xiN: last stage of the forward sweep as wave 0 holds it
         if (w0) {
             if constexpr (term) {
                 if (lane < S) c_t = (rl[lane] + h[8 * N + lane]) * rsq[lane];
@@ -268,6 +268,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                     const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
                     if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
                 }
+                xiN = xi;
             }
         }
         __syncthreads();                                        // C2
@@ -280,7 +281,9 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         }
         if constexpr (term) {
             if (w0) {
-                {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
+                double wq[7];
+                if constexpr ((N - 1) & 1) term_omega(Ri, y7, xiN, re_sum, lg, lc, wq);      // (even N: every lane ends the sweep with xi_N[lc])
+                else {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
                     if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;           // d7 (w7 is free until omega' is written)
                     WSYNC();
                     const double zv = ri_t_times(Ri, w7, lg, lc) + y7[lg < 7 ? lg : 0];
@@ -290,11 +293,10 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                     const double wv = ri_times(Ri, z7, lg, lc);
                     if (lc == 0 && lg < 7) w7[lg] = wv;
                     WSYNC();
+#pragma unroll
+                    for (int j = 0; j < 7; j++) wq[j] = w7[j];
                 }
                 double v = -c_t;                                // v = -c~ + M' omega'
-                double wq[7];
-#pragma unroll
-                for (int j = 0; j < 7; j++) wq[j] = w7[j];
                 const double rq = rsq[lane];
                 LDS_GROUP();
 #pragma unroll
@@ -556,6 +558,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         if (bad_sh) { if (tid == 0) atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_NUMERIC); break; }   // see lmpc_solve_kernel
         TSMW(13);
         // ---- predictor (affine scaling) direction, rest: forward sweep on wave 0, then the slack and terminal steps ----------------
+        double xiN = 0.0;
         if (w0) {
             double fm[N];
 #pragma unroll
@@ -571,6 +574,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
                 if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
             }
+            xiN = xi;
         }
         __syncthreads();
         TSMW(33);
@@ -582,7 +586,9 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         }
         if constexpr (term) {
             if (w0) {
-                {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
+                double wq[7];
+                if constexpr ((N - 1) & 1) term_omega(Ri, y7, xiN, re_sum, lg, lc, wq);      // (even N: every lane ends the sweep with xi_N[lc])
+                else {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
                     if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;           // d7 (w7 is free until omega' is written)
                     WSYNC();
                     const double zv = ri_t_times(Ri, w7, lg, lc) + y7[lg < 7 ? lg : 0];
@@ -592,11 +598,10 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                     const double wv = ri_times(Ri, z7, lg, lc);
                     if (lc == 0 && lg < 7) w7[lg] = wv;
                     WSYNC();
+#pragma unroll
+                    for (int j = 0; j < 7; j++) wq[j] = w7[j];
                 }
                 double v = -ct[lane];                           // v = -c~ + M' omega'
-                double wq[7];
-#pragma unroll
-                for (int j = 0; j < 7; j++) wq[j] = w7[j];
                 const double rq = rsq[lane];
                 LDS_GROUP();
 #pragma unroll

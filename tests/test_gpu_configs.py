@@ -252,7 +252,7 @@ def test_inexact_status_is_usable(built):
     xP, uP = g["xPID"], g["uPID"]
     for _ in range(4):
         ctx.model_add_trajectory(xP, uP); ctx.ss_add_trajectory(xP, uP)
-    seen = 0
+    seen = 0; uncert = 0
     for seed in (1, 3):
         rng = np.random.default_rng(seed)
         tb = rng.integers(0, 900, size=B)
@@ -261,17 +261,25 @@ def test_inexact_status_is_usable(built):
         out = ctx.step_batch(x0, np.stack([xP[t + 1:t + N + 2] for t in tb]), np.stack([uP[t + 1:t + N + 1] for t in tb]), uP[tb].copy(), zt=zt, timeStep=ts)
         st = out["status"]
         assert np.all((st & ~_capi.ST_INEXACT) == 0), np.unique(st, return_counts=True)
-        bad = np.nonzero(st)[0][:2]
+        bad = np.nonzero(st)[0][:4]
         if len(bad):
+            # every flagged solution carries a solver-independent KKT certificate at the level LMPC_ST_INEXACT is defined by (include/lmpc_hip.h)
+            from tests import kkt_batch
+            c = kkt_batch.certificate(par, out["A"][bad], out["B"][bad], out["C"][bad], x0[bad], uP[tb[bad]], out["xPred"][bad], out["uPred"][bad], out["slack"][bad],
+                                      out["mu"][bad], ssSel=out["ssSel"][bad], qSel=out["qSel"][bad], lambd=out["lambd"][bad], sTerm=out["sTerm"][bad])
+            assert c["worst"].max() <= 1e-5, c["worst"]
             sel = ctx.select_batch(x0[bad], zt[bad], None, None, ts[bad])
             for j, b in enumerate(bad):
                 P, q, Aq, l, u = orc.assemble_lmpc_qp(par, list(out["A"][b]), list(out["B"][b]), list(out["C"][b]), x0[b], uP[tb[b]], out["ssSel"][b].T, sel["qSel"][j])
                 ex, cert = orc.osqp_solve_exact(P, q, Aq, l, u)
-                assert cert < 1e-7
+                if cert >= 1e-7:       # these are the worst-conditioned QPs of 8192 (barrier weights over 26 decades): the oracle's own solver does not always certify
+                    uncert += 1
+                    continue
                 w = np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()])
                 assert np.abs(w - ex.x[:102]).max() < common.TOL_XU
                 seen += 1
-    print("inexact problems checked:", seen)
+    print("inexact problems compared with the oracle optimum:", seen, "; oracle could not certify:", uncert)
+    assert seen >= 1 or uncert == 0
     ctx.close()
 
 
