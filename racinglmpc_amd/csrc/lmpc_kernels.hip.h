@@ -944,10 +944,10 @@ __device__ __forceinline__ double ri_times(const double *Ri, const double *b, in
 // Ri' is formed from that register, z7 reaches lane (lg, lc) as element lc through the LDS crossbar (ds_bpermute from the first lane of
 // group lc), and the seven results leave as wave-uniform values (v_readlane).  Same products and the same summation order as the
 // ri_t_times / ri_times pair on LDS copies, hence bit-identical; ~0.7 k cycles less per solve on the critical wave.
-__device__ __forceinline__ void term_omega(const double *Ri, const double *y7, double xiN, double re_sum, int lg, int lc, double (&w)[7]) {
+__device__ __forceinline__ void term_omega(const double *Ri, double yv /* y7[lg] */, double xiN, double re_sum, int lg, int lc, double (&w)[7]) {
     const double b_ = lc < 6 ? xiN : (lc == 6 ? -re_sum : 0.0);
     const bool on1 = lg < 7 && lc <= lg;
-    const double r1 = Ri[(on1 ? lc : 0) * 7 + (on1 ? lg : 0)], yv = y7[lg < 7 ? lg : 0];
+    const double r1 = Ri[(on1 ? lc : 0) * 7 + (on1 ? lg : 0)];
     const double zv = sum_over_c(on1 ? r1 * b_ : 0.0) + yv;                       // z7[lg], in every lane of group lg
     const double zt = lane_gather(zv, 32 * lc);                                   // z7[lc]
     const bool on2 = lg < 7 && lc >= lg && lc < 7;
@@ -955,6 +955,20 @@ __device__ __forceinline__ void term_omega(const double *Ri, const double *y7, d
     const double wv = sum_over_c(on2 ? r2 * zt : 0.0);                            // omega'[lg], in every lane of group lg
 #pragma unroll
     for (int j = 0; j < 7; j++) w[j] = rdlane(wv, 8 * j);
+}
+
+// Terminal costate of a Newton solve, same scheme: enters with mc = (M c~)[lg] in every lane of group lg (the DPP sum that formed it),
+// returns [Ri (Ri' d0 + y7)][lg], d0 = (0, -re_sum), y7 = Ri' (M c~), in every lane of group lg, and y7[lg] itself for term_omega.
+__device__ __forceinline__ double term_costate(const double *Ri, double mc, double re_sum, int lg, int lc, double &yv) {
+    const bool on1 = lg < 7 && lc <= lg;
+    const double r1 = Ri[(on1 ? lc : 0) * 7 + (on1 ? lg : 0)], r6 = Ri[6 * 7 + (lg < 7 ? lg : 0)];
+    const double b1 = lane_gather(mc, 32 * lc);                                   // (M c~)[lc]
+    yv = sum_over_c(on1 ? r1 * b1 : 0.0);                                         // y7[lg]
+    const double zq = fma(r6, -re_sum, yv);
+    const double b2 = lane_gather(zq, 32 * lc);
+    const bool on2 = lg < 7 && lc >= lg && lc < 7;
+    const double r2 = Ri[(on2 ? lg : 0) * 7 + (on2 ? lc : 0)];
+    return sum_over_c(on2 ? r2 * b2 : 0.0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1186,7 +1200,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             for (int j = 0; j < 4; j++) v -= Fu[j * 2 + c] * h[2 * N + 4 * k + j];
             gup[i] = v;
         }
-        double c_t[CH], xiN = 0.0;                              // xiN: last stage of the forward sweep as the lanes hold it
+        double c_t[CH], xiN = 0.0, mc_g = 0.0, y7v = 0.0;       // xiN: last stage of the forward sweep as the lanes hold it; (M c~)[lg], y7[lg]
         if constexpr (term) {
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
@@ -1206,7 +1220,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
                 for (int c = lc; c < S; c += 8) acc = lg < 6 ? fma(SS[lg * S + c], ct[c], acc) : acc + ct[c];
             }
             acc = sum_over_c(acc);
-            if (lg < 7 && lc == 0) McL[lg] = acc;
+            mc_g = lg < 7 ? acc : 0.0;                          // (M c~)[lg] in every lane of group lg
         }
         FOR_LANES(i, 8 * N) {                                   // gamma_k = [gx' - Kx' gu' ; -Ku' gu'] = [gx';0] + Phi[6:8,:]' gu'
             const int k = i >> 3, c = i & 7;
@@ -1216,16 +1230,12 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             v = fma(PhiK[k * 16 + 8 + c], gup[2 * k + 1], v);
             gam[i] = v;
         }
-        __syncthreads();
-        {   // terminal costate p_N = (rx_N + [Ri (Ri' d0 + y7)]_{0:6}, 0), y7 = Ri' (M c~), d0 = (0, -re_sum)
+        double pN;                                              // terminal costate p_N = (rx_N + [Ri (Ri' d0 + y7)]_{0:6}, 0), element lg in every lane of group lg
+        {
             double v = 0.0;
-            if constexpr (term) {
-                const double yv = ri_t_times(Ri, McL, lg, lc);
-                if (lc == 0 && lg < 7) { y7[lg] = yv; sT[lg] = fma(Ri[6 * 7 + lg], -re_sum, yv); }      // sT: scratch for Ri' d0 + y7
-                __syncthreads();
-                v = ri_times(Ri, sT, lg, lc);
-            }
-            if (lc == 0) pst[N * 8 + lg] = lg < 6 ? rx[N * 6 + lg] + v : 0.0;
+            if constexpr (term) v = term_costate(Ri, mc_g, re_sum, lg, lc, y7v);                 // (in registers: no LDS round trip, no barrier)
+            pN = lg < 6 ? rx[N * 6 + lg] + v : 0.0;
+            if (lc == 0) pst[N * 8 + lg] = pN;                  // (k0 of the last stage reads it from LDS, two barriers from here)
         }
         __syncthreads();
         TSTAMP(30);
@@ -1235,7 +1245,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             double gm[N];
 #pragma unroll
             for (int k = 0; k < N; k++) gm[k] = (k & 1) ? gam[k * 8 + lg] : gam[k * 8 + lc];
-            double pv = ((N - 1) & 1) ? pst[N * 8 + lc] : pst[N * 8 + lg];
+            double pv = ((N - 1) & 1) ? lane_gather(pN, 32 * lc) : pN;
 #pragma unroll
             for (int k = N - 1; k >= 0; k--) {
                 double pr = ph[k] * pv;
@@ -1288,11 +1298,11 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         }
         if constexpr (term) {
             double wq[7];
-            if constexpr ((N - 1) & 1) term_omega(Ri, y7, xiN, re_sum, lg, lc, wq);          // (even N: every lane ends the sweep with xi_N[lc])
+            if constexpr ((N - 1) & 1) term_omega(Ri, y7v, xiN, re_sum, lg, lc, wq);         // (even N: every lane ends the sweep with xi_N[lc])
             else {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
                 if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;               // d7 (w7 is free until omega' is written)
                 __syncthreads();
-                const double zv = ri_t_times(Ri, w7, lg, lc) + y7[lg < 7 ? lg : 0];
+                const double zv = ri_t_times(Ri, w7, lg, lc) + y7v;
                 __syncthreads();
                 if (lc == 0 && lg < 7) z7[lg] = zv;
                 __syncthreads();

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     //   C2  wave 0 alone: backward sweep, feed-forward terms phi_k (lane-parallel, two passes of eight stages), forward sweep
     //   C3  slack and terminal steps
     auto kkt_solve = [&](double re_sum) {
-        double c_t = 0.0, xiN = 0.0;                            // xiN: last stage of the forward sweep as wave 0 holds it
+        double c_t = 0.0, xiN = 0.0, mc_g = 0.0, y7v = 0.0, pN = 0.0;   // wave 0's registers: last stage of the forward sweep, (M c~)[lg], y7[lg], p_N[lg]
         if (w0) {
             if constexpr (term) {
                 if (lane < S) c_t = (rl[lane] + h[8 * N + lane]) * rsq[lane];
@@ -190,18 +190,13 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                     acc = lg < 7 ? acc : 0.0;
                 }
                 acc = sum_over_c(acc);
-                if (lg < 7 && lc == 0) McL[lg] = acc;
-                WSYNC();
+                mc_g = acc;                                     // (M c~)[lg] in every lane of group lg
             }
-            {   // terminal costate p_N = (rx_N + [Ri (Ri' d0 + y7)]_{0:6}, 0), y7 = Ri' (M c~) (ri_t_times / ri_times: lmpc_kernels.hip.h)
+            {   // terminal costate p_N = (rx_N + [Ri (Ri' d0 + y7)]_{0:6}, 0), y7 = Ri' (M c~), in registers (term_costate: lmpc_kernels.hip.h)
                 double v = 0.0;
-                if constexpr (term) {
-                    const double yv = ri_t_times(Ri, McL, lg, lc);
-                    if (lc == 0 && lg < 7) { y7[lg] = yv; z7[lg] = fma(Ri[6 * 7 + lg], -re_sum, yv); }   // z7 is free until the forward sweep has finished
-                    WSYNC();
-                    v = ri_times(Ri, z7, lg, lc);
-                }
-                if (lc == 0) pst[N * 8 + lg] = lg < 6 ? rx[N * 6 + lg] + v : 0.0;
+                if constexpr (term) v = term_costate(Ri, mc_g, re_sum, lg, lc, y7v);
+                pN = lg < 6 ? rx[N * 6 + lg] + v : 0.0;
+                if (lc == 0) pst[N * 8 + lg] = pN;              // (the phi pass reads it from LDS)
             }
             if (lane < 6) dx[lane] = 0.0;
         } else {
@@ -228,7 +223,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 double gm[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) gm[k] = (k & 1) ? gam[k * 8 + lg] : gam[k * 8 + lc];
-                double pv = ((N - 1) & 1) ? pst[N * 8 + lc] : pst[N * 8 + lg];
+                double pv = ((N - 1) & 1) ? lane_gather(pN, 32 * lc) : pN;
                 LDS_GROUP();
 #pragma unroll
                 for (int k = N - 1; k >= 0; k--) {
@@ -282,11 +277,11 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         if constexpr (term) {
             if (w0) {
                 double wq[7];
-                if constexpr ((N - 1) & 1) term_omega(Ri, y7, xiN, re_sum, lg, lc, wq);      // (even N: every lane ends the sweep with xi_N[lc])
+                if constexpr ((N - 1) & 1) term_omega(Ri, y7v, xiN, re_sum, lg, lc, wq);     // (even N: every lane ends the sweep with xi_N[lc])
                 else {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
                     if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;           // d7 (w7 is free until omega' is written)
                     WSYNC();
-                    const double zv = ri_t_times(Ri, w7, lg, lc) + y7[lg < 7 ? lg : 0];
+                    const double zv = ri_t_times(Ri, w7, lg, lc) + y7v;
                     WSYNC();
                     if (lc == 0 && lg < 7) z7[lg] = zv;
                     WSYNC();
@@ -587,7 +582,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         if constexpr (term) {
             if (w0) {
                 double wq[7];
-                if constexpr ((N - 1) & 1) term_omega(Ri, y7, xiN, re_sum, lg, lc, wq);      // (even N: every lane ends the sweep with xi_N[lc])
+                if constexpr ((N - 1) & 1) term_omega(Ri, y7[lg < 7 ? lg : 0], xiN, re_sum, lg, lc, wq);   // (y7: wave 1's, from step 0 of the pipeline)
                 else {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
                     if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;           // d7 (w7 is free until omega' is written)
                     WSYNC();
