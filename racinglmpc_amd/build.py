@@ -10,7 +10,7 @@ VSRC = os.path.join(_HERE, "csrc", "lmpc_variant.hip")
 # (N, numSS_points) pairs compiled into liblmpc_hip.so itself (lmpc_capi.hip: builtin_variant) and the extra ones build() prepares as
 # shared objects of their own, in parallel; anything else is built the first time a Context asks for it
 BUILTIN = {(n, s) for n in (8, 12, 14, 20, 40) for s in (0, 48)}
-EXTRA_VARIANTS = [(10, 48), (16, 48), (24, 48), (30, 48), (12, 24), (12, 36), (16, 36), (10, 0), (16, 0), (12, 60), (12, 96), (14, 160)]
+EXTRA_VARIANTS = [(10, 48), (16, 48), (24, 48), (30, 48), (12, 24), (12, 36), (16, 36), (10, 0), (16, 0), (12, 60), (12, 72), (12, 96), (14, 160)]
 OUT = os.path.join(_HERE, "liblmpc_hip.so")
 
 

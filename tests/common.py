@@ -20,6 +20,11 @@ def load_lmpc_golden():
     return np.load(os.path.join(GOLDEN, "lmpc_n12.npz"))
 
 
+def load_wide_golden():
+    """Reference-executed LMPC steps with numSS_it = 6, numSS_Points = 72 (tests/golden/make_wide_golden.py)."""
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "lmpc_wide_n12.npz")))
+
+
 def load_ltv_golden():
     return np.load(os.path.join(GOLDEN, "ltvmpc_n12.npz"))
 

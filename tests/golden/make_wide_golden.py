@@ -1,0 +1,90 @@
+"""tests/golden/make_wide_golden.py -- fixture for a safe set WIDER than one wavefront (numSS_it = 6, numSS_Points = 72: 72 + 6 terminal
+columns > 64 lanes), produced by EXECUTING the reference's LMPC class exactly as tests/golden/make_golden.py does (same stand-ins for
+cvxopt.qp / osqp.OSQP, same NumPy>=2 fix).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_wide_golden.py          (needs /root/reference)
+
+main.py:100-110 with numSS_it = 6 (initControllerParameters.py:43-44 sets numSS_Points = 12 numSS_it): six copies of the PID lap in the
+safe set, four in the regression store, then a few closed-loop steps (plant = the reference's Simulator.dynModel, driven with the certified
+optimum's first input).  No addPoint between the steps, so the stores stay what they were after the first solve (whose addTerminalComponents
+edits one entry of lap 0 in place through the xLin view, reference quirk E-2: every lap is handed over as its own copy here, so only SS[0]
+is touched).  Per step: the controller's inputs, the reference's own A, B, C, selection (SS, Qfun, successors), assembled QP, and the
+certified optimum of that QP.  Output: tests/golden/lmpc_wide_n12.npz.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402
+from oracle import lmpc_oracle as orc  # noqa: E402
+
+
+def main():
+    mg.install_standins()
+    PC, ICP, PM, SM, TR, UT = mg.load_reference()
+    N, n, d = 12, 6, 2
+    numSS_it, numSS_Points = 6, 72
+    x0 = np.array([0.5, 0, 0, 0, 0, 0]); xS = [x0, x0]
+    np.random.seed(0)
+    map_ = TR.Map(0.4)
+    simulator = SM.Simulator(map_)
+    xPID, uPID, xPID_glob, _ = simulator.sim(xS, UT.PID(0.8))
+    _it, _pts, Laps, TimeLMPC, QterminalSlack, lmpcParameters = ICP.initLMPCParams(map_, N)
+    lmpcParameters.timeVarying = True
+    pm = PM.PredictiveModel(n, d, map_, 4)
+    for i in range(4):
+        pm.addTrajectory(xPID.copy(), uPID.copy())
+    lmpc = PC.LMPC(numSS_Points, numSS_it, QterminalSlack, lmpcParameters, pm)
+    for i in range(numSS_it):
+        lmpc.addTrajectory(xPID.copy(), uPID.copy(), xPID_glob.copy())
+    recs = []
+    np.random.seed(3)
+    # start 40 steps into the lap (the car is moving; the first windows are centred, not clipped at row 0)
+    t0 = 40
+    xc, xg = xPID[t0].copy(), xPID_glob[t0].copy()
+    lmpc.xLin = xPID[t0 + 1:t0 + N + 2].copy(); lmpc.uLin = uPID[t0 + 1:t0 + N + 1].copy()
+    lmpc.zt = xPID[t0 + N + 1].copy(); lmpc.OldInput = uPID[t0 - 1].copy(); lmpc.timeStep = t0
+    for t in range(12):
+        xpp = None if isinstance(lmpc.xPred, list) else lmpc.xPred.copy()
+        rec = dict(t=lmpc.timeStep, x0=xc.copy(), xLin=np.array(lmpc.xLin).copy(), uLin=np.array(lmpc.uLin).copy(),
+                   OldInput=np.array(lmpc.OldInput, float).reshape(-1).copy(), zt=np.array(lmpc.zt).copy(),
+                   hasPred=0 if xpp is None else 1, xPredPrev=np.zeros((N + 1, n)) if xpp is None else xpp)
+        mg.CAPTURE.clear()
+        lmpc.solve(xc)
+        P, q, A, l, u, sol, y, status, it_, sp = mg.CAPTURE[-1]
+        rec.update(A=np.array(lmpc.A), B=np.array(lmpc.B), C=np.array(lmpc.C),
+                   SSsel=lmpc.SS_PointSelectedTot.copy(), Qsel=lmpc.Qfun_SelectedTot.copy(),
+                   Succ=lmpc.Succ_SS_PointSelectedTot.copy(), SuccU=lmpc.Succ_uSS_PointSelectedTot.copy(),
+                   q=q, l=l, u=u, sol=sol, status=status)
+        rec["Pp"], rec["Pi"], rec["Px"] = mg.csc_parts(P)
+        rec["Ap"], rec["Ai"], rec["Ax"] = mg.csc_parts(A)
+        ex, cert = orc.osqp_solve_exact(P, q, A, l, u)
+        rec["sol_opt"], rec["y_opt"], rec["cert_opt"] = ex.x, ex.y, cert
+        recs.append(rec)
+        # continue from the certified optimum (the restated OSQP's eps = 1e-3 answer is what the reference flow would carry on with;
+        # the optimum keeps the recorded inputs of the next step independent of that solver)
+        xo = ex.x[:n * (N + 1)].reshape(N + 1, n); uo = ex.x[n * (N + 1):n * (N + 1) + d * N].reshape(N, d)
+        lam = ex.x[n * (N + 1) + d * N + 2 * N:n * (N + 1) + d * N + 2 * N + numSS_Points]
+        lmpc.xPred, lmpc.uPred = xo.copy(), uo.copy()
+        lmpc.zt = np.dot(lmpc.Succ_SS_PointSelectedTot, lam); lmpc.zt_u = np.dot(lmpc.Succ_uSS_PointSelectedTot, lam)
+        lmpc.xLin = np.vstack((xo[1:, :], lmpc.zt)); lmpc.uLin = np.vstack((uo[1:, :], lmpc.zt_u)); lmpc.OldInput = uo[0, :].copy()
+        xc, xg = simulator.dynModel(xc, xg, uo[0, :].copy())
+    out = {k: mg.stack([r[k] for r in recs]) for k in recs[0].keys()}
+    out.update(xPID=xPID.copy(), uPID=uPID.copy(), track=map_.PointAndTangent.copy(), trackLength=map_.TrackLength,
+               numSS_it=numSS_it, numSS_Points=numSS_Points, nSS=len(lmpc.SS))
+    for l_, (S, U, Qf) in enumerate(zip(lmpc.SS, lmpc.uSS, lmpc.Qfun)):
+        out["SS%d" % l_] = S.copy(); out["uSS%d" % l_] = U.copy(); out["Qfun%d" % l_] = Qf.copy()
+    np.savez_compressed(os.path.join(HERE, "lmpc_wide_n12.npz"), **out)
+    nact = [int(np.sum(r["sol_opt"][n * (N + 1) + d * N + 2 * N:n * (N + 1) + d * N + 2 * N + numSS_Points] > 1e-6)) for r in recs]
+    print("wide-safe-set fixture: %d steps, nz = %d, m = %d, certificates <= %.1e, lambdas above 1e-6 per step: %s" % (
+        len(recs), out["q"].shape[1], out["l"].shape[1], out["cert_opt"].max(), nact))
+    for root, dirs, files in os.walk(mg.REF):
+        assert "__pycache__" not in dirs, "reference tree was written to"
+
+
+if __name__ == "__main__":
+    main()

@@ -99,6 +99,56 @@ def test_full_step_matches_reference_path(g):
     assert res["max_err_xu"] < common.TOL_XU
 
 
+def test_wide_safe_set_matches_reference(built):
+    """numSS_it = 6, numSS_Points = 72 -- more terminal-block columns (78) than a wavefront has lanes -- on the steps recorded from the
+    EXECUTED reference (tests/golden/make_wide_golden.py): selection of the six laps bit-exact (SS, Q-function with its shift, successor
+    rows), A, B, C within the regression tolerance, explicit QP matrices bit-exact, xPred / uPred at the certified optimum of the reference's
+    own QP, and zt / zt_u of feasibleStateInput.  Runs on the one-wave kernel (several columns per lane) at every batch size."""
+    from racinglmpc_amd import _capi
+    g = common.load_wide_golden()
+    S, L = int(g["numSS_Points"]), int(g["numSS_it"])
+    gl = common.load_lmpc_golden()
+    cfg, par = common.lmpc_config(gl, 12, max_batch=16, numSS_it=L, numSS_Points=S)
+    ctx = _capi.Context(cfg)
+    assert ctx.S == S and ctx.solver_waves(1) == 1
+    for _ in range(4):
+        ctx.model_add_trajectory(g["xPID"], g["uPID"])
+    for l in range(L):
+        ctx.ss_add_trajectory(g["xPID"], g["uPID"])
+        ctx.ss_replace_lap(l, g["SS%d" % l], g["uSS%d" % l], g["Qfun%d" % l])       # lap 0 carries the in-place edit of quirk E-2
+    R = g["x0"].shape[0]
+    out = ctx.step_batch(g["x0"], g["xLin"], g["uLin"], g["OldInput"], zt=g["zt"], xPredPrev=g["xPredPrev"], hasPred=g["hasPred"].astype(np.int32),
+                         timeStep=g["t"].astype(np.int32))
+    assert np.all(out["status"] == 0), out["status"]
+    assert np.array_equal(out["ssSel"], np.transpose(g["SSsel"], (0, 2, 1))) and np.array_equal(out["qSel"], g["Qsel"])
+    for got, ref in ((out["A"], g["A"]), (out["B"], g["B"]), (out["C"], g["C"])):
+        assert (np.abs(got - ref) / (1 + np.abs(ref))).max() < common.TOL_ABC
+    sel = ctx.select_batch(g["x0"], g["zt"], g["xPredPrev"], g["hasPred"].astype(np.int32), g["t"].astype(np.int32))
+    assert np.array_equal(sel["succ"], np.transpose(g["Succ"], (0, 2, 1))) and np.array_equal(sel["succU"], np.transpose(g["SuccU"], (0, 2, 1)))
+    P, q, A, l, u = ctx.assemble_batch(g["A"], g["B"], g["C"], g["x0"], g["OldInput"], np.transpose(g["SSsel"], (0, 2, 1)), g["Qsel"])
+    worst = 0.0
+    nxu = 6 * 13 + 2 * 12
+    for r in range(R):
+        Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="")
+        assert np.array_equal(P[r], Pr) and np.array_equal(A[r], Ar) and np.array_equal(q[r], qr) and np.array_equal(l[r], lr) and np.array_equal(u[r], ur)
+        w = np.concatenate([out["xPred"][r].ravel(), out["uPred"][r].ravel()])
+        worst = max(worst, np.abs(w - g["sol_opt"][r][:nxu]).max())
+        lam = g["sol_opt"][r][nxu + 24:nxu + 24 + S]
+        assert np.abs(out["ztNext"][r] - g["Succ"][r] @ lam).max() < 1e-5 and np.abs(out["ztuNext"][r] - g["SuccU"][r] @ lam).max() < 1e-5
+    # the QP solve alone on the reference's own A, B, C and selection
+    out2 = ctx.qp_solve_batch(g["A"], g["B"], g["C"], g["x0"], g["OldInput"], np.transpose(g["SSsel"], (0, 2, 1)), g["Qsel"])
+    assert np.all(out2["status"] == 0)
+    for r in range(R):
+        w = np.concatenate([out2["xPred"][r].ravel(), out2["uPred"][r].ravel(), out2["slack"][r], out2["lambd"][r], out2["sTerm"][r]])
+        worst = max(worst, np.abs(w[:nxu] - g["sol_opt"][r][:nxu]).max())
+        Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="")
+        c = common.certificate(Pr, qr, Ar, lr, ur, w, out2["mu"][r], 8 * 12 + S)
+        assert max(c.values()) < common.TOL_KKT
+    print("wide safe set (%d points from %d laps): worst |xu - certified optimum| %.2e, IPM iterations max %d" % (S, L, worst, out["iters"].max()))
+    assert worst < common.TOL_XU
+    ctx.close()
+
+
 def test_ltv_mpc_variant(built):
     """No terminal set (MPC class, timeVarying=True, main.py:86-94): regression + QP vs the reference-executed fixture."""
     from racinglmpc_amd import _capi

@@ -134,3 +134,29 @@ def test_oracle_noslack_assembly_matches_reference():
         assert np.array_equal(P, P2) and np.array_equal(q, q2) and np.array_equal(A, A2) and np.array_equal(l, l2) and np.array_equal(u, u2)
         assert P.shape == (102, 102) and A.shape == (72 + 78, 102)
         assert max(orc.kkt_certificate(P, q, A, l, u, g["sol_opt"][r], g["y_opt"][r]).values()) < 1e-9
+
+
+def test_wide_safe_set_restatement_matches_reference():
+    """numSS_it = 6, numSS_Points = 72 (more terminal columns than lanes of a wavefront), recorded from the executed reference
+    (tests/golden/make_wide_golden.py): regression, selection of six laps with successors and Q-function shift, assembled QP."""
+    g = common.load_wide_golden()
+    par = orc.QPParams.lmpc_default(12)
+    par.numSS_Points, par.numSS_it = int(g["numSS_Points"]), int(g["numSS_it"])
+    TL = float(g["trackLength"]); L = int(g["nSS"])
+    SS = [g["SS%d" % i] for i in range(L)]; uSS = [g["uSS%d" % i] for i in range(L)]; Qf = [g["Qfun%d" % i] for i in range(L)]
+    for r in range(g["x0"].shape[0]):
+        A, B, C = orc.compute_ltv_dynamics([g["xPID"]] * 4, [g["uPID"]] * 4, [0, 1, 2, 3], g["track"], g["xLin"][r], g["uLin"][r], 12)
+        for got, ref in ((A, g["A"][r]), (B, g["B"][r]), (C, g["C"][r])):
+            assert (np.abs(got - ref) / (1 + np.abs(ref))).max() < 1e-10
+        zt = g["zt"][r].copy()
+        if zt[4] - g["x0"][r][4] > TL / 2:
+            zt[4] = np.max([zt[4] - TL, 0])
+        xpp = g["xPredPrev"][r] if g["hasPred"][r] else None
+        SSsel, Qsel, Succ, SuccU = orc.terminal_components(SS, uSS, Qf, [s_.shape[0] for s_ in SS], zt, par.numSS_Points, par.numSS_it, xpp, L,
+                                                           int(g["t"][r]), 12, TL)
+        assert np.array_equal(SSsel, g["SSsel"][r]) and np.array_equal(Qsel, g["Qsel"][r])
+        assert np.array_equal(Succ, g["Succ"][r]) and np.array_equal(SuccU, g["SuccU"][r])
+        P, q, Aq, l, u = orc.assemble_lmpc_qp(par, g["A"][r], g["B"][r], g["C"][r], g["x0"][r], g["OldInput"][r], SSsel, Qsel)
+        Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="")
+        assert np.array_equal(P, Pr) and np.array_equal(q, qr) and np.array_equal(Aq, Ar) and np.array_equal(l, lr) and np.array_equal(u, ur)
+        assert g["cert_opt"][r] < 1e-8
