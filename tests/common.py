@@ -20,9 +20,13 @@ def load_lmpc_golden():
     return np.load(os.path.join(GOLDEN, "lmpc_n12.npz"))
 
 
-def load_wide_golden():
-    """Reference-executed LMPC steps with numSS_it = 6, numSS_Points = 72 (tests/golden/make_wide_golden.py)."""
-    return dict(np.load(os.path.join(ROOT, "tests", "golden", "lmpc_wide_n12.npz")))
+def load_variant_golden(name):
+    """Reference-executed LMPC steps of another configuration (tests/golden/make_wide_golden.py): "lmpc_wide_n12" (numSS_it = 6, numSS_Points = 72)
+    or "lmpc_n14" (main.py's horizon).  The safe set is numSS_it copies of the PID lap, lap 0 as the reference left it (SS0)."""
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz")))
+    L = int(g["nSS"])
+    g["SS"] = [g["SS0"]] + [g["xPID"]] * (L - 1); g["uSS"] = [g["uPID"]] * L; g["Qf"] = [g["Qfun"]] * L
+    return g
 
 
 def load_ltv_golden():

@@ -1,6 +1,8 @@
-"""tests/golden/make_wide_golden.py -- fixture for a safe set WIDER than one wavefront (numSS_it = 6, numSS_Points = 72: 72 + 6 terminal
-columns > 64 lanes), produced by EXECUTING the reference's LMPC class exactly as tests/golden/make_golden.py does (same stand-ins for
-cvxopt.qp / osqp.OSQP, same NumPy>=2 fix).
+"""tests/golden/make_wide_golden.py -- fixtures for LMPC configurations other than lmpc_n12.npz's, produced by EXECUTING the reference's LMPC
+class exactly as tests/golden/make_golden.py does (same stand-ins for cvxopt.qp / osqp.OSQP, same NumPy>=2 fix):
+
+  lmpc_wide_n12.npz   N = 12, numSS_it = 6, numSS_Points = 72: a safe set WIDER than one wavefront (72 + 6 terminal columns > 64 lanes)
+  lmpc_n14.npz        N = 14, numSS_it = 4, numSS_Points = 48: the horizon main.py itself uses (main.py:43)
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_wide_golden.py          (needs /root/reference)
 
@@ -8,8 +10,8 @@ main.py:100-110 with numSS_it = 6 (initControllerParameters.py:43-44 sets numSS_
 safe set, four in the regression store, then a few closed-loop steps (plant = the reference's Simulator.dynModel, driven with the certified
 optimum's first input).  No addPoint between the steps, so the stores stay what they were after the first solve (whose addTerminalComponents
 edits one entry of lap 0 in place through the xLin view, reference quirk E-2: every lap is handed over as its own copy here, so only SS[0]
-is touched).  Per step: the controller's inputs, the reference's own A, B, C, selection (SS, Qfun, successors), assembled QP, and the
-certified optimum of that QP.  Output: tests/golden/lmpc_wide_n12.npz.
+is touched; the fixture keeps SS0 and asserts that the other laps still equal the PID lap).  Per step: the controller's inputs, the
+reference's own A, B, C, selection (SS, Qfun, successors), assembled QP, and the certified optimum of that QP.
 """
 import os
 import sys
@@ -23,11 +25,9 @@ import make_golden as mg  # noqa: E402
 from oracle import lmpc_oracle as orc  # noqa: E402
 
 
-def main():
-    mg.install_standins()
-    PC, ICP, PM, SM, TR, UT = mg.load_reference()
-    N, n, d = 12, 6, 2
-    numSS_it, numSS_Points = 6, 72
+def make(PC, ICP, PM, SM, TR, UT, N, numSS_it, fname):
+    n, d = 6, 2
+    numSS_Points = 12 * numSS_it                           # initControllerParameters.py:43-44
     x0 = np.array([0.5, 0, 0, 0, 0, 0]); xS = [x0, x0]
     np.random.seed(0)
     map_ = TR.Map(0.4)
@@ -76,12 +76,22 @@ def main():
     out = {k: mg.stack([r[k] for r in recs]) for k in recs[0].keys()}
     out.update(xPID=xPID.copy(), uPID=uPID.copy(), track=map_.PointAndTangent.copy(), trackLength=map_.TrackLength,
                numSS_it=numSS_it, numSS_Points=numSS_Points, nSS=len(lmpc.SS))
-    for l_, (S, U, Qf) in enumerate(zip(lmpc.SS, lmpc.uSS, lmpc.Qfun)):
-        out["SS%d" % l_] = S.copy(); out["uSS%d" % l_] = U.copy(); out["Qfun%d" % l_] = Qf.copy()
-    np.savez_compressed(os.path.join(HERE, "lmpc_wide_n12.npz"), **out)
+    out["N"] = N
+    out["SS0"] = lmpc.SS[0].copy(); out["Qfun"] = lmpc.Qfun[0].copy()                   # (lap 0: edited in place by the first solve, quirk E-2)
+    assert int(np.sum(lmpc.SS[0] != xPID)) <= 1                                         # (here the first solve does not trigger the edit: zt starts next to x0)
+    for l_ in range(len(lmpc.SS)):
+        assert np.array_equal(lmpc.uSS[l_], uPID) and np.array_equal(lmpc.Qfun[l_], lmpc.Qfun[0]) and (l_ == 0 or np.array_equal(lmpc.SS[l_], xPID))
+    np.savez_compressed(os.path.join(HERE, fname), **out)
     nact = [int(np.sum(r["sol_opt"][n * (N + 1) + d * N + 2 * N:n * (N + 1) + d * N + 2 * N + numSS_Points] > 1e-6)) for r in recs]
-    print("wide-safe-set fixture: %d steps, nz = %d, m = %d, certificates <= %.1e, lambdas above 1e-6 per step: %s" % (
+    print(fname + ": %d steps, nz = %d, m = %d, certificates <= %.1e, lambdas above 1e-6 per step: %s" % (
         len(recs), out["q"].shape[1], out["l"].shape[1], out["cert_opt"].max(), nact))
+
+
+def main():
+    mg.install_standins()
+    ref = mg.load_reference()
+    make(*ref, 12, 6, "lmpc_wide_n12.npz")
+    make(*ref, 14, 4, "lmpc_n14.npz")
     for root, dirs, files in os.walk(mg.REF):
         assert "__pycache__" not in dirs, "reference tree was written to"
 

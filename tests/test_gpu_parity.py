@@ -99,23 +99,25 @@ def test_full_step_matches_reference_path(g):
     assert res["max_err_xu"] < common.TOL_XU
 
 
-def test_wide_safe_set_matches_reference(built):
-    """numSS_it = 6, numSS_Points = 72 -- more terminal-block columns (78) than a wavefront has lanes -- on the steps recorded from the
-    EXECUTED reference (tests/golden/make_wide_golden.py): selection of the six laps bit-exact (SS, Q-function with its shift, successor
-    rows), A, B, C within the regression tolerance, explicit QP matrices bit-exact, xPred / uPred at the certified optimum of the reference's
-    own QP, and zt / zt_u of feasibleStateInput.  Runs on the one-wave kernel (several columns per lane) at every batch size."""
+@pytest.mark.parametrize("name", ["lmpc_wide_n12", "lmpc_n14"])
+def test_other_configurations_match_reference(built, name):
+    """Steps recorded from the EXECUTED reference in two more configurations (tests/golden/make_wide_golden.py): numSS_it = 6, numSS_Points = 72
+    -- more terminal-block columns (78) than a wavefront has lanes: the one-wave kernel with several columns per lane at every batch size --
+    and main.py's own horizon N = 14.  Selection bit-exact (SS, Q-function with its shift, successor rows), A, B, C within the regression
+    tolerance, explicit QP matrices bit-exact, xPred / uPred at the certified optimum of the reference's own QP, zt / zt_u of
+    feasibleStateInput."""
     from racinglmpc_amd import _capi
-    g = common.load_wide_golden()
-    S, L = int(g["numSS_Points"]), int(g["numSS_it"])
+    g = common.load_variant_golden(name)
+    N, S, L = int(g["N"]), int(g["numSS_Points"]), int(g["numSS_it"])
     gl = common.load_lmpc_golden()
-    cfg, par = common.lmpc_config(gl, 12, max_batch=16, numSS_it=L, numSS_Points=S)
+    cfg, par = common.lmpc_config(gl, N, max_batch=16, numSS_it=L, numSS_Points=S)
     ctx = _capi.Context(cfg)
-    assert ctx.S == S and ctx.solver_waves(1) == 1
+    assert ctx.S == S and (ctx.solver_waves(1) == 1) == (S + 6 > 64)
     for _ in range(4):
         ctx.model_add_trajectory(g["xPID"], g["uPID"])
     for l in range(L):
         ctx.ss_add_trajectory(g["xPID"], g["uPID"])
-        ctx.ss_replace_lap(l, g["SS%d" % l], g["uSS%d" % l], g["Qfun%d" % l])       # lap 0 carries the in-place edit of quirk E-2
+        ctx.ss_replace_lap(l, g["SS"][l], g["uSS"][l], g["Qf"][l])
     R = g["x0"].shape[0]
     out = ctx.step_batch(g["x0"], g["xLin"], g["uLin"], g["OldInput"], zt=g["zt"], xPredPrev=g["xPredPrev"], hasPred=g["hasPred"].astype(np.int32),
                          timeStep=g["t"].astype(np.int32))
@@ -127,13 +129,13 @@ def test_wide_safe_set_matches_reference(built):
     assert np.array_equal(sel["succ"], np.transpose(g["Succ"], (0, 2, 1))) and np.array_equal(sel["succU"], np.transpose(g["SuccU"], (0, 2, 1)))
     P, q, A, l, u = ctx.assemble_batch(g["A"], g["B"], g["C"], g["x0"], g["OldInput"], np.transpose(g["SSsel"], (0, 2, 1)), g["Qsel"])
     worst = 0.0
-    nxu = 6 * 13 + 2 * 12
+    nxu = 6 * (N + 1) + 2 * N
     for r in range(R):
         Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="")
         assert np.array_equal(P[r], Pr) and np.array_equal(A[r], Ar) and np.array_equal(q[r], qr) and np.array_equal(l[r], lr) and np.array_equal(u[r], ur)
         w = np.concatenate([out["xPred"][r].ravel(), out["uPred"][r].ravel()])
         worst = max(worst, np.abs(w - g["sol_opt"][r][:nxu]).max())
-        lam = g["sol_opt"][r][nxu + 24:nxu + 24 + S]
+        lam = g["sol_opt"][r][nxu + 2 * N:nxu + 2 * N + S]
         assert np.abs(out["ztNext"][r] - g["Succ"][r] @ lam).max() < 1e-5 and np.abs(out["ztuNext"][r] - g["SuccU"][r] @ lam).max() < 1e-5
     # the QP solve alone on the reference's own A, B, C and selection
     out2 = ctx.qp_solve_batch(g["A"], g["B"], g["C"], g["x0"], g["OldInput"], np.transpose(g["SSsel"], (0, 2, 1)), g["Qsel"])
@@ -142,9 +144,9 @@ def test_wide_safe_set_matches_reference(built):
         w = np.concatenate([out2["xPred"][r].ravel(), out2["uPred"][r].ravel(), out2["slack"][r], out2["lambd"][r], out2["sTerm"][r]])
         worst = max(worst, np.abs(w[:nxu] - g["sol_opt"][r][:nxu]).max())
         Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="")
-        c = common.certificate(Pr, qr, Ar, lr, ur, w, out2["mu"][r], 8 * 12 + S)
+        c = common.certificate(Pr, qr, Ar, lr, ur, w, out2["mu"][r], 8 * N + S)
         assert max(c.values()) < common.TOL_KKT
-    print("wide safe set (%d points from %d laps): worst |xu - certified optimum| %.2e, IPM iterations max %d" % (S, L, worst, out["iters"].max()))
+    print("%s (N = %d, %d points from %d laps): worst |xu - certified optimum| %.2e, IPM iterations max %d" % (name, N, S, L, worst, out["iters"].max()))
     assert worst < common.TOL_XU
     ctx.close()
 

@@ -136,16 +136,18 @@ def test_oracle_noslack_assembly_matches_reference():
         assert max(orc.kkt_certificate(P, q, A, l, u, g["sol_opt"][r], g["y_opt"][r]).values()) < 1e-9
 
 
-def test_wide_safe_set_restatement_matches_reference():
-    """numSS_it = 6, numSS_Points = 72 (more terminal columns than lanes of a wavefront), recorded from the executed reference
-    (tests/golden/make_wide_golden.py): regression, selection of six laps with successors and Q-function shift, assembled QP."""
-    g = common.load_wide_golden()
-    par = orc.QPParams.lmpc_default(12)
+@pytest.mark.parametrize("name", ["lmpc_wide_n12", "lmpc_n14"])
+def test_other_configurations_restatement_matches_reference(name):
+    """Fixtures recorded from the executed reference (tests/golden/make_wide_golden.py): numSS_it = 6, numSS_Points = 72 (more terminal columns
+    than lanes of a wavefront) and main.py's own horizon N = 14: regression, selection with successors and Q-function shift, assembled QP."""
+    g = common.load_variant_golden(name)
+    N = int(g["N"])
+    par = orc.QPParams.lmpc_default(N)
     par.numSS_Points, par.numSS_it = int(g["numSS_Points"]), int(g["numSS_it"])
     TL = float(g["trackLength"]); L = int(g["nSS"])
-    SS = [g["SS%d" % i] for i in range(L)]; uSS = [g["uSS%d" % i] for i in range(L)]; Qf = [g["Qfun%d" % i] for i in range(L)]
+    SS, uSS, Qf = g["SS"], g["uSS"], g["Qf"]
     for r in range(g["x0"].shape[0]):
-        A, B, C = orc.compute_ltv_dynamics([g["xPID"]] * 4, [g["uPID"]] * 4, [0, 1, 2, 3], g["track"], g["xLin"][r], g["uLin"][r], 12)
+        A, B, C = orc.compute_ltv_dynamics([g["xPID"]] * 4, [g["uPID"]] * 4, [0, 1, 2, 3], g["track"], g["xLin"][r], g["uLin"][r], N)
         for got, ref in ((A, g["A"][r]), (B, g["B"][r]), (C, g["C"][r])):
             assert (np.abs(got - ref) / (1 + np.abs(ref))).max() < 1e-10
         zt = g["zt"][r].copy()
@@ -153,7 +155,7 @@ def test_wide_safe_set_restatement_matches_reference():
             zt[4] = np.max([zt[4] - TL, 0])
         xpp = g["xPredPrev"][r] if g["hasPred"][r] else None
         SSsel, Qsel, Succ, SuccU = orc.terminal_components(SS, uSS, Qf, [s_.shape[0] for s_ in SS], zt, par.numSS_Points, par.numSS_it, xpp, L,
-                                                           int(g["t"][r]), 12, TL)
+                                                           int(g["t"][r]), N, TL)
         assert np.array_equal(SSsel, g["SSsel"][r]) and np.array_equal(Qsel, g["Qsel"][r])
         assert np.array_equal(Succ, g["Succ"][r]) and np.array_equal(SuccU, g["SuccU"][r])
         P, q, Aq, l, u = orc.assemble_lmpc_qp(par, g["A"][r], g["B"][r], g["C"][r], g["x0"][r], g["OldInput"][r], SSsel, Qsel)
