@@ -3,6 +3,7 @@ class exactly as tests/golden/make_golden.py does (same stand-ins for cvxopt.qp 
 
   lmpc_wide_n12.npz   N = 12, numSS_it = 6, numSS_Points = 72: a safe set WIDER than one wavefront (72 + 6 terminal columns > 64 lanes)
   lmpc_n14.npz        N = 14, numSS_it = 4, numSS_Points = 48: the horizon main.py itself uses (main.py:43)
+  lmpc_n40.npz        N = 40, numSS_it = 4, numSS_Points = 48: BASELINE.json configs[4]'s horizon (8 steps)
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_wide_golden.py          (needs /root/reference)
 
@@ -25,7 +26,7 @@ import make_golden as mg  # noqa: E402
 from oracle import lmpc_oracle as orc  # noqa: E402
 
 
-def make(PC, ICP, PM, SM, TR, UT, N, numSS_it, fname):
+def make(PC, ICP, PM, SM, TR, UT, N, numSS_it, fname, steps=12):
     n, d = 6, 2
     numSS_Points = 12 * numSS_it                           # initControllerParameters.py:43-44
     x0 = np.array([0.5, 0, 0, 0, 0, 0]); xS = [x0, x0]
@@ -48,7 +49,7 @@ def make(PC, ICP, PM, SM, TR, UT, N, numSS_it, fname):
     xc, xg = xPID[t0].copy(), xPID_glob[t0].copy()
     lmpc.xLin = xPID[t0 + 1:t0 + N + 2].copy(); lmpc.uLin = uPID[t0 + 1:t0 + N + 1].copy()
     lmpc.zt = xPID[t0 + N + 1].copy(); lmpc.OldInput = uPID[t0 - 1].copy(); lmpc.timeStep = t0
-    for t in range(12):
+    for t in range(steps):
         xpp = None if isinstance(lmpc.xPred, list) else lmpc.xPred.copy()
         rec = dict(t=lmpc.timeStep, x0=xc.copy(), xLin=np.array(lmpc.xLin).copy(), uLin=np.array(lmpc.uLin).copy(),
                    OldInput=np.array(lmpc.OldInput, float).reshape(-1).copy(), zt=np.array(lmpc.zt).copy(),
@@ -92,6 +93,7 @@ def main():
     ref = mg.load_reference()
     make(*ref, 12, 6, "lmpc_wide_n12.npz")
     make(*ref, 14, 4, "lmpc_n14.npz")
+    make(*ref, 40, 4, "lmpc_n40.npz", steps=8)
     for root, dirs, files in os.walk(mg.REF):
         assert "__pycache__" not in dirs, "reference tree was written to"
 

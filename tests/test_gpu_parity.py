@@ -99,7 +99,7 @@ def test_full_step_matches_reference_path(g):
     assert res["max_err_xu"] < common.TOL_XU
 
 
-@pytest.mark.parametrize("name", ["lmpc_wide_n12", "lmpc_n14"])
+@pytest.mark.parametrize("name", ["lmpc_wide_n12", "lmpc_n14", "lmpc_n40"])
 def test_other_configurations_match_reference(built, name):
     """Steps recorded from the EXECUTED reference in two more configurations (tests/golden/make_wide_golden.py): numSS_it = 6, numSS_Points = 72
     -- more terminal-block columns (78) than a wavefront has lanes: the one-wave kernel with several columns per lane at every batch size --

@@ -136,7 +136,7 @@ def test_oracle_noslack_assembly_matches_reference():
         assert max(orc.kkt_certificate(P, q, A, l, u, g["sol_opt"][r], g["y_opt"][r]).values()) < 1e-9
 
 
-@pytest.mark.parametrize("name", ["lmpc_wide_n12", "lmpc_n14"])
+@pytest.mark.parametrize("name", ["lmpc_wide_n12", "lmpc_n14", "lmpc_n40"])
 def test_other_configurations_restatement_matches_reference(name):
     """Fixtures recorded from the executed reference (tests/golden/make_wide_golden.py): numSS_it = 6, numSS_Points = 72 (more terminal columns
     than lanes of a wavefront) and main.py's own horizon N = 14: regression, selection with successors and Q-function shift, assembled QP."""
