@@ -4,6 +4,7 @@ class exactly as tests/golden/make_golden.py does (same stand-ins for cvxopt.qp 
   lmpc_wide_n12.npz   N = 12, numSS_it = 6, numSS_Points = 72: a safe set WIDER than one wavefront (72 + 6 terminal columns > 64 lanes)
   lmpc_n14.npz        N = 14, numSS_it = 4, numSS_Points = 48: the horizon main.py itself uses (main.py:43)
   lmpc_n40.npz        N = 40, numSS_it = 4, numSS_Points = 48: BASELINE.json configs[4]'s horizon (8 steps)
+  lmpc_30laps_n12.npz N = 12, 30 PID laps of different speeds in both stores (BASELINE.json configs[2]): sorted insert, the four fastest
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_wide_golden.py          (needs /root/reference)
 
@@ -88,9 +89,73 @@ def make(PC, ICP, PM, SM, TR, UT, N, numSS_it, fname, steps=12):
         len(recs), out["q"].shape[1], out["l"].shape[1], out["cert_opt"].max(), nact))
 
 
+def make_30laps(PC, ICP, PM, SM, TR, UT, fname="lmpc_30laps_n12.npz", steps=10):
+    """BASELINE.json configs[2] / SURVEY 8(d) "safe set from 30 laps": 30 single-lap PID trajectories (lap i at target speed 0.6 + 0.02 i,
+    np.random.seed(i)) handed to PredictiveModel.addTrajectory (sorted insert, :35-46; the regression uses the first trToUse = 4 of the sorted
+    store) and LMPC.addTrajectory (the selection uses argsort(LapTime)[:4], :395-402), then closed-loop steps started on lap 29."""
+    N, n, d, numSS_it, numSS_Points = 12, 6, 2, 4, 48
+    map_ = TR.Map(0.4)
+    x0 = np.array([0.5, 0, 0, 0, 0, 0])
+    _it, _pts, Laps, TimeLMPC, QterminalSlack, lmpcParameters = ICP.initLMPCParams(map_, N)
+    lmpcParameters.timeVarying = True
+    pm = PM.PredictiveModel(n, d, map_, 4)
+    laps = []
+    for i in range(30):
+        np.random.seed(i)
+        sim1 = SM.Simulator(map_, multiLap=False)
+        xl, ul, gl, _ = sim1.sim([x0, x0], UT.PID(0.6 + 0.02 * i))
+        laps.append((xl.copy(), ul.copy(), gl.copy()))
+        pm.addTrajectory(xl.copy(), ul.copy())
+    lmpc = PC.LMPC(numSS_Points, numSS_it, QterminalSlack, lmpcParameters, pm)      # (its constructor reads the model's last stored lap, :89)
+    for xl, ul, gl in laps:
+        lmpc.addTrajectory(xl.copy(), ul.copy(), gl.copy())
+    xq, uq, gq = laps[29]
+    recs = []
+    simulator = SM.Simulator(map_)
+    np.random.seed(3)
+    t0 = 30
+    xc, xg = xq[t0].copy(), gq[t0].copy()
+    lmpc.xLin = xq[t0 + 1:t0 + N + 2].copy(); lmpc.uLin = uq[t0 + 1:t0 + N + 1].copy()
+    lmpc.zt = xq[t0 + N + 1].copy(); lmpc.OldInput = uq[t0 - 1].copy(); lmpc.timeStep = t0
+    for t in range(steps):
+        xpp = None if isinstance(lmpc.xPred, list) else lmpc.xPred.copy()
+        rec = dict(t=lmpc.timeStep, x0=xc.copy(), xLin=np.array(lmpc.xLin).copy(), uLin=np.array(lmpc.uLin).copy(),
+                   OldInput=np.array(lmpc.OldInput, float).reshape(-1).copy(), zt=np.array(lmpc.zt).copy(),
+                   hasPred=0 if xpp is None else 1, xPredPrev=np.zeros((N + 1, n)) if xpp is None else xpp)
+        mg.CAPTURE.clear()
+        lmpc.solve(xc)
+        P, q, A, l, u, sol, y, status, it_, sp = mg.CAPTURE[-1]
+        rec.update(A=np.array(lmpc.A), B=np.array(lmpc.B), C=np.array(lmpc.C),
+                   SSsel=lmpc.SS_PointSelectedTot.copy(), Qsel=lmpc.Qfun_SelectedTot.copy(),
+                   Succ=lmpc.Succ_SS_PointSelectedTot.copy(), SuccU=lmpc.Succ_uSS_PointSelectedTot.copy(),
+                   q=q, l=l, u=u, sol=sol, status=status)
+        rec["Pp"], rec["Pi"], rec["Px"] = mg.csc_parts(P)
+        rec["Ap"], rec["Ai"], rec["Ax"] = mg.csc_parts(A)
+        ex, cert = orc.osqp_solve_exact(P, q, A, l, u)
+        rec["sol_opt"], rec["y_opt"], rec["cert_opt"] = ex.x, ex.y, cert
+        recs.append(rec)
+        xo = ex.x[:n * (N + 1)].reshape(N + 1, n); uo = ex.x[n * (N + 1):n * (N + 1) + d * N].reshape(N, d)
+        lam = ex.x[n * (N + 1) + d * N + 2 * N:n * (N + 1) + d * N + 2 * N + numSS_Points]
+        lmpc.xPred, lmpc.uPred = xo.copy(), uo.copy()
+        lmpc.zt = np.dot(lmpc.Succ_SS_PointSelectedTot, lam); lmpc.zt_u = np.dot(lmpc.Succ_uSS_PointSelectedTot, lam)
+        lmpc.xLin = np.vstack((xo[1:, :], lmpc.zt)); lmpc.uLin = np.vstack((uo[1:, :], lmpc.zt_u)); lmpc.OldInput = uo[0, :].copy()
+        xc, xg = simulator.dynModel(xc, xg, uo[0, :].copy())
+    out = {k: mg.stack([r[k] for r in recs]) for k in recs[0].keys()}
+    out.update(track=map_.PointAndTangent.copy(), trackLength=map_.TrackLength, numSS_it=numSS_it, numSS_Points=numSS_Points, N=N, nLaps=30)
+    for i, (xl, ul, gl) in enumerate(laps):
+        assert np.array_equal(lmpc.SS[i], xl) and np.array_equal(lmpc.uSS[i], ul)          # (no in-place edit happened: xLin was replaced before the first solve)
+        out["lapx%d" % i] = xl; out["lapu%d" % i] = ul; out["Qfun%d" % i] = lmpc.Qfun[i].copy()
+    out["modelOrder"] = np.array([[j for j, (xl, _, _) in enumerate(laps) if xl is not None and xs.shape == xl.shape and np.array_equal(xs, xl)][0] for xs in pm.xStored])
+    out["LapTime"] = np.array(lmpc.LapTime)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname + ": %d steps, lap lengths %d..%d, model store order (first 6): %s, fastest four: %s, certificates <= %.1e" % (
+        len(recs), min(lmpc.LapTime), max(lmpc.LapTime), list(out["modelOrder"][:6]), list(np.argsort(lmpc.LapTime)[:4]), out["cert_opt"].max()))
+
+
 def main():
     mg.install_standins()
     ref = mg.load_reference()
+    make_30laps(*ref)
     make(*ref, 12, 6, "lmpc_wide_n12.npz")
     make(*ref, 14, 4, "lmpc_n14.npz")
     make(*ref, 40, 4, "lmpc_n40.npz", steps=8)

@@ -162,3 +162,34 @@ def test_other_configurations_restatement_matches_reference(name):
         Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="")
         assert np.array_equal(P, Pr) and np.array_equal(q, qr) and np.array_equal(Aq, Ar) and np.array_equal(l, lr) and np.array_equal(u, ur)
         assert g["cert_opt"][r] < 1e-8
+
+
+def test_30_lap_stores_restatement_matches_reference():
+    """BASELINE configs[2] on the executed reference (lmpc_30laps_n12.npz): 30 laps of different lengths through PredictiveModel.addTrajectory's
+    sorted insert and LMPC.addTrajectory; regression over the first four of the sorted store, selection over the four fastest laps."""
+    g = dict(np.load(common.GOLDEN + "/lmpc_30laps_n12.npz"))
+    N = int(g["N"]); nl = int(g["nLaps"]); TL = float(g["trackLength"])
+    par = orc.QPParams.lmpc_default(N)
+    model = orc.OracleModel(g["track"], 4)
+    for i in range(nl):
+        model.addTrajectory(g["lapx%d" % i], g["lapu%d" % i])
+    order = [[j for j in range(nl) if g["lapx%d" % j].shape == xs.shape and np.array_equal(g["lapx%d" % j], xs)][0] for xs in model.xStored]
+    assert np.array_equal(order, g["modelOrder"])
+    SS = [g["lapx%d" % i] for i in range(nl)]; uSS = [g["lapu%d" % i] for i in range(nl)]
+    Qf = [orc.compute_cost(g["lapx%d" % i], TL) for i in range(nl)]
+    for i in range(nl):
+        assert np.array_equal(Qf[i], g["Qfun%d" % i])
+    for r in range(g["x0"].shape[0]):
+        A, B, C = orc.compute_ltv_dynamics(model.xStored, model.uStored, model.usedIt, g["track"], g["xLin"][r], g["uLin"][r], N)
+        for got, ref in ((A, g["A"][r]), (B, g["B"][r]), (C, g["C"][r])):
+            assert (np.abs(got - ref) / (1 + np.abs(ref))).max() < 1e-10
+        zt = g["zt"][r].copy()
+        if zt[4] - g["x0"][r][4] > TL / 2:
+            zt[4] = np.max([zt[4] - TL, 0])
+        xpp = g["xPredPrev"][r] if g["hasPred"][r] else None
+        SSsel, Qsel, Succ, SuccU = orc.terminal_components(SS, uSS, Qf, list(g["LapTime"]), zt, 48, 4, xpp, nl, int(g["t"][r]), N, TL)
+        assert np.array_equal(SSsel, g["SSsel"][r]) and np.array_equal(Qsel, g["Qsel"][r])
+        assert np.array_equal(Succ, g["Succ"][r]) and np.array_equal(SuccU, g["SuccU"][r])
+        P, q, Aq, l, u = orc.assemble_lmpc_qp(par, g["A"][r], g["B"][r], g["C"][r], g["x0"][r], g["OldInput"][r], SSsel, Qsel)
+        Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="")
+        assert np.array_equal(P, Pr) and np.array_equal(q, qr) and np.array_equal(Aq, Ar) and np.array_equal(l, lr) and np.array_equal(u, ur)
