@@ -46,36 +46,99 @@ class LocalComm:
         pass
 
 
+def _rdzv_file(port):
+    """Same-node hand-off file: every rank of one launch has the same parent process (the launcher's agent, or bench.py --gpus N itself)."""
+    import tempfile
+    return os.path.join(tempfile.gettempdir(), "lmpc_rdzv_%d_%d.id" % (os.getppid(), int(port)))
+
+
+def _is_local(addr):
+    if os.environ.get("LMPC_RDZV_TCP") == "1":                      # (tests: force the TCP hand-off)
+        return False
+    return addr in ("127.0.0.1", "localhost", "::1") or addr == socket.gethostname()
+
+
 def _rendezvous_id(rank, world, addr, port, make_id, timeout=120.0):
-    """Rank 0 creates the RCCL unique id and serves it to the world - 1 other ranks over TCP (addr, port)."""
+    """Rank 0 creates the RCCL unique id and hands it to the world - 1 other ranks: through a file in the temporary directory when the
+    ranks share a node (no port to collide on, nothing to resolve; a rank acknowledges with a file of its own), and over TCP (addr, port)
+    for ranks on other nodes or without a shared temporary directory.  Rank 0 returns once every other rank has the id."""
+    path = _rdzv_file(port)
     if rank == 0:
         uid = make_id()
-        if world > 1:
+        if world == 1:
+            return uid
+        try:
+            tmp = path + ".tmp%d" % os.getpid()
+            with open(tmp, "wb") as f:
+                f.write(uid)
+            os.replace(tmp, path)                                   # atomic: a reader sees all 128 bytes or no file
+        except OSError:
+            pass
+        try:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port)); srv.listen(world); srv.settimeout(timeout)
-            try:
-                for _ in range(world - 1):
-                    conn, _peer = srv.accept()
-                    conn.sendall(uid); conn.close()
-            finally:
+            srv.bind((addr, port)); srv.listen(world); srv.settimeout(0.05)
+        except OSError:
+            srv = None                                              # port taken: the file is the hand-off
+        served, t0 = set(), time.time()
+        try:
+            while len(served) < world - 1:
+                for r in range(1, world):
+                    if os.path.exists(path + ".ack%d" % r):
+                        served.add(r)
+                if srv is not None and len(served) < world - 1:
+                    try:
+                        conn, _peer = srv.accept()
+                        conn.settimeout(5.0); conn.sendall(uid)
+                        try:
+                            served.add(int(conn.recv(16).decode() or "-1"))      # the peer answers with its rank
+                        except (OSError, ValueError):
+                            pass
+                        conn.close()
+                    except socket.timeout:
+                        pass
+                elif srv is None:
+                    time.sleep(0.02)
+                if time.time() - t0 > timeout:
+                    raise TimeoutError("rendezvous: %d of %d ranks fetched the RCCL id within %.0f s" % (len(served), world - 1, timeout))
+        finally:
+            if srv is not None:
                 srv.close()
+            for f in [path] + [path + ".ack%d" % r for r in range(1, world)]:
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
         return uid
     t0 = time.time()
+    local = _is_local(addr)
     while True:
-        try:
-            s = socket.create_connection((addr, port), timeout=5.0)
-            break
-        except OSError:
-            if time.time() - t0 > timeout:
-                raise
-            time.sleep(0.05)
+        if local and os.path.exists(path):
+            try:
+                with open(path, "rb") as f:
+                    buf = f.read()
+            except OSError:
+                buf = b""
+            if len(buf) == 128:
+                with open(path + ".ack%d" % rank, "wb") as f:
+                    f.write(b"1")
+                return buf
+        if not local or time.time() - t0 > 15.0:                   # another node, or no shared temporary directory: ask rank 0
+            try:
+                s = socket.create_connection((addr, port), timeout=5.0)
+                break
+            except OSError:
+                pass
+        if time.time() - t0 > timeout:
+            raise TimeoutError("rendezvous: no RCCL id from rank 0 within %.0f s (file %s, tcp %s:%d)" % (timeout, path, addr, port))
+        time.sleep(0.02)
     buf = b""
     while len(buf) < 128:
         chunk = s.recv(128 - len(buf))
         if not chunk:
             raise ConnectionError("rendezvous: rank 0 closed the connection early")
         buf += chunk
+    s.sendall(str(rank).encode())
     s.close()
     return buf
 

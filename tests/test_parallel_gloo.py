@@ -1,6 +1,8 @@
 """CPU, world_size 2, gloo: sharding and the per-lap exchange give identical, deterministic results on all ranks."""
 import os
 import subprocess
+
+import pytest
 import sys
 
 import numpy as np
@@ -92,11 +94,14 @@ print("ok", rank)
 '''
 
 
-def test_unique_id_rendezvous_three_processes(tmp_path):
-    """The TCP hand-off of the RCCL unique id (rank 0 creates, the others fetch), without a GPU: three processes, any start order."""
+@pytest.mark.parametrize("tcp", ["0", "1"])
+def test_unique_id_rendezvous_three_processes(tmp_path, tcp):
+    """The hand-off of the RCCL unique id (rank 0 creates, the others fetch), without a GPU: three processes, any start order; through the
+    same-node file (default for a local MASTER_ADDR) and over TCP (other nodes; forced here with LMPC_RDZV_TCP=1)."""
     script = tmp_path / "rdzv.py"
     script.write_text(RDZV_WORKER)
-    procs = [subprocess.Popen([sys.executable, str(script), common.ROOT, str(r), "3", "29689"], stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in (2, 1, 0)]
+    procs = [subprocess.Popen([sys.executable, str(script), common.ROOT, str(r), "3", "2968%s" % (9 if tcp == "1" else 7)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              env=dict(os.environ, LMPC_RDZV_TCP=tcp)) for r in (2, 1, 0)]
     for p in procs:
         out, err = p.communicate(timeout=120)
         assert p.returncode == 0 and out.decode().startswith("ok"), err.decode()
