@@ -14,7 +14,8 @@ NH = int(os.environ.get("EXP_N", "12"))            # horizon
 sizes = [int(a) for a in sys.argv[1:]] or [1, 256, 512, 1024, 4096, 8192]
 row = []
 for B in sizes:
-    r = bench.run_config(g, NH, B, 0, steps=20 if B <= 1024 and NH <= 20 else 6, warmup=3)
+    kw = {"tol_res": float(os.environ["EXP_TOLRES"])} if "EXP_TOLRES" in os.environ else {}
+    r = bench.run_config(g, NH, B, 0, steps=20 if B <= 1024 and NH <= 20 else 6, warmup=3, **kw)
     row.append("B=%d: %.0f/s (solve %.3f ms, K1 %.3f ms, ok %d/%d, it max %d)" % (B, r["solves_per_s"], r["kernel_ms"]["lmpc_solve_kernel"], r["kernel_ms"]["lmpc_regress_kernel"] or 0.0,
                                                                                   r["solved_ok"], B, r["ipm_iters_max"]))
 print("N=%d NW=%s  " % (NH, os.environ.get("LMPC_FORCE_NW", "auto")) + " | ".join(row))
