@@ -25,7 +25,7 @@ extern "C" {
 #define LMPC_MAX_TRACK_ROWS 16
 #define LMPC_MAX_USED_LAPS 8       /* trToUse / numSS_it upper bound */
 #define LMPC_MAX_N 64
-#define LMPC_MAX_SS_POINTS 250     /* numSS_points upper bound (up to 58 every kernel; beyond that the one-wave solve kernel only) */
+#define LMPC_MAX_SS_POINTS 250     /* numSS_points upper bound (beyond 58 the terminal block takes several columns per lane) */
 
 /* error codes (function return values) */
 #define LMPC_OK 0

@@ -146,9 +146,12 @@ static int create_body(lmpc_ctx *c) {
     // CU.  Measured (solve kernel, ms; two waves | one wave): N=12 B=1024 0.30 | 0.40, B=2048 (two rounds | one round) 0.56 | 0.47;  N=14 B=512 0.33 | 0.42, B=1024 0.48 | 0.44;
     // N=20 B=512 0.43 | 0.56, B=1024 0.79 | 0.63;  N=40 B=512 1.35 | 1.00, B=1024 2.33 | 1.78 (and four waves: 1.18, 2.05).
     c->mw2_max_batch = c->mw_max_batch == c->n_cu ? (cfg->N <= 12 ? 4 : cfg->N <= 24 ? 2 : 0) * c->n_cu : 0;
+
+    // safe sets wider than 58 points (several terminal-block columns per lane): the two-wave kernel is built for one wave per SIMD
+    // (two QPs per CU), so its regime ends at two QPs per CU
+    if (cfg->numSS_it > 0 && cfg->numSS_points + 6 > WAVE && c->mw2_max_batch > 2 * c->n_cu) c->mw2_max_batch = 2 * c->n_cu;
+    if (c->var.lds_mw == 0) { c->mw_max_batch = 0; c->mw2_max_batch = 0; }        // (a variant without multi-wave kernels)
     if (const char *e = getenv("LMPC_MW2_MAX_BATCH")) c->mw2_max_batch = atoi(e);        // (experiments)
-    // safe sets wider than 58 points (numSS_points + 6 terminal columns > one per lane) exist as one-wave kernels only
-    if (c->var.lds_mw == 0) { c->mw_max_batch = 0; c->mw2_max_batch = 0; }
     // Fused step (regression inside the one-wave solve kernel): bit-identical results, 42 MB less HBM traffic per step at batch 4096, but
     // MEASURED SLOWER -- 1.37 vs 1.01 + 0.23 ms at batch 4096, 2.48 vs 1.81 + 0.44 ms at batch 8192 with six QPs per CU; 1.92 vs 1.45 + 0.41 ms
     // at batch 8192 with eight: the regression's short dependent chains (DPP minima, 5 x 5 Cholesky, scattered L2 reads) want the four waves

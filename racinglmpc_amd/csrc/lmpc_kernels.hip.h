@@ -824,6 +824,7 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
 
 template <int N, int S> struct solve_lds {
     static constexpr int M = 8 * N + S;
+    static constexpr int CH = (S + 6 + WAVE - 1) / WAVE, CW = CH * WAVE;       // terminal-block columns per lane of the wave that owns them
     static constexpr int oAB = 0, oC = oAB + 48 * N;                      // AB[k] = [A_k | B_k] (6 x 8), C_k
     static constexpr int ox = oC + 6 * N, ou = ox + 6 * (N + 1), os = ou + 2 * N, olam = os + 2 * N;
     static constexpr int odx = olam + S, odu = odx + 6 * (N + 1), ods = odu + 2 * N, odl = ods + 2 * N;
@@ -833,8 +834,8 @@ template <int N, int S> struct solve_lds {
     static constexpr int oPhi = orl + S, oPiAll = oPhi + 64 * N, oMi = oPiAll + 64 * N, ogam = oMi + 4 * N, ogup = ogam + 8 * N,
                          opst = ogup + 2 * N, ok0 = opst + 8 * (N + 1), odnu = ogam;              // dnu reuses gamma (dead after the sweeps)
     static constexpr int okap = ok0 + 2 * N, orDs = okap + 2 * N, oeta = orDs + 2 * N, oe = oeta + 2 * N;
-    static constexpr int oRi = oe + 2 * N, orsq = oRi + 56, oct = orsq + WAVE;
-    static constexpr int oMt = oct + WAVE, oWl = oMt + (S > 0 ? 8 * WAVE : 0), oMc = oWl + (S > 0 ? 64 : 0);   // M transposed (col-major, 8 per column), Gram matrix, M c~
+    static constexpr int oRi = oe + 2 * N, orsq = oRi + 56, oct = orsq + CW;
+    static constexpr int oMt = oct + CW, oWl = oMt + (S > 0 ? 8 * CW : 0), oMc = oWl + (S > 0 ? 64 : 0);   // M transposed (col-major, 8 per column), Gram matrix, M c~
     static constexpr int oSS = oMc + 8, oQsel = oSS + 6 * S, oy7 = oQsel + S, oz7 = oy7 + 8, ow7 = oz7 + 8, oPiT = ow7 + 8, osT = oPiT + 36;
     static constexpr int opar = osT + 8, tot = opar + PAR_TOT;
 };

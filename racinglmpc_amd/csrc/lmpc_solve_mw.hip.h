@@ -29,7 +29,7 @@ template <int N, int S, int NW>
 // (registers: four waves per QP = one wave per SIMD; two waves per QP = two waves per SIMD only where the LDS footprint lets three or more
 // QPs share a CU -- long horizons keep their sweep operands (3 N doubles per lane) in registers and need the full file: at N = 40 the
 // 256-register build spilled 221 VGPRs to scratch)
-__global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 > 160 * 1024) ? 1 : 2) void lmpc_solve_kernel_mw(lmpc_dev_params p, int B, lmpc_solve_io io) {
+__global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 > 160 * 1024 || solve_lds<N, S>::CH > 1) ? 1 : 2) void lmpc_solve_kernel_mw(lmpc_dev_params p, int B, lmpc_solve_io io) {
     static_assert(NW == 2 || NW == 4, "wave 0 runs the sequential recursions, waves 1 .. NW-1 everything that can run beside them");
     extern __shared__ double sm[];
     using LL = solve_lds<N, S>;
@@ -150,10 +150,15 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     // loop-invariant pieces of the stage Hessian W for this lane's (a, c) = (lg, lc) tile entry (used by wave 0)
     const ricc_consts rc = ricc_setup(lane, Q2, Fx, R2, dR2, Fu);
     double ph[N];
-    double mcol[7];
-    const double tsq_lane = (term && lane >= S && lane < S + 6) ? frsqrt(T2p[lane - S]) : 0.0;   // T^-1/2 entry of this lane's slack column of M (loop invariant)
+    constexpr int CH = LL::CH;                               // terminal-block columns per lane of wave 0 (column = lane + 64 ch; 1 up to 58 safe-set points)
+    double mcol[CH][7], tsq_lane[CH];                        // columns of M = [E D^-1/2 | T7^-1/2]; T^-1/2 entry of a slack column (loop invariant)
 #pragma unroll
-    for (int j = 0; j < 7; j++) mcol[j] = 0.0;
+    for (int ch = 0; ch < CH; ch++) {
+        const int col = lane + WAVE * ch;
+        tsq_lane[ch] = (term && col >= S && col < S + 6) ? frsqrt(T2p[col - S]) : 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) mcol[ch][j] = 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < N; k++) ph[k] = 0.0;
     __syncthreads();
@@ -173,20 +178,24 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     //   C2  wave 0 alone: backward sweep, feed-forward terms phi_k (lane-parallel, two passes of eight stages), forward sweep
     //   C3  slack and terminal steps
     auto kkt_solve = [&](double re_sum) {
-        double c_t = 0.0, xiN = 0.0, mc_g = 0.0, y7v = 0.0, pN = 0.0;   // wave 0's registers: last stage of the forward sweep, (M c~)[lg], y7[lg], p_N[lg]
+        double c_t[CH], xiN = 0.0, mc_g = 0.0, y7v = 0.0, pN = 0.0;   // wave 0's registers: last stage of the forward sweep, (M c~)[lg], y7[lg], p_N[lg]
         if (w0) {
             if constexpr (term) {
-                if (lane < S) c_t = (rl[lane] + h[8 * N + lane]) * rsq[lane];
-                ct[lane] = c_t;
-                WSYNC();
-                double acc = 0.0;                               // M c~ : lane (j, part) adds 8 of the 64 columns
-                {
-                    double mq[8], cq[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) { mq[q] = Mt[lc * 8 + (lg < 7 ? lg : 0) + 64 * q]; cq[q] = ct[lc + 8 * q]; }
+                for (int ch = 0; ch < CH; ch++) {
+                    const int col = lane + WAVE * ch;
+                    c_t[ch] = col < S ? (rl[col] + h[8 * N + col]) * rsq[col] : 0.0;
+                    ct[col] = c_t[ch];
+                }
+                WSYNC();
+                double acc = 0.0;                               // M c~ : lane (j, part) adds every 8th of the 64 CH columns
+                {
+                    double mq[8 * CH], cq[8 * CH];
+#pragma unroll
+                    for (int q = 0; q < 8 * CH; q++) { mq[q] = Mt[lc * 8 + (lg < 7 ? lg : 0) + 64 * q]; cq[q] = ct[lc + 8 * q]; }
                     LDS_GROUP();
 #pragma unroll
-                    for (int q = 0; q < 8; q++) acc = fma(mq[q], cq[q], acc);
+                    for (int q = 0; q < 8 * CH; q++) acc = fma(mq[q], cq[q], acc);
                     acc = lg < 7 ? acc : 0.0;
                 }
                 acc = sum_over_c(acc);
@@ -291,12 +300,16 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
 #pragma unroll
                     for (int j = 0; j < 7; j++) wq[j] = w7[j];
                 }
-                double v = -c_t;                                // v = -c~ + M' omega'
-                const double rq = rsq[lane];
-                LDS_GROUP();
 #pragma unroll
-                for (int j = 0; j < 7; j++) v = fma(mcol[j], wq[j], v);
-                if (lane < S) dl[lane] = v * rq;
+                for (int ch = 0; ch < CH; ch++) {
+                    const int col = lane + WAVE * ch;
+                    double v = -c_t[ch];                        // v = -c~ + M' omega'
+                    const double rq = rsq[col];
+                    LDS_GROUP();
+#pragma unroll
+                    for (int j = 0; j < 7; j++) v = fma(mcol[ch][j], wq[j], v);
+                    if (col < S) dl[col] = v * rq;
+                }
             }
         }
         __syncthreads();                                        // C3
@@ -315,21 +328,25 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         if (w0) {
             if constexpr (term) {
 #pragma unroll
-                for (int j = 0; j < 7; j++) mcol[j] = 0.0;
-                if (lane < S) {
-                    const double rs_ = frsqrt(th[8 * N + lane] + p.reg); rsq[lane] = rs_;
+                for (int ch = 0; ch < CH; ch++) {
+                    const int col = lane + WAVE * ch;
 #pragma unroll
-                    for (int j = 0; j < 6; j++) mcol[j] = SS[j * S + lane] * rs_;
-                    mcol[6] = rs_;
-                } else {
-                    rsq[lane] = 1.0;
+                    for (int j = 0; j < 7; j++) mcol[ch][j] = 0.0;
+                    if (col < S) {
+                        const double rs_ = frsqrt(th[8 * N + col] + p.reg); rsq[col] = rs_;
 #pragma unroll
-                    for (int j = 0; j < 6; j++) if (lane - S == j) mcol[j] = tsq_lane;
+                        for (int j = 0; j < 6; j++) mcol[ch][j] = SS[j * S + col] * rs_;
+                        mcol[ch][6] = rs_;
+                    } else {
+                        rsq[col] = 1.0;
+#pragma unroll
+                        for (int j = 0; j < 6; j++) if (col - S == j) mcol[ch][j] = tsq_lane[ch];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 7; j++) Mt[col * 8 + j] = mcol[ch][j];
+                    Mt[col * 8 + 7] = 0.0;
                 }
                 double Rr[7][7], rinv[7];
-#pragma unroll
-                for (int j = 0; j < 7; j++) Mt[lane * 8 + j] = mcol[j];
-                Mt[lane * 8 + 7] = 0.0;
                 WSYNC();
                 {   // Gram matrix W = M M' on the matrix cores (see lmpc_solve_kernel)
                     typedef double v4d __attribute__((ext_vector_type(4)));
@@ -337,7 +354,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                     const int kk = lane >> 4, ii = lane & 15;
                     const bool live = ii < 8;
 #pragma unroll
-                    for (int s_ = 0; s_ < 16; s_ += 4) {
+                    for (int s_ = 0; s_ < 16 * CH; s_ += 4) {
                         double a0 = Mt[(4 * s_ + kk) * 8 + (ii & 7)], a1 = Mt[(4 * (s_ + 1) + kk) * 8 + (ii & 7)], a2 = Mt[(4 * (s_ + 2) + kk) * 8 + (ii & 7)], a3 = Mt[(4 * (s_ + 3) + kk) * 8 + (ii & 7)];
                         a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0; a2 = live ? a2 : 0.0; a3 = live ? a3 : 0.0;
                         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
@@ -491,19 +508,21 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         } else {
             double pv = 0.0;
             if (wave == 1) {                                 // step 0: terminal costate p_N
-                double c_t = 0.0;
                 if constexpr (term) {
-                    if (lane < S) c_t = (rl[lane] + m[8 * N + lane]) * rsq[lane];
-                    ct[lane] = c_t;
-                    WSYNC();
-                    double acc = 0.0;                               // M c~ : lane (j, part) adds 8 of the 64 columns
-                    {
-                        double mq[8], cq[8];
 #pragma unroll
-                        for (int q = 0; q < 8; q++) { mq[q] = Mt[lc * 8 + (lg < 7 ? lg : 0) + 64 * q]; cq[q] = ct[lc + 8 * q]; }
+                    for (int ch = 0; ch < CH; ch++) {
+                        const int col = lane + WAVE * ch;
+                        ct[col] = col < S ? (rl[col] + m[8 * N + col]) * rsq[col] : 0.0;
+                    }
+                    WSYNC();
+                    double acc = 0.0;                               // M c~ : lane (j, part) adds every 8th of the 64 CH columns
+                    {
+                        double mq[8 * CH], cq[8 * CH];
+#pragma unroll
+                        for (int q = 0; q < 8 * CH; q++) { mq[q] = Mt[lc * 8 + (lg < 7 ? lg : 0) + 64 * q]; cq[q] = ct[lc + 8 * q]; }
                         LDS_GROUP();
 #pragma unroll
-                        for (int q = 0; q < 8; q++) acc = fma(mq[q], cq[q], acc);
+                        for (int q = 0; q < 8 * CH; q++) acc = fma(mq[q], cq[q], acc);
                         acc = lg < 7 ? acc : 0.0;
                     }
                     acc = sum_over_c(acc);
@@ -596,12 +615,16 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
 #pragma unroll
                     for (int j = 0; j < 7; j++) wq[j] = w7[j];
                 }
-                double v = -ct[lane];                           // v = -c~ + M' omega'
-                const double rq = rsq[lane];
-                LDS_GROUP();
 #pragma unroll
-                for (int j = 0; j < 7; j++) v = fma(mcol[j], wq[j], v);
-                if (lane < S) dl[lane] = v * rq;
+                for (int ch = 0; ch < CH; ch++) {
+                    const int col = lane + WAVE * ch;
+                    double v = -ct[col];                        // v = -c~ + M' omega'
+                    const double rq = rsq[col];
+                    LDS_GROUP();
+#pragma unroll
+                    for (int j = 0; j < 7; j++) v = fma(mcol[ch][j], wq[j], v);
+                    if (col < S) dl[col] = v * rq;
+                }
             }
         }
         __syncthreads();
@@ -681,9 +704,9 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         if constexpr (term) {
             if (wave == NW - 1) {                                // multiplier of sum(lambda) = 1: mean over the lambda rows
                 double v = 0.0;
-                if (lane < S) { v = -rl[lane] + dm[8 * N + lane];
+                for (int c = lane; c < S; c += WAVE) { v += -rl[c] + dm[8 * N + c];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) v -= SS[j * S + lane] * T2p[j] * w7[j]; }
+                    for (int j = 0; j < 6; j++) v -= SS[j * S + c] * T2p[j] * w7[j]; }
                 v = wsum(v) / (double)S;
                 if (lane == 0) red[9 * 4] = v;
             }
@@ -726,13 +749,13 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             double acc[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[j] = 0.0;
-            if (lane < S) {
-                const int l = lane / p.ppl, cc = lane % p.ppl;
+            for (int c = lane; c < S; c += WAVE) {
+                const int l = c / p.ppl, cc = c % p.ppl;
                 const double *base = p.sstore + (size_t)p.sslot[l] * LMPC_COLS * p.lap_stride;
                 int r1 = sel_start[l] + cc + 1; r1 = r1 > p.sslen[l] - 1 ? p.sslen[l] - 1 : r1;
-                const double lv = lam[lane];
+                const double lv = lam[c];
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc[j] = base[j * p.lap_stride + r1] * lv;
+                for (int j = 0; j < 8; j++) acc[j] = fma(base[j * p.lap_stride + r1], lv, acc[j]);
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[j] = wsum(acc[j]);

@@ -19,7 +19,7 @@ struct lmpc_variant_api {
 };
 
 template <int N, int S> struct lmpc_variant_launchers {
-    static constexpr bool has_mw = S + 6 <= WAVE;      // the multi-wave kernels keep one terminal-block column per lane; wider safe sets run on the one-wave kernel
+    static constexpr bool has_mw = true;               // (every supported S: wave 0 of the multi-wave kernels carries ceil((S + 6) / 64) terminal-block columns per lane)
     static constexpr size_t lds1 = (size_t)solve_lds1<N, S>::tot * sizeof(double), ldsm = has_mw ? (size_t)solve_lds<N, S>::tot * sizeof(double) : 0;
     // fused step (io.mode & 4): the regression's work space sits behind [A_k | B_k], C_k; it fits the solve's footprint at the reference's
     // settings (4 laps x 7 points) and grows it a little beyond

@@ -260,7 +260,6 @@ def test_general_horizon_and_safe_set_size(built, N, numSS_it, ppl):
         cfg, _ = common.lmpc_config(g, N, max_batch=B, numSS_it=numSS_it, numSS_Points=S)
         ctx = _capi.Context(cfg)
         assert ctx.S == S
-        assert ctx.solver_waves(B) == 1 or S + 6 <= 64
         for i in range(max(4, numSS_it)):
             if i < 4:
                 ctx.model_add_trajectory(xP, uP)

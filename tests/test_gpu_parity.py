@@ -112,7 +112,7 @@ def test_other_configurations_match_reference(built, name):
     gl = common.load_lmpc_golden()
     cfg, par = common.lmpc_config(gl, N, max_batch=16, numSS_it=L, numSS_Points=S)
     ctx = _capi.Context(cfg)
-    assert ctx.S == S and (ctx.solver_waves(1) == 1) == (S + 6 > 64)
+    assert ctx.S == S and ctx.solver_waves(1) == 4
     for _ in range(4):
         ctx.model_add_trajectory(g["xPID"], g["uPID"])
     for l in range(L):
