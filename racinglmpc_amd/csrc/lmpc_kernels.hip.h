@@ -64,7 +64,10 @@ __device__ __forceinline__ void wave_argmin(double &v, int &i) {
 // Map.curvature, Track.py:292-310.  Returns 0 and sets *bad when s lies on no segment (the reference raises).
 __device__ __forceinline__ double track_curvature(const lmpc_dev_params &p, double s, int *bad) {
     const double TL = p.TL;
-    while (s > TL) s = s - TL;
+    // `while s > TrackLength: s = s - TrackLength` of the reference, bounded: an infinite or absurd s (a diverged rollout) must not hang the
+    // GPU -- beyond 64 laps it is reported as "on no segment", which is what the reference's own loop could never return from either
+    for (int lap = 0; lap < 64 && s > TL; lap++) s = s - TL;
+    if (!(s <= TL)) { *bad = 1; return 0.0; }
     for (int i = 0; i < p.track_rows; i++) {
         const double c0 = p.track[i * 6 + 3], len = p.track[i * 6 + 4];
         if (s >= c0 && s < c0 + len) return p.track[i * 6 + 5];
@@ -188,8 +191,9 @@ __global__ void lmpc_global_position_kernel(lmpc_dev_params p, int n, const doub
     if (e >= n) return;
     const double PI = 3.141592653589793;
     double s = s_in[e]; const double ey = ey_in[e];
-    while (s > p.TL) s = s - p.TL;
+    for (int lap = 0; lap < 4096 && s > p.TL; lap++) s = s - p.TL;                          // (`while s > TrackLength`, bounded: an infinite s must not hang the GPU)
     int i = -1;
+    if (!(s <= p.TL)) s = -1.0;                                                               // -> on no segment
     for (int r = 0; r < p.track_rows; r++) { const double c0 = p.track[r * 6 + 3]; if (s >= c0 && s < c0 + p.track[r * 6 + 4]) { i = r; break; } }
     if (i < 0) { status[e] = LMPC_ST_NO_SEGMENT; xy[2 * e] = 0.0; xy[2 * e + 1] = 0.0; return; }
     const double *ti = p.track + i * 6, *tp = p.track + (i > 0 ? i - 1 : p.track_rows - 1) * 6;

@@ -297,6 +297,26 @@ def test_more_status_flags(g):
     ctx.close()
 
 
+@pytest.mark.timeout(120)
+def test_diverged_states_do_not_hang_the_device(g):
+    """The reference wraps s with `while s > TrackLength: s = s - TrackLength` (Track.py:292-310): with s = +inf (a diverged rollout) that
+    loop never returns.  On the device it is bounded -- an infinite, NaN or absurd s ends up as LMPC_ST_NO_SEGMENT in every kernel that
+    looks the curvature up (regression, plant, global position) and the call returns."""
+    from racinglmpc_amd import _capi
+    ctx, par = common.make_lmpc_ctx(g, 4, max_batch=8)
+    bad_s = np.array([np.inf, 1e300, np.nan, -np.inf, 19.0 * 1e6])
+    xy, st = ctx.global_position_batch(np.concatenate([bad_s, [3.0, 19.2296 * 3 + 1.0]]), np.zeros(7))
+    assert np.all(st[:5] == _capi.ST_NO_SEGMENT) and np.all(st[5:] == 0)
+    xl = np.tile(g["rec_xLin"][:1], (5, 1, 1)); ul = np.tile(g["rec_uLin"][:1], (5, 1, 1))
+    xl[np.arange(5), 3, 4] = bad_s                                            # one linearisation point per problem off the rails
+    A, B, C, rst = ctx.regress_batch(xl, ul)
+    assert np.all(rst[:, 3] & _capi.ST_NO_SEGMENT) and np.all(np.delete(rst, 3, axis=1) == 0)
+    x = np.tile(g["xPID"][50], (5, 1)); x[:, 4] = bad_s
+    xn, xgn, pst = ctx.plant_step_batch(x, x.copy(), np.tile(g["uPID"][50], (5, 1)), np.zeros((5, 3)))
+    assert np.all(pst != 0)
+    ctx.close()
+
+
 def _flag(name):
     from racinglmpc_amd import _capi
     return getattr(_capi, name)
