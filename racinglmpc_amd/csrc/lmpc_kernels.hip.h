@@ -944,6 +944,22 @@ __device__ __forceinline__ double ri_times(const double *Ri, const double *b, in
     return sum_over_c(v);
 }
 
+// Roll-out x_{k+1} = A_k x_k + C_k (u = 0) that gives the interior-point iteration its start, by one wave, in registers: lane c < 6 carries
+// x_k[c], the six entries reach every lane as wave-uniform values (v_readlane), the rows of A_k and C_k are independent loads the
+// compiler issues ahead.  Same multiply-add order as the LDS form (12 round trips and barriers), ~14 k cycles less per solve.
+template <int N> __device__ __forceinline__ void rollout_start(const double *AB, const double *Cg, double *x, int lane) {
+    const int c = lane < 6 ? lane : 0;
+    double xc = x[c];                                         // x_0 (written by the caller, visible)
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double v = Cg[k * 6 + c];
+#pragma unroll
+        for (int j = 0; j < 6; j++) v = fma(AB[k * 48 + c * 8 + j], rdlane(xc, j), v);
+        xc = v;
+        if (lane < 6) x[(k + 1) * 6 + lane] = v;
+    }
+}
+
 // Terminal part of a Newton solve without LDS round trips: omega' = Ri (Ri' d7 + y7), d7 = (dx_N ; -re_sum).  The forward sweep ends (for
 // even N: its last stage sums over the groups) with every lane (lg, lc) holding xi_N[lc], which is d7[lc] for lc < 6: the product with
 // Ri' is formed from that register, z7 reaches lane (lg, lc) as element lc through the LDS crossbar (ds_bpermute from the first lane of
@@ -1109,6 +1125,16 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     __syncthreads();
     const double a_s = wave_uniform(par[PAR_AS]), c_s = wave_uniform(par[PAR_CS]);
 
+    // A_k, B_k, C_k of this problem: the global loads are issued here, into registers, so that their latency runs beside the lap scans of
+    // the selection; they reach LDS afterwards
+    constexpr int TA = (36 * N + WAVE - 1) / WAVE, TB = (12 * N + WAVE - 1) / WAVE;
+    double preA[TA], preB[TB];
+    const bool preload = (io.mode & 2) && !(io.mode & 4);
+    if (preload) {
+        FOR_LANES_T(i, t, 36 * N) preA[t] = io.A[(size_t)b * 36 * N + i];
+        FOR_LANES_T(i, t, 12 * N) preB[t] = io.Bm[(size_t)b * 12 * N + i];
+        FOR_LANES_T(i, t, 6 * N) c_r[t] = io.C[(size_t)b * 6 * N + i];
+    }
     // K2: safe-set selection (k2_select), then the regression status bits of this problem's N points
     if constexpr (term) { k2_select<N, S, 1>(p, io, b, lane, 0, SS, Qsel, sel_start, &st_sh); __syncthreads(); }
     if (io.rstatus && lane < N) { const int rs_ = io.rstatus[(size_t)b * N + lane]; if (rs_) atomicOr(&st_sh, rs_); }
@@ -1120,10 +1146,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     // LMPC.unpackSolution (:364-375); inequality rows in the reference's order (buildIneqConstr :166-198,
     // addSafeSetIneqConstr :340-343).  s_T is eliminated (s_T = SS lambda - x_N).
     // ------------------------------------------------------------------------------------------------
-    if (!(io.mode & 4)) {
-        FOR_LANES(i, 36 * N) { const int k = i / 36, r = (i % 36) / 6, c = i % 6; AB[k * 48 + r * 8 + c] = io.A[(size_t)b * 36 * N + i]; }
-        FOR_LANES(i, 12 * N) { const int k = i / 12, r = (i % 12) >> 1, c = i & 1; AB[k * 48 + r * 8 + 6 + c] = io.Bm[(size_t)b * 12 * N + i]; }
-        FOR_LANES_T(i, t, 6 * N) c_r[t] = io.C[(size_t)b * 6 * N + i];
+    if (preload) {
+        FOR_LANES_T(i, t, 36 * N) { const int k = i / 36, r = (i % 36) / 6, c = i % 6; AB[k * 48 + r * 8 + c] = preA[t]; }
+        FOR_LANES_T(i, t, 12 * N) { const int k = i / 12, r = (i % 12) >> 1, c = i & 1; AB[k * 48 + r * 8 + 6 + c] = preB[t]; }
     }
     double *Cs = sm + LL::oCs;                             // C_k for the roll-out below (scratch; afterwards C lives in c_r only)
     FOR_LANES_T(i, t, 6 * N) Cs[i] = c_r[t];
@@ -1133,16 +1158,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     FOR_LANES(i, 2 * N) u[i] = 0.0;
     const double uOld0 = wave_uniform(io.uOld[(size_t)b * 2 + 0]), uOld1 = wave_uniform(io.uOld[(size_t)b * 2 + 1]);
     __syncthreads();
-#pragma unroll 1
-    for (int k = 0; k < N; k++) {                          // strictly interior start: u = 0, x by roll-out
-        if (lane < 6) {
-            double v = Cs[k * 6 + lane];
-#pragma unroll
-            for (int j = 0; j < 6; j++) v = fma(AB[k * 48 + lane * 8 + j], x[k * 6 + j], v);
-            x[(k + 1) * 6 + lane] = v;
-        }
-        __syncthreads();
-    }
+    rollout_start<N>(AB, Cs, x, lane);                     // strictly interior start: u = 0, x by roll-out
+    __syncthreads();
     // Lane slacks: a row the roll-out violates starts one unit inside (s = violation + 1); every other slack starts at 1 / c_s, where
     // the multiplier of s >= 0 (mu0 / s) already balances the slack's linear cost c_s -- from s = 1 the first Newton steps were spent
     // driving ~2N slacks to zero against the positivity bound (11.0 -> 9.5 iterations on the bench batch, 12 -> 6 on the LTV-MPC QPs)
