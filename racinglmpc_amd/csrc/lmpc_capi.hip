@@ -34,6 +34,9 @@ struct lmpc_ctx {
     double *w_x0, *w_xLin, *w_uLin, *w_uOld, *w_zt, *w_xPP, *w_A, *w_B, *w_C, *w_ssSel, *w_qSel, *w_succ, *w_succU, *w_ztUsed;
     double *w_xPred, *w_uPred, *w_slack, *w_lam, *w_sT, *w_mu, *w_ztN, *w_ztuN, *w_resid;
     int *w_hasPred, *w_tstep, *w_status, *w_iters, *w_rstatus;
+    // the work buffers are ranges of two device slabs (inputs | outputs); small batches move each slab with ONE copy through pinned host
+    // mirrors (h_in / h_out) instead of one pageable copy per array -- 24 copies of ~10 us each were 60 % of a batch-1 lmpc_step_batch call
+    char *slab_in, *slab_out, *h_in, *h_out; size_t slab_in_bytes, slab_out_bytes;
     lmpc_variant_api var;                    // launchers of the (N, numSS_points) instantiation of the solve kernels in use
     void *var_dl;                            // dlopen handle when that instantiation lives in its own shared object (lmpc_variant.hip)
     int mw_max_batch, mw2_max_batch, n_cu;   // largest batch served by the four-wave / the two-wave solve kernel
@@ -127,6 +130,8 @@ static void fill_params(lmpc_ctx *c) {
 
 }  // extern "C" (helpers)
 
+#define LMPC_SLAB_COPY_MAX ((size_t)256 * 1024)     // one-copy path of lmpc_step_batch up to this many output bytes (batch 1 .. ~16)
+
 // everything of lmpc_create that can fail; the caller destroys the context on any error (one failure path, no leaks)
 static int create_body(lmpc_ctx *c) {
     const lmpc_config *cfg = &c->cfg;
@@ -169,14 +174,26 @@ static int create_body(lmpc_ctx *c) {
     HIPCHK(hipMemset(c->mqpar, 0, (size_t)cfg->max_laps * c->mq_chunks * 6 * sizeof(double)));
     HIPCHK(hipMemset(c->sstore, 0, store_elems * sizeof(double)));
     const size_t B = cfg->max_batch, N = cfg->N, S = cfg->numSS_it > 0 ? cfg->numSS_points : 0, M = 8 * N + S;
-#define DALLOC(ptr, n) HIPCHK(hipMalloc(&c->ptr, std::max<size_t>((n), 1) * sizeof(*c->ptr)))
-    DALLOC(w_x0, B * 6); DALLOC(w_xLin, B * (N + 1) * 6); DALLOC(w_uLin, B * N * 2); DALLOC(w_uOld, B * 2); DALLOC(w_zt, B * 6);
-    DALLOC(w_xPP, B * (N + 1) * 6); DALLOC(w_A, B * N * 36); DALLOC(w_B, B * N * 12); DALLOC(w_C, B * N * 6);
-    DALLOC(w_ssSel, B * S * 6); DALLOC(w_qSel, B * S); DALLOC(w_succ, B * S * 6); DALLOC(w_succU, B * S * 2); DALLOC(w_ztUsed, B * 6);
-    DALLOC(w_xPred, B * (N + 1) * 6); DALLOC(w_uPred, B * N * 2); DALLOC(w_slack, B * N * 2); DALLOC(w_lam, B * S); DALLOC(w_sT, B * 6);
-    DALLOC(w_mu, B * M); DALLOC(w_ztN, B * 6); DALLOC(w_ztuN, B * 2); DALLOC(w_resid, B * 3);
-    DALLOC(w_hasPred, B); DALLOC(w_tstep, B); DALLOC(w_status, B); DALLOC(w_iters, B); DALLOC(w_rstatus, B * N);
-#undef DALLOC
+    // two passes over the same list: sizes first, then pointers into the slabs (every range 256-byte aligned)
+    for (int pass = 0; pass < 2; pass++) {
+        size_t oi = 0, oo = 0;
+#define SLAB(ptr, n, slab, off) do { const size_t bytes_ = (std::max<size_t>((n), 1) * sizeof(*c->ptr) + 255) & ~(size_t)255; \
+                                     if (pass) c->ptr = (decltype(c->ptr))(c->slab + off); off += bytes_; } while (0)
+        SLAB(w_x0, B * 6, slab_in, oi); SLAB(w_xLin, B * (N + 1) * 6, slab_in, oi); SLAB(w_uLin, B * N * 2, slab_in, oi); SLAB(w_uOld, B * 2, slab_in, oi);
+        SLAB(w_zt, B * 6, slab_in, oi); SLAB(w_xPP, B * (N + 1) * 6, slab_in, oi); SLAB(w_hasPred, B, slab_in, oi); SLAB(w_tstep, B, slab_in, oi);
+        SLAB(w_xPred, B * (N + 1) * 6, slab_out, oo); SLAB(w_uPred, B * N * 2, slab_out, oo); SLAB(w_slack, B * N * 2, slab_out, oo); SLAB(w_lam, B * S, slab_out, oo);
+        SLAB(w_sT, B * 6, slab_out, oo); SLAB(w_ztN, B * 6, slab_out, oo); SLAB(w_ztuN, B * 2, slab_out, oo); SLAB(w_ssSel, B * S * 6, slab_out, oo);
+        SLAB(w_qSel, B * S, slab_out, oo); SLAB(w_mu, B * M, slab_out, oo); SLAB(w_A, B * N * 36, slab_out, oo); SLAB(w_B, B * N * 12, slab_out, oo);
+        SLAB(w_C, B * N * 6, slab_out, oo); SLAB(w_status, B, slab_out, oo); SLAB(w_iters, B, slab_out, oo); SLAB(w_resid, B * 3, slab_out, oo);
+        SLAB(w_succ, B * S * 6, slab_out, oo); SLAB(w_succU, B * S * 2, slab_out, oo); SLAB(w_ztUsed, B * 6, slab_out, oo); SLAB(w_rstatus, B * N, slab_out, oo);
+#undef SLAB
+        if (!pass) {
+            c->slab_in_bytes = oi; c->slab_out_bytes = oo;
+            HIPCHK(hipMalloc(&c->slab_in, oi)); HIPCHK(hipMalloc(&c->slab_out, oo));
+            HIPCHK(hipMemset(c->slab_in, 0, oi)); HIPCHK(hipMemset(c->slab_out, 0, oo));
+            if (oo <= LMPC_SLAB_COPY_MAX) { HIPCHK(hipHostMalloc(&c->h_in, oi)); HIPCHK(hipHostMalloc(&c->h_out, oo)); memset(c->h_in, 0, oi); }
+        }
+    }
     return LMPC_OK;
 }
 
@@ -213,10 +230,10 @@ int lmpc_destroy(lmpc_ctx *c) {
     rollout_free(c);
     if (c->comm) { (void)ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    void *ptrs[] = {c->mstore, c->sstore, c->mquant, c->mqpar, c->w_x0, c->w_xLin, c->w_uLin, c->w_uOld, c->w_zt, c->w_xPP, c->w_A, c->w_B, c->w_C, c->w_ssSel, c->w_qSel,
-                    c->w_succ, c->w_succU, c->w_ztUsed, c->w_xPred, c->w_uPred, c->w_slack, c->w_lam, c->w_sT, c->w_mu, c->w_ztN, c->w_ztuN, c->w_resid,
-                    c->w_hasPred, c->w_tstep, c->w_status, c->w_iters, c->w_rstatus};
+    void *ptrs[] = {c->mstore, c->sstore, c->mquant, c->mqpar, c->slab_in, c->slab_out};      // (the w_* work buffers are ranges of the two slabs)
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->var_dl) dlclose(c->var_dl);
     delete c;
@@ -540,6 +557,20 @@ int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, co
     const int N = c->cfg.N; const bool term = c->cfg.numSS_it > 0; const int S = term ? c->cfg.numSS_points : 0;
     if (term) ARGCHK(zt != nullptr);
     HIPCHK(hipSetDevice(c->cfg.device));
+    const bool one_copy = c->h_in && B == c->cfg.max_batch;          // small contexts (the drop-in classes: max_batch = 1): one copy each way
+    if (one_copy) {
+#define STAGE(wptr, src, n) memcpy(c->h_in + ((char *)c->wptr - c->slab_in), src, sizeof(*c->wptr) * (size_t)(n))
+        STAGE(w_x0, x0, (size_t)B * 6); STAGE(w_xLin, xLin, (size_t)B * (N + 1) * 6); STAGE(w_uLin, uLin, (size_t)B * N * 2); STAGE(w_uOld, uOld, (size_t)B * 2);
+        memset(c->h_in + ((char *)c->w_hasPred - c->slab_in), 0, sizeof(int) * B); memset(c->h_in + ((char *)c->w_tstep - c->slab_in), 0, sizeof(int) * B);
+        if (term) {
+            STAGE(w_zt, zt, (size_t)B * 6);
+            if (xPredPrev) STAGE(w_xPP, xPredPrev, (size_t)B * (N + 1) * 6);
+            if (hasPred && xPredPrev) STAGE(w_hasPred, hasPred, B);
+            if (timeStep) STAGE(w_tstep, timeStep, B);
+        }
+#undef STAGE
+        HIPCHK(hipMemcpyAsync(c->slab_in, c->h_in, c->slab_in_bytes, hipMemcpyHostToDevice, c->stream));
+    } else {
     H2D(c->w_x0, x0, (size_t)B * 6); H2D(c->w_xLin, xLin, (size_t)B * (N + 1) * 6); H2D(c->w_uLin, uLin, (size_t)B * N * 2); H2D(c->w_uOld, uOld, (size_t)B * 2);
     if (term) {
         H2D(c->w_zt, zt, (size_t)B * 6);
@@ -547,11 +578,28 @@ int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, co
         if (hasPred && xPredPrev) H2D(c->w_hasPred, hasPred, B); else HIPCHK(hipMemsetAsync(c->w_hasPred, 0, sizeof(int) * B, c->stream));
         if (timeStep) H2D(c->w_tstep, timeStep, B); else HIPCHK(hipMemsetAsync(c->w_tstep, 0, sizeof(int) * B, c->stream));
     }
+    }
     lmpc_step_dev_args a; memset(&a, 0, sizeof(a));
     a.x0 = c->w_x0; a.xLin = c->w_xLin; a.uLin = c->w_uLin; a.uOld = c->w_uOld; a.zt = c->w_zt; a.xPredPrev = c->w_xPP; a.hasPred = c->w_hasPred; a.timeStep = c->w_tstep;
     a.xPred = c->w_xPred; a.uPred = c->w_uPred; a.slack = c->w_slack; a.lambda = c->w_lam; a.sTerm = c->w_sT; a.ztNext = c->w_ztN; a.ztuNext = c->w_ztuN;
     a.ssSel = c->w_ssSel; a.qSel = c->w_qSel; a.A = c->w_A; a.Bm = c->w_B; a.C = c->w_C; a.mu = c->w_mu; a.resid = c->w_resid; a.status = c->w_status; a.iters = c->w_iters;
     int rc = lmpc_step_batch_dev(c, B, &a); if (rc) return rc;
+    if (one_copy) {
+        // everything up to (not including) the selection-only buffers w_succ ..: one copy into the pinned mirror, then plain memcpys
+        const size_t nbytes = (size_t)((char *)c->w_succ - c->slab_out);
+        HIPCHK(hipMemcpyAsync(c->h_out, c->slab_out, nbytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+#define UNSTAGE(dst, wptr, n) do { if (dst) memcpy(dst, c->h_out + ((char *)c->wptr - c->slab_out), sizeof(*c->wptr) * (size_t)(n)); } while (0)
+        UNSTAGE(xPred, w_xPred, (size_t)B * (N + 1) * 6); UNSTAGE(uPred, w_uPred, (size_t)B * N * 2); UNSTAGE(slack, w_slack, (size_t)B * N * 2);
+        if (term) { UNSTAGE(lambda, w_lam, (size_t)B * S); UNSTAGE(sTerm, w_sT, (size_t)B * 6); UNSTAGE(ssSel, w_ssSel, (size_t)B * S * 6); UNSTAGE(qSel, w_qSel, (size_t)B * S); }
+        UNSTAGE(mu, w_mu, (size_t)B * (8 * N + S)); UNSTAGE(ztNext, w_ztN, (size_t)B * 6); UNSTAGE(ztuNext, w_ztuN, (size_t)B * 2);
+        UNSTAGE(Aout, w_A, (size_t)B * N * 36); UNSTAGE(Bout, w_B, (size_t)B * N * 12); UNSTAGE(Cout, w_C, (size_t)B * N * 6);
+        UNSTAGE(status, w_status, B); UNSTAGE(resid, w_resid, (size_t)B * 3); UNSTAGE(iters, w_iters, B);
+#undef UNSTAGE
+        const int *it_ = (const int *)(c->h_out + ((char *)c->w_iters - c->slab_out));
+        for (int b = 0; b < B; b++) c->stats.ipm_iters += it_[b];
+        return LMPC_OK;
+    }
     D2H(xPred, c->w_xPred, (size_t)B * (N + 1) * 6); D2H(uPred, c->w_uPred, (size_t)B * N * 2); D2H(slack, c->w_slack, (size_t)B * N * 2);
     if (term) { D2H(lambda, c->w_lam, (size_t)B * S); D2H(sTerm, c->w_sT, (size_t)B * 6); D2H(ssSel, c->w_ssSel, (size_t)B * S * 6); D2H(qSel, c->w_qSel, (size_t)B * S); }
     D2H(mu, c->w_mu, (size_t)B * (8 * N + S));
