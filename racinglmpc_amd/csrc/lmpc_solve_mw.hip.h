@@ -413,6 +413,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 }
             }
             WSYNC();
+            TSMW(110);
         } else {
             double rmax = 0.0, remax = 0.0, lsum = 0.0;
             FOR_HELP(i, 6 * (N + 1), 0) {                     // stationarity rows of x_k
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             double gsum = gsum_c;
             if (wave == 1) gsum += gs0[lane];                // (written by wave 0 together with the step, a barrier ago)
             red_put(0, wsum(gsum)); red_put(1, wmax(rmax)); red_put(2, wsum(lsum)); red_put(3, wmax(remax));
+            TSMW(111);
         }
         __syncthreads();                                     // B1
         {

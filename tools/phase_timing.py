@@ -31,7 +31,7 @@ ids_all, cyc_all = tb[0::2], tb[1::2]
 ids, cyc = ids_all[:4000], cyc_all[:4000]
 n = int(np.argmax(ids == 21)) + 1
 ids, cyc = ids[:n], cyc[:n]
-names = {(0, 1): "prologue+select", (1, 10): "init (load, rollout)", (10, 11): "residuals", (11, 12): "factor: terminal (MGS2, Ri, PiT)",
+names = {(10, 110): "mw phase 1: wave 0's terminal factor", (110, 12): "mw phase 1: wave 0 waits for the helpers / convergence test", (0, 1): "prologue+select", (1, 10): "init (load, rollout)", (10, 11): "residuals", (11, 12): "factor: terminal (MGS2, Ri, PiT)",
          (12, 13): "factor: stages", (13, 30): "solve A: pre", (30, 31): "solve: backward sweep", (31, 32): "solve: k0/phi", (32, 33): "solve: forward sweep",
          (33, 14): "solve A: post", (14, 15): "predictor post (steps, sigma, h)", (15, 30): "solve B: pre", (33, 16): "solve B: post",
          (10, 12): "mw phase 1: terminal factor || residuals + predictor rhs", (12, 19): "mw phase 2: Riccati stages || predictor back-sweep + phi one stage behind", (19, 13): "mw phase 2: last pipeline step",
@@ -57,3 +57,14 @@ if os.environ.get("LMPC_TIMING_MW"):
             wi, wc = ids_all[4000 * w:4000 * (w + 1)], cyc_all[4000 * w:4000 * (w + 1)]
             sel = (wc > base) & (wc < t13[1] + 2000) & (wi >= 200)
             print("wave %d:" % w, " ".join("%d@%d" % (i, c - base) for i, c in zip(wi[sel], wc[sel])))
+
+    # phase 1 of the second iteration: when wave 0 (terminal factor) and the helper waves (residuals) reach the barrier, relative to stamp 10
+    t10 = cyc[ids == 10]; t110 = cyc[ids == 110]
+    if len(t10) > 1 and len(t110) > 1:
+        msg = ["wave 0 +%d" % (t110[1] - t10[1])]
+        for w in (1, 2, 3):
+            wi, wc = ids_all[4000 * w:4000 * (w + 1)], cyc_all[4000 * w:4000 * (w + 1)]
+            sel = (wi == 111) & (wc > t10[1])
+            if sel.any():
+                msg.append("wave %d +%d" % (w, wc[sel][0] - t10[1]))
+        print("phase 1 arrivals at the barrier (iteration 1): " + ", ".join(msg))
