@@ -4,6 +4,7 @@ class exactly as tests/golden/make_golden.py does (same stand-ins for cvxopt.qp 
   lmpc_wide_n12.npz   N = 12, numSS_it = 6, numSS_Points = 72: a safe set WIDER than one wavefront (72 + 6 terminal columns > 64 lanes)
   lmpc_n14.npz        N = 14, numSS_it = 4, numSS_Points = 48: the horizon main.py itself uses (main.py:43)
   lmpc_n40.npz        N = 40, numSS_it = 4, numSS_Points = 48: BASELINE.json configs[4]'s horizon (8 steps)
+  mpc_n14.npz         N = 14: main.py's stage 2 (LTI MPC on Utilities.Regression's A, B) and stage 3 (LTV MPC), ten closed-loop steps each
   lmpc_30laps_n12.npz N = 12, 30 PID laps of different speeds in both stores (BASELINE.json configs[2]): sorted insert, the four fastest
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_wide_golden.py          (needs /root/reference)
@@ -152,9 +153,61 @@ def make_30laps(PC, ICP, PM, SM, TR, UT, fname="lmpc_30laps_n12.npz", steps=10):
         len(recs), min(lmpc.LapTime), max(lmpc.LapTime), list(out["modelOrder"][:6]), list(np.argsort(lmpc.LapTime)[:4]), out["cert_opt"].max()))
 
 
+def make_mpc_n14(PC, ICP, PM, SM, TR, UT, fname="mpc_n14.npz", steps=10):
+    """main.py:71-94 at its own horizon N = 14: stage 2, the LTI MPC on (A, B) from Utilities.Regression (lamb = 1e-7), and stage 3, the LTV
+    MPC on the local regressions around the shifted prediction; ten closed-loop steps each from x0 = [0.5, 0, 0, 0, 0, 0]."""
+    N, n, d, vt = 14, 6, 2, 0.8
+    x0 = np.array([0.5, 0, 0, 0, 0, 0]); xS = [x0, x0]
+    np.random.seed(0)
+    map_ = TR.Map(0.4)
+    simulator = SM.Simulator(map_)
+    xPID, uPID, xPID_glob, _ = simulator.sim(xS, UT.PID(vt))
+    mpcParam, ltvmpcParam = ICP.initMPCParams(n, d, N, vt)
+    A_lti, B_lti, _err = UT.Regression(xPID, uPID, 0.0000001)
+    mpcParam.A = A_lti; mpcParam.B = B_lti
+    out = dict(xPID=xPID.copy(), uPID=uPID.copy(), track=map_.PointAndTangent.copy(), trackLength=map_.TrackLength, N=N, A_lti=A_lti.copy(), B_lti=B_lti.copy())
+    for tag, ctrl in (("lti", PC.MPC(mpcParam)), ("ltv", None)):
+        if ctrl is None:
+            pm1 = PM.PredictiveModel(n, d, map_, 1)
+            pm1.addTrajectory(xPID.copy(), uPID.copy())
+            ltvmpcParam.timeVarying = True
+            ctrl = PC.MPC(ltvmpcParam, pm1)
+        recs = []
+        np.random.seed(1)
+        xc, xg = x0.copy(), x0.copy()
+        for t in range(steps):
+            rec = dict(x0=xc.copy(), OldInput=np.array(ctrl.OldInput, float).reshape(-1).copy())
+            if tag == "ltv":
+                rec.update(xLin=np.array(ctrl.xLin).copy(), uLin=np.array(ctrl.uLin).copy())
+            mg.CAPTURE.clear()
+            ctrl.solve(xc)
+            P, q, A, l, u, sol, y, status, it_, sp = mg.CAPTURE[-1]
+            if tag == "ltv":
+                rec.update(A=np.array(ctrl.A), B=np.array(ctrl.B), C=np.array(ctrl.C))
+            rec.update(q=q, l=l, u=u, status=status)
+            rec["Pp"], rec["Pi"], rec["Px"] = mg.csc_parts(P)
+            rec["Ap"], rec["Ai"], rec["Ax"] = mg.csc_parts(A)
+            ex, cert = orc.osqp_solve_exact(P, q, A, l, u)
+            rec["sol_opt"], rec["cert_opt"] = ex.x, cert
+            recs.append(rec)
+            uo = ex.x[n * (N + 1):n * (N + 1) + d * N].reshape(N, d); xo = ex.x[:n * (N + 1)].reshape(N + 1, n)
+            # carry on from the certified optimum (MPC.solve's tail, :131-137, with the optimum in place of the eps = 1e-3 answer)
+            ctrl.xPred, ctrl.uPred = xo.copy(), uo.copy()
+            ctrl.zt, ctrl.zt_u = xo[-1, :].copy(), uo[-1, :].copy()
+            if tag == "ltv":
+                ctrl.xLin = np.vstack((xo[1:, :], ctrl.zt)); ctrl.uLin = np.vstack((uo[1:, :], ctrl.zt_u))
+            ctrl.OldInput = uo[0, :].copy()
+            xc, xg = simulator.dynModel(xc, xg, uo[0, :].copy())
+        for k in recs[0].keys():
+            out[tag + "_" + k] = mg.stack([r[k] for r in recs])
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname + ": %d + %d steps, nz = %d, certificates <= %.1e / %.1e" % (steps, steps, out["lti_q"].shape[1], out["lti_cert_opt"].max(), out["ltv_cert_opt"].max()))
+
+
 def main():
     mg.install_standins()
     ref = mg.load_reference()
+    make_mpc_n14(*ref)
     make_30laps(*ref)
     make(*ref, 12, 6, "lmpc_wide_n12.npz")
     make(*ref, 14, 4, "lmpc_n14.npz")

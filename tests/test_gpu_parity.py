@@ -206,6 +206,42 @@ def test_ltv_mpc_variant(built):
     ctx.close()
 
 
+def test_mpc_n14_matches_reference(built):
+    """main.py's stages 2 and 3 at N = 14 against the executed reference (mpc_n14.npz): Utilities.Regression's (A, B) from the HIP kernel, the LTI
+    MPC's optimum on them, the LTV MPC's regressions and optimum; explicit matrices of both bit-exact."""
+    from racinglmpc_amd import _capi, Utilities
+    g = dict(np.load(common.GOLDEN + "/mpc_n14.npz"))
+    N = int(g["N"]); nxu = 6 * (N + 1) + 2 * N
+    A2, B2, _E = Utilities.Regression(g["xPID"], g["uPID"], 0.0000001)
+    assert max((np.abs(A2 - g["A_lti"]) / (1 + np.abs(g["A_lti"]))).max(), (np.abs(B2 - g["B_lti"]) / (1 + np.abs(g["B_lti"]))).max()) < 1e-7
+    cfg, par = common.mpc_config(g, N, max_batch=16)
+    ctx = _capi.Context(cfg)
+    ctx.model_add_trajectory(g["xPID"], g["uPID"])
+    R = g["lti_x0"].shape[0]
+    At = np.tile(g["A_lti"][None, None], (R, N, 1, 1)); Bt = np.tile(g["B_lti"][None, None], (R, N, 1, 1)); Ct = np.zeros((R, N, 6))
+    out = ctx.qp_solve_batch(At, Bt, Ct, g["lti_x0"], g["lti_OldInput"])
+    assert np.all(out["status"] == 0)
+    w = np.concatenate([out["xPred"].reshape(R, -1), out["uPred"].reshape(R, -1)], axis=1)
+    e_lti = np.abs(w - g["lti_sol_opt"][:, :nxu]).max()
+    P, q, A, l, u = ctx.assemble_batch(At, Bt, Ct, g["lti_x0"], g["lti_OldInput"])
+    for r in range(R):
+        Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="lti_")
+        assert np.array_equal(P[r], Pr) and np.array_equal(A[r], Ar) and np.array_equal(q[r], qr) and np.array_equal(l[r], lr) and np.array_equal(u[r], ur)
+    out = ctx.step_batch(g["ltv_x0"], g["ltv_xLin"], g["ltv_uLin"], g["ltv_OldInput"])
+    assert np.all(out["status"] == 0)
+    for got, ref in ((out["A"], g["ltv_A"]), (out["B"], g["ltv_B"]), (out["C"], g["ltv_C"])):
+        assert (np.abs(got - ref) / (1 + np.abs(ref))).max() < common.TOL_ABC
+    w = np.concatenate([out["xPred"].reshape(R, -1), out["uPred"].reshape(R, -1)], axis=1)
+    e_ltv = np.abs(w - g["ltv_sol_opt"][:, :nxu]).max()
+    P, q, A, l, u = ctx.assemble_batch(g["ltv_A"], g["ltv_B"], g["ltv_C"], g["ltv_x0"], g["ltv_OldInput"])
+    for r in range(R):
+        Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="ltv_")
+        assert np.array_equal(P[r], Pr) and np.array_equal(A[r], Ar) and np.array_equal(q[r], qr) and np.array_equal(l[r], lr) and np.array_equal(u[r], ur)
+    print("N = 14: LTI MPC |xu - opt| %.2e, LTV MPC |xu - opt| %.2e" % (e_lti, e_ltv))
+    assert e_lti < common.TOL_XU and e_ltv < common.TOL_XU
+    ctx.close()
+
+
 def test_mpc_hard_lane_constraints(built):
     """MPCParams(slacks=False) (PredictiveControllers.py:184-198, 218-221, 248-254): no slack variables, hard lane rows.  Fixture recorded from the
     executed reference class (tests/golden/make_noslack_golden.py; lane half-width 1 cm so that up to five hard rows are active):

@@ -193,3 +193,22 @@ def test_30_lap_stores_restatement_matches_reference():
         P, q, Aq, l, u = orc.assemble_lmpc_qp(par, g["A"][r], g["B"][r], g["C"][r], g["x0"][r], g["OldInput"][r], SSsel, Qsel)
         Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="")
         assert np.array_equal(P, Pr) and np.array_equal(q, qr) and np.array_equal(Aq, Ar) and np.array_equal(l, lr) and np.array_equal(u, ur)
+
+
+def test_mpc_n14_restatement_matches_reference():
+    """main.py's stages 2 and 3 at its own horizon N = 14, recorded from the executed reference (mpc_n14.npz): LTI MPC on Utilities.Regression's
+    (A, B), LTV MPC on the local regressions -- assembled QPs bit-exact, regressions to 1e-10."""
+    g = dict(np.load(common.GOLDEN + "/mpc_n14.npz"))
+    N = int(g["N"])
+    par = orc.QPParams.mpc_default(N, 0.8)
+    for r in range(g["lti_x0"].shape[0]):
+        P, q, A, l, u = orc.assemble_mpc_qp(par, g["A_lti"], g["B_lti"], None, g["lti_x0"][r], g["lti_OldInput"][r])
+        Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="lti_")
+        assert np.array_equal(P, Pr) and np.array_equal(q, qr) and np.array_equal(A, Ar) and np.array_equal(l, lr) and np.array_equal(u, ur)
+    for r in range(g["ltv_x0"].shape[0]):
+        A, B, C = orc.compute_ltv_dynamics([g["xPID"]], [g["uPID"]], [0], g["track"], g["ltv_xLin"][r], g["ltv_uLin"][r], N)
+        for got, ref in ((A, g["ltv_A"][r]), (B, g["ltv_B"][r]), (C, g["ltv_C"][r])):
+            assert (np.abs(got - ref) / (1 + np.abs(ref))).max() < 1e-10
+        P, q, Aq, l, u = orc.assemble_mpc_qp(par, list(g["ltv_A"][r]), list(g["ltv_B"][r]), list(g["ltv_C"][r]), g["ltv_x0"][r], g["ltv_OldInput"][r])
+        Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="ltv_")
+        assert np.array_equal(P, Pr) and np.array_equal(q, qr) and np.array_equal(Aq, Ar) and np.array_equal(l, lr) and np.array_equal(u, ur)
