@@ -172,6 +172,13 @@ __device__ __forceinline__ double frcp(double x) {
 //    iterate is still far from the path (one 38-iteration stall in 1024 problems of the NumPy model); gated it never fired there.
 //  * separate primal / dual step lengths after an iteration whose gap shrank by less than 1 / LMPC_SEP_THRESHOLD.
 #define LMPC_SEP_THRESHOLD 0.1
+// Barrier weights theta = mu / t are capped at 1e11 in the Newton matrix: 1 / theta >= 1e-11 is a dual regularisation of the inequality row
+// (F dw + (1 / theta_c) dmu = -r_c / mu); the right-hand side uses the same effective reciprocal rt = 1 / max(t, 1e-11 mu), so the fixed
+// point does not move and the row's equation is off by 1e-11 dmu only.  Uncapped, an active lane row (t ~ 1e-14, mu ~ 10: main.py's fast
+// laps, ey on the lane boundary) puts 1e15 into a stage Hessian whose other entries are O(1) and the Riccati recursion loses the regular
+// part of the cost-to-go to rounding: the dual residual stalls at 1e-7 and the iteration wanders off (tests/ipm_model.py, tools/ipm_model_sets.py).
+#define LMPC_TH_INV 1e-11
+__device__ __forceinline__ double barrier_rt(double t, double mu) { return frcp(fmax(t, mu * LMPC_TH_INV)); }
 __device__ __forceinline__ double step_fraction(double sig, double gap) { return sig < 1e-3 ? fmax(0.995, 1.0 - 10.0 * gap) : 0.995; }
 
 __device__ __forceinline__ double frsqrt(double x) {
@@ -1368,7 +1375,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
             const int r = lane + WAVE * j;
-            if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; gsum = fma(tt, m[r], gsum); }
+            if (r < M) gsum = fma(t_r[j], m[r], gsum);      // (the row slacks are iterates of their own: t <- t + alpha dt at the step, never b - F w)
         }
         if constexpr (term) ss_times<S>(SS, lam, x + N * 6, sT, lane);
         FOR_LANES_T(i, t, 6 * N) nu[i] = nu_r[t];               // (scratch is free between the step and the factorisation)
@@ -1429,7 +1436,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         TSTAMP(11);
         // ---- factorisation of the Newton (block-banded KKT) matrix -------------------------------------
 #pragma unroll
-        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) th[r] = m[r] * frcp(t_r[j]); }
+        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) th[r] = m[r] * barrier_rt(t_r[j], m[r]); }
         __syncthreads();
         FOR_LANES_T(i, t, 2 * N) {
             const double d_ = frcp(a_s + th[i] + th[6 * N + i]);
@@ -1545,7 +1552,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
 
         TSTAMP(13);
         // ---- predictor (affine scaling) direction: h = mu -------------------------------------------------
-        FOR_LANES(r, M) h[r] = m[r];
+#pragma unroll
+        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) h[r] = t_r[j] * th[r]; }      // t mu rt: mu itself wherever the weight is not capped
         __syncthreads();
         kkt_solve(re_sum);
         TSTAMP(14);
@@ -1555,7 +1563,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             const int r = lane + WAVE * j; dma_r[j] = 0.0;
             if (r < M) {
                 const double dta = -rowF(r, dx, du, ds, dl), mr = m[r];
-                const double dma = -mr - th[r] * dta;
+                const double dma = -h[r] - th[r] * dta;
                 dt_r[j] = dta; dma_r[j] = dma;
                 if (dta < 0.0) apmax = fmin(apmax, -t_r[j] * frcp(dta));
                 if (dma < 0.0) admax = fmin(admax, -mr * frcp(dma));
@@ -1575,7 +1583,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         // ---- corrector: h = (t mu - sigma gap + dt_aff dmu_aff) / t ----------------------------------------
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) h[r] = m[r] + (tp_r[j] - tgt) * frcp(t_r[j]); }
+        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) { const double mr = m[r]; h[r] = (fma(t_r[j], mr, tp_r[j]) - tgt) * barrier_rt(t_r[j], mr); } }
         __syncthreads();
         TSTAMP(15);
         kkt_solve(re_sum);
@@ -1587,8 +1595,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
             if (r < M) {
                 const double dtt = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dmm = -h[r] - th[r] * dtt;
-                dm[r] = dmm;
-                if constexpr (EQ) dt_r[j] = dtt;
+                dm[r] = dmm; dt_r[j] = dtt;
                 if (dtt < 0.0) apx = fmin(apx, -t_r[j] * frcp(dtt));
                 if (dmm < 0.0) adx = fmin(adx, -mr * frcp(dmm));
             }
@@ -1642,7 +1649,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
         FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
         FOR_LANES(i, 2 * N) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
         if constexpr (term) { FOR_LANES(c, S) lam[c] = fma(al, dl[c], lam[c]); }
-        FOR_LANES(r, M) m[r] = fma(ald, dm[r], m[r]);
+#pragma unroll
+        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) { m[r] = fma(ald, dm[r], m[r]); t_r[j] = fma(al, dt_r[j], t_r[j]); } }
         {
             double aa[N], tm[N];
 #pragma unroll

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     __shared__ int st_sh, bad_sh;
     __shared__ double gs0[WAVE];                             // wave 0's per-lane share of sum t mu (it does not take part in the residual reductions)
     __shared__ int sel_start[LMPC_MAX_USED_LAPS];
+    __shared__ double ss_rowsum[6];                          // sum over the selected safe-set points of each state (loop invariant)
     double *phi = phi_sh;
     if (tid == 0) { st_sh = 0; bad_sh = 0; }
     // stage the parameter block
@@ -77,7 +78,10 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     auto red_min = [&](int slot) { double r = red[slot * 4]; for (int w = 1; w < NW; w++) r = fmin(r, red[slot * 4 + w]); return r; };
 
     // K2: safe-set selection, one lap per wave (k2_select, lmpc_kernels.hip.h), then the regression status bits of this problem
-    if constexpr (term) { k2_select<N, S, NW>(p, io, b, lane, wave, SS, Qsel, sel_start, &st_sh); __syncthreads(); }
+    if constexpr (term) {
+        k2_select<N, S, NW>(p, io, b, lane, wave, SS, Qsel, sel_start, &st_sh); __syncthreads();
+        if (tid < 6) { double v = 0.0; for (int c = 0; c < S; c++) v += SS[tid * S + c]; ss_rowsum[tid] = v; }
+    }
     if (io.rstatus && tid < N) { const int rs_ = io.rstatus[(size_t)b * N + tid]; if (rs_) atomicOr(&st_sh, rs_); }
     if (!(io.mode & 2)) { if (tid == 0) io.status[b] = st_sh; return; }
 
@@ -137,13 +141,18 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     // carried from iteration to iteration by the thread that owns the row (t <- t + alpha dt with dt = -F dw: the rows are linear, and the
     // update keeps the relative accuracy of a slack that has shrunk to 1e-13, which b - F w recomputed from the iterate does not); the
     // terminal slack likewise (s_T <- s_T + alpha ds_T).  One pass over the rows per iteration, together with the step, instead of three.
+    // rt is the EFFECTIVE reciprocal 1 / max(t, 1e-11 mu) (barrier weight capped at 1e11, see LMPC_TH_INV): matrix (theta = mu rt) and right-hand
+    // sides (predictor h = t mu rt, corrector h = (t mu + dt dmu - sigma gap) rt) use the same one, so the capped row is a regularised row.
     double t_r[RPL], rt_r[RPL], tp_r[RPL], dt_r[RPL];
     double gsum_c = 0.0;                                   // this thread's share of sum t mu (the complementarity gap)
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
         const int r = tid + NT * j;
         t_r[j] = 1.0; rt_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
-        if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam), mm = mu0 / tt; t_r[j] = tt; m[r] = mm; rt_r[j] = frcp(tt); th[r] = mm * rt_r[j]; gsum_c = fma(tt, mm, gsum_c); }
+        if (r < M) {
+            const double tt = rowb(r) - rowF(r, x, u, s, lam), mm = mu0 / tt; t_r[j] = tt; m[r] = mm;
+            rt_r[j] = barrier_rt(tt, mm); th[r] = mm * rt_r[j]; h[r] = tt * th[r]; gsum_c = fma(tt, mm, gsum_c);      // h: the predictor's right-hand side, see the step
+        }
     }
     if (w0) gs0[lane] = gsum_c;                            // wave 0's share of sum t mu: folded into the gap by wave 1 (wave 0 skips the residual reductions)
     if constexpr (term) { if (wave == NW - 1) ss_times<S>(SS, lam, x + N * 6, sT, lane); }      // terminal slack s_T = SS lambda - x_N
@@ -438,21 +447,21 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 const double up = k > 0 ? u[(k - 1) * 2 + c] : (c == 0 ? uOld0 : uOld1);
                 double v = R2[c * 2] * u[k * 2] + R2[c * 2 + 1] * u[k * 2 + 1] + dR2[c] * (u[i] - up);
                 if (k < N - 1) v += dR2[c] * (u[i] - u[(k + 1) * 2 + c]);
-                double fh = 0.0;
+                double fh = 0.0, fhp = 0.0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) fh = fma(Fu[j * 2 + c], m[2 * N + 4 * k + j], fh);
+                for (int j = 0; j < 4; j++) { fh = fma(Fu[j * 2 + c], m[2 * N + 4 * k + j], fh); fhp = fma(Fu[j * 2 + c], h[2 * N + 4 * k + j], fhp); }
                 v += fh;
 #pragma unroll
                 for (int j = 0; j < 6; j++) v -= AB[k * 48 + j * 8 + 6 + c] * nu[k * 6 + j];
                 ru[i] = v; rmax = fmax(rmax, fabs(v));
-                gup[i] = v - fh;                              // gu' = ru - Fu' h_u with h = mu
+                gup[i] = v - fhp;                             // gu' = ru - Fu' h_u with the predictor's h (= mu wherever the weight is not capped)
                 const double ml = m[i], ms = m[6 * N + i];
                 const double vs = a_s * s[i] + c_s - ml - ms;
                 rs[i] = vs; rmax = fmax(rmax, fabs(vs));
                 const double d_ = frcp(a_s + th[i] + th[6 * N + i]);
                 rDs[i] = d_; kap[i] = th[i] * (a_s + th[6 * N + i]) * d_;
-                const double e_ = -(vs + ml + ms);
-                ee[i] = e_; eta[i] = ml + th[i] * e_ * d_;
+                const double hl = h[i], e_ = -(vs + hl + h[6 * N + i]);
+                ee[i] = e_; eta[i] = hl + th[i] * e_ * d_;
             }
             if constexpr (term) {
                 FOR_HELP(c, S, 6 * (N + 1) + 2 * N) {
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
 #pragma unroll
                     for (int ch = 0; ch < CH; ch++) {
                         const int col = lane + WAVE * ch;
-                        ct[col] = col < S ? (rl[col] + m[8 * N + col]) * rsq[col] : 0.0;
+                        ct[col] = col < S ? (rl[col] + h[8 * N + col]) * rsq[col] : 0.0;
                     }
                     WSYNC();
                     double acc = 0.0;                               // M c~ : lane (j, part) adds every 8th of the 64 CH columns
@@ -637,7 +646,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             const int r = tid + NT * j; dma_r[j] = 0.0;
             if (r < M) {
                 const double dta = -rowF(r, dx, du, ds, dl), mr = m[r];
-                const double dma = -mr - th[r] * dta;
+                const double dma = -h[r] - th[r] * dta;
                 dt_r[j] = dta; dma_r[j] = dma;
                 if (dta < 0.0) apmax = fmin(apmax, -t_r[j] * frcp(dta));
                 if (dma < 0.0) admax = fmin(admax, -mr * frcp(dma));
@@ -661,11 +670,11 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         TSMW(15);
         // ---- corrector ---------------------------------------------------------------------------------------
 #pragma unroll
-        for (int j = 0; j < RPL; j++) { const int r = tid + NT * j; if (r < M) h[r] = m[r] + (tp_r[j] - tgt) * rt_r[j]; }
+        for (int j = 0; j < RPL; j++) { const int r = tid + NT * j; if (r < M) h[r] = (fma(t_r[j], m[r], tp_r[j]) - tgt) * rt_r[j]; }
         __syncthreads();
         kkt_solve(re_sum);
         TSMW(16);
-        double apx = INFINITY, adx = INFINITY;
+        double apx = INFINITY, adx = INFINITY, dsum = 0.0;   // dsum: this thread's lambda rows' share of the step of the multiplier of sum(lambda) = 1
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
             const int r = tid + NT * j;
@@ -675,9 +684,11 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 dm[r] = dmm; dt_r[j] = dtt;
                 if (dtt < 0.0) apx = fmin(apx, -t_r[j] * frcp(dtt));
                 if (dmm < 0.0) adx = fmin(adx, -mr * frcp(dmm));
+                if constexpr (term) { if (r >= 8 * N) dsum += dmm - rl[r - 8 * N]; }
             }
         }
         red_put(7, wmin(apx)); red_put(8, wmin(adx));
+        if constexpr (term) red_put(10, wsum(dsum));
         if constexpr (term) { if (wave == NW - 1) ss_times<S>(SS, dl, dx + N * 6, w7, lane); }          // d s_T
         __syncthreads();
         const double frac = step_fraction(sig, gap);
@@ -703,15 +714,14 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             }
             nu[i] = fma(ald, -g, nu[i]);
         }
+        // multiplier of sum(lambda) = 1: mean over the lambda rows of  -rl_c + dmu_c - SS_c' T ds_T;  the rows' owners summed the first two
+        // terms above, the third is sum_j T_j ds_T[j] (sum_c SS[j][c]) with the row sums of SS formed once (every thread: same value)
+        double deta = 0.0;
         if constexpr (term) {
-            if (wave == NW - 1) {                                // multiplier of sum(lambda) = 1: mean over the lambda rows
-                double v = 0.0;
-                for (int c = lane; c < S; c += WAVE) { v += -rl[c] + dm[8 * N + c];
+            deta = red_sum(10);
 #pragma unroll
-                    for (int j = 0; j < 6; j++) v -= SS[j * S + c] * T2p[j] * w7[j]; }
-                v = wsum(v) / (double)S;
-                if (lane == 0) red[9 * 4] = v;
-            }
+            for (int j = 0; j < 6; j++) deta -= T2p[j] * w7[j] * ss_rowsum[j];
+            deta /= (double)S;
         }
         FOR_OFF(i, 6 * (N + 1), O1) x[i] = fma(al, dx[i], x[i]);
         FOR_OFF(i, 2 * N, O2) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
@@ -722,13 +732,14 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             const int r = tid + NT * j;
             if (r < M) {
                 const double tt = fma(al, dt_r[j], t_r[j]), mm = fma(ald, dm[r], m[r]);
-                t_r[j] = tt; m[r] = mm; rt_r[j] = frcp(tt); th[r] = mm * rt_r[j]; gsum_c = fma(tt, mm, gsum_c);
+                t_r[j] = tt; m[r] = mm; rt_r[j] = barrier_rt(tt, mm); th[r] = mm * rt_r[j]; gsum_c = fma(tt, mm, gsum_c);
+                h[r] = tt * th[r];                              // next predictor's right-hand side (dm[r], which shares the place, was consumed one line up)
             }
         }
         if (w0) gs0[lane] = gsum_c;
         if constexpr (term) { if (tid < 6) sT[tid] = fma(al, w7[tid], sT[tid]); }
         __syncthreads();
-        if constexpr (term) eta_m = fma(ald, red[9 * 4], eta_m);
+        if constexpr (term) eta_m = fma(ald, deta, eta_m);
         TSMW(18);
     }
     if (!converged && tid == 0 && !(st_sh & (LMPC_ST_NUMERIC | LMPC_ST_INEXACT)))

@@ -128,7 +128,7 @@ def kkt_solve(qp, f, th_lane, th_s, gx, gu, gs, h_lane, h_u, h_s, gl, re_dyn, re
     return dx, du, ds, dl
 
 
-def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=False):
+def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True):
     """Returns dict(x,u,s,lam,sT, mu (ineq duals in reference row order), iters, gap, rd, re)."""
     par = qp.par; N = qp.N; S = qp.S; Fx, Fu = par.Fx, par.Fu; bx, bu = par.bx, par.bu
     dR2 = 2 * par.dR; a = 2 * par.Qslack[0]; c1 = par.Qslack[1]
@@ -154,7 +154,8 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=Fa
     sep = False; gap_prev = None          # separate primal/dual steps only after an iteration with poor progress
     qscale = max(1.0, float(np.max(np.abs(qp.Qsel)))) if qp.term else 1.0
     for it in range(maxit):
-        t_lane, t_u, t_s, t_l = slacks()
+        if not carry_t or it == 0:
+            t_lane, t_u, t_s, t_l = slacks()       # (carry_t: the row slacks are iterates of their own, t += alpha dt, never a difference of O(1) numbers)
         gap = (t_lane.ravel() @ m_lane.ravel() + t_u.ravel() @ m_u.ravel() + t_s.ravel() @ m_s.ravel() + t_l @ m_l) / mtot
         if gap_prev is not None:
             sep = gap > 0.1 * gap_prev
@@ -182,19 +183,26 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=Fa
         info = dict(iters=it, gap=gap, rd=rd, re=re)
         if gap < tol_gap and rd < tol_res * qscale and re < tol_res:
             break
-        th_lane, th_u, th_s, th_l = m_lane / t_lane, m_u / t_u, m_s / t_s, (m_l / t_l if qp.term else np.zeros(0))
+        ts = (t_lane, t_u, t_s, t_l); ms = (m_lane, m_u, m_s, m_l)
+        # Barrier weights theta = mu / t are capped at th_max in the Newton matrix: 1 / theta >= 1 / th_max is a dual regularisation of the row
+        # (F dw + (1 / theta_c) dmu = -r_c / mu), so the right-hand side uses the same effective reciprocal rt = 1 / max(t, mu / th_max) as the
+        # matrix and the fixed point does not move.  Uncapped, an active lane row (t ~ 1e-14, mu ~ 10) puts 1e15 into a stage Hessian whose
+        # other entries are O(1): the Riccati recursion then loses the regular part of the cost-to-go to rounding (main.py's fast laps).
+        cap = (lambda t, m: np.maximum(t, m / th_max)) if th_max is not None else (lambda t, m: t)
+        rts = [1.0 / cap(t, m) if t.size else t for t, m in zip(ts, ms)]
+        th_lane, th_u, th_s, th_l = ths = [m * rt for m, rt in zip(ms, rts)]
         f = kkt_factor(qp, th_lane, th_u, th_s, th_l, reg_l)
         # terminal slack eliminated: its Hessian T enters W7 through T^-1 (kept in factor)
         def solve(h_lane, h_u, h_s, h_l):
             return kkt_solve(qp, f, th_lane, th_s, rx, ru, rs, h_lane, h_u, h_s, rl + h_l, re_dyn, re_sum)
         # predictor: h = mu
-        dxa, dua, dsa, dla = solve(m_lane, m_u, m_s, m_l)
+        hp = [t * m * rt for t, m, rt in zip(ts, ms, rts)]                # (= mu wherever the weight is not capped)
+        dxa, dua, dsa, dla = solve(*hp)
         def ineq_steps(dx, du, ds, dl):
             fl = dx[:N] @ Fx.T
             return -(fl - ds), -(du @ Fu.T), ds, (dl if qp.term else np.zeros(0))
         dt = ineq_steps(dxa, dua, dsa, dla)
-        ts = (t_lane, t_u, t_s, t_l); ms = (m_lane, m_u, m_s, m_l); ths = (th_lane, th_u, th_s, th_l)
-        dma = [-m - th * d for m, th, d in zip(ms, ths, dt)]
+        dma = [-h_ - th * d for h_, th, d in zip(hp, ths, dt)]
         def maxstep(vs, dvs):
             al = np.inf
             for v, dv in zip(vs, dvs):
@@ -209,10 +217,10 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=Fa
         sig = (gap_aff / gap) ** 3
         tgt = max(sig * gap, 0.01 * tol_gap)          # keep the complementarity products off the rounding floor
         rc = [t * m - tgt + d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]
-        hs = [r / t for r, t in zip(rc, ts)]
+        hs = [r * rt for r, rt in zip(rc, rts)]
         dx, du, ds, dl = solve(*hs)
         dt = ineq_steps(dx, du, ds, dl)
-        dm = [(-r - m * d) / t for r, m, d, t in zip(rc, ms, dt, ts)]
+        dm = [-h_ - th * d for h_, th, d in zip(hs, ths, dt)]
         frac = max(0.995, 1.0 - 10.0 * gap) if sig < 1e-3 else 0.995      # longer steps in the final phase only (step_fraction in the kernel)
         al = min(1.0, frac * maxstep(ts, dt)); ald = min(1.0, frac * maxstep(ms, dm))
         if not sep:
@@ -234,6 +242,8 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-10, verbose=Fa
             # row lambda_i: -dm_l + SS'(T dsT) + deta = -rl  -> average over rows for robustness
             deta = np.mean(-rl + dm[3] - qp.SS.T @ (T * dsT))
         x += al * dx; u += al * du; s += al * ds
+        if carry_t:
+            t_lane, t_u, t_s, t_l = [t + al * d for t, d in zip(ts, dt)]
         if qp.term:
             lam += al * dl
         m_lane, m_u, m_s, m_l = [m + ald * d for m, d in zip(ms, dm)]

@@ -1,0 +1,77 @@
+"""-m gpu: the reference's actual experiment through the drop-in classes -- main.py:97-121, 40 LMPC laps at N = 14 (Laps = 40 + numSS_it,
+initControllerParameters.py:46), Simulator.sim's loop (SysModel.py:22-54) with the oracle's restatement of the plant and seeded noise.
+
+What the reference converges to (oracle restatement of its flow, tests/golden/reference_flow_laps_n14.json): 201..204 steps in the first LMPC
+lap, ~100 by lap 7, 66..73 from lap 27 on, vx up to 3.5 m/s, |ey| up to 0.45 (lane slacks active).  That regime is where the round-2 kernels
+flagged LMPC_ST_INEXACT once or twice per lap (an active lane row's barrier weight mu / t ~ 1e15 cost the Riccati recursion its accuracy); the
+capped weights (LMPC_TH_INV, lmpc_kernels.hip.h) removed that: the tests assert NO status bit on any of the ~3 900 closed-loop QPs of a run.
+
+Behavioural half of the a17 parity statement.  The reference's solver returns an eps = 1e-3 iterate, the GPU path the certified optimum, so the two
+closed loops are compared as closed loops:
+  * against the oracle flow solved to the certified optimum (same noise): identical lap lengths while round-off has not been amplified
+    (the first laps; the loop is chaotic at the scale of single steps from about lap 8 on);
+  * against the oracle's eps = 1e-3 flow: lap lengths scatter by +-5 steps from noise seed to noise seed in EITHER flow (201..212 vs 203..208 in lap 0
+    over eight seeds), so seed-by-seed agreement to +-2 steps does not exist even between two seeds of the reference flow itself; the means over the
+    eight seeds agree to 1.5 / 0.3 / 0.5 steps in laps 0 / 1 / 2, asserted to +-3.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import closed_loop, common
+
+pytestmark = pytest.mark.gpu
+
+
+def _fixture():
+    with open(os.path.join(common.GOLDEN, "reference_flow_laps_n14.json")) as f:
+        return json.load(f)
+
+
+def _clean(recs):
+    for r in recs:
+        assert "error" not in r, r
+        assert r["status"] == {0: r["steps"]}, "status bits in lap %d: %s" % (r["lap"], r["status"])
+
+
+def test_forty_laps_at_main_py_horizon(built):
+    g = common.load_lmpc_golden()
+    ref = _fixture()["laps40"]
+    seeds = sorted(ref)
+    runs = {}
+    for seed in seeds:
+        recs = closed_loop.run_laps(closed_loop.DropinFlow(g, 14), g, 40, seed=int(seed))
+        assert len(recs) == 40
+        _clean(recs)                                                    # zero NUMERIC / MAXITER / REG_SINGULAR / INEXACT over the whole experiment
+        runs[seed] = np.array([r["steps"] for r in recs])
+        assert max(r["iters_max"] for r in recs) <= 25
+        assert max(r["vx_max"] for r in recs) > 3.0                     # the regime the reference ends up in was actually reached
+        print("seed %s: %s" % (seed, runs[seed].tolist()))
+    gpu = np.mean([runs[s] for s in seeds], axis=0); cpu = np.mean([ref[s] for s in seeds], axis=0)
+    assert gpu[-10:].mean() <= 75.0 and abs(gpu[-10:].mean() - cpu[-10:].mean()) <= 3.0       # converged lap time (reference flow: ~69 steps)
+    assert np.abs(gpu - cpu).max() <= 5.0, (gpu - cpu)                  # three-seed means, lap by lap (seed-to-seed scatter of one flow: +-5)
+    assert np.abs(gpu - cpu)[15:].max() <= 4.0 and abs((gpu - cpu).mean()) <= 2.0
+
+
+def test_first_laps_against_both_reference_flows(built):
+    g = common.load_lmpc_golden()
+    # (a) same noise, certified optimum on both sides: the closed loops coincide
+    exact = closed_loop.run_laps(closed_loop.OracleFlow(g, 14, solver="exact"), g, 2, seed=5)
+    gpu = closed_loop.run_laps(closed_loop.DropinFlow(g, 14), g, 2, seed=5)
+    _clean(gpu)
+    assert [r["steps"] for r in gpu] == [r["steps"] for r in exact]
+    assert [r["lap_time"] for r in gpu] == [r["lap_time"] for r in exact]                       # Qfun[it][0]
+    assert abs(gpu[1]["vx_max"] - exact[1]["vx_max"]) < 1e-4 and abs(gpu[1]["ey_max"] - exact[1]["ey_max"]) < 1e-4
+    # (b) the eps = 1e-3 reference flow, eight noise seeds, three laps: means within +-3 steps, every GPU lap inside the band the reference flow spans
+    ref = _fixture()["laps3"]
+    runs = []
+    for seed in sorted(ref, key=int):
+        recs = closed_loop.run_laps(closed_loop.DropinFlow(g, 14), g, 3, seed=int(seed))
+        _clean(recs)
+        runs.append([r["steps"] for r in recs])
+    runs = np.array(runs, float); refa = np.array([ref[s] for s in sorted(ref, key=int)], float)
+    print("GPU", runs.T.tolist(), "reference flow", refa.T.tolist())
+    assert np.abs(runs.mean(axis=0) - refa.mean(axis=0)).max() <= 3.0
+    assert np.all(runs >= refa.min(axis=0) - 3) and np.all(runs <= refa.max(axis=0) + 3)

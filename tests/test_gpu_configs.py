@@ -312,3 +312,63 @@ def test_fused_step_matches_two_kernel_step(built):
     assert int(np.sum(a["status"] != 0)) == 1
     for k in ("A", "B", "C", "xPred", "uPred", "slack", "lambd", "sTerm", "ztNext", "ztuNext", "ssSel", "qSel", "mu", "status", "iters"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def _k1k2_oracle(pt, TL, laps4, N, inp, b):
+    """Oracle regression (a3-a9) and selection (a14-a15) of problem b of a batch; laps4: the four laps both stores use, in the library's order."""
+    from oracle import lmpc_oracle as orc
+    xS = [l[0] for l in laps4]; uS = [l[1] for l in laps4]
+    A, B, C = orc.compute_ltv_dynamics(xS, uS, [0, 1, 2, 3], pt, inp["xLin"][b], inp["uLin"][b], N)
+    Qf = [orc.compute_cost(x, TL) for x in xS]
+    z = inp["zt"][b].copy()
+    if z[4] - inp["x0"][b][4] > TL / 2:
+        z[4] = np.max([z[4] - TL, 0])
+    SSsel, Qsel, _, _ = orc.terminal_components(xS, uS, Qf, [x.shape[0] for x in xS], z, 48, 4, None, 4, int(inp["timeStep"][b]), N, TL)
+    return A, B, C, SSsel, Qsel
+
+
+def test_k1_k2_match_oracle_on_every_bench_problem(built):
+    """K1 (regression) and K2 (selection) against the oracle on ALL 256 problems of bench.synth_batch -- the inputs the driver times -- and on 256
+    evenly spaced problems of the 4096-problem / 30-lap batch: A, B, C to 1e-9 relative, SS_sel and Qfun_sel np.array_equal.  (The full-batch KKT
+    certificates of test_gpu_certificates.py are built from the GPU's own A, B, C and selection: they certify K3 on every problem, this test K1 / K2.)"""
+    import bench
+    from racinglmpc_amd import _capi
+    g = common.load_lmpc_golden()
+    pt = np.array(g["track"]); TL = float(g["trackLength"]); N = 12
+    # (a) bench batch
+    cfg, _ = common.lmpc_config(g, N, max_batch=256)
+    ctx = _capi.Context(cfg)
+    pid = (np.array(g["xPID"]), np.array(g["uPID"]))
+    for _ in range(4):
+        ctx.model_add_trajectory(*pid); ctx.ss_add_trajectory(*pid)
+    inp = bench.synth_batch(g, 256, N, seed=1234)
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    worst = 0.0
+    for b in range(256):
+        A, B, C, SSsel, Qsel = _k1k2_oracle(pt, TL, [pid] * 4, N, inp, b)
+        for got, ref in ((out["A"][b], A), (out["B"][b], B), (out["C"][b], C)):
+            worst = max(worst, (np.abs(got - ref) / (1 + np.abs(ref))).max())
+        assert np.array_equal(out["ssSel"][b], SSsel.T) and np.array_equal(out["qSel"][b], Qsel), b
+    print("bench batch, all 256 problems: worst relative |A,B,C - oracle| %.2e, selections identical" % worst)
+    assert worst < common.TOL_ABC
+    ctx.close()
+    # (b) 4096 problems / 30 laps, every 16th problem
+    laps = pid_laps_batched(pt, 30)
+    cfg, _ = common.lmpc_config(g, N, max_batch=4096, max_laps=40, max_lap_len=1024)
+    ctx = _capi.Context(cfg)
+    for x, u in laps:
+        ctx.model_add_trajectory(x, u); ctx.ss_add_trajectory(x, u)
+    order = sorted(range(30), key=lambda i: (laps[i][0].shape[0], i))
+    laps4 = [laps[i] for i in order[:4]]
+    inp = bench.synth_batch(g, 4096, N, seed=1234, lap=laps[29])
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    assert np.all(out["status"] == 0)
+    worst = 0.0
+    for b in range(0, 4096, 16):
+        A, B, C, SSsel, Qsel = _k1k2_oracle(pt, TL, laps4, N, inp, b)
+        for got, ref in ((out["A"][b], A), (out["B"][b], B), (out["C"][b], C)):
+            worst = max(worst, (np.abs(got - ref) / (1 + np.abs(ref))).max())
+        assert np.array_equal(out["ssSel"][b], SSsel.T) and np.array_equal(out["qSel"][b], Qsel), b
+    print("4096 / 30 laps, 256 evenly spaced problems: worst relative |A,B,C - oracle| %.2e, selections identical" % worst)
+    assert worst < common.TOL_ABC
+    ctx.close()
