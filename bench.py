@@ -216,9 +216,11 @@ def spawn_ranks(n, argv):
     if "--dry-run" not in argv:
         ge.build()                                  # once, before the ranks need the library
     port = _free_port()
+    nonce = "%d-%d" % (os.getpid(), int(time.time()))           # names this launch's rendezvous file (parallel._rdzv_file)
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LMPC_BENCH_SPAWNED="1")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LMPC_BENCH_SPAWNED="1",
+                   LMPC_RDZV_NONCE=nonce)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else None))
     # rank 0's stdout is collected by a reader thread; the ranks are polled so that one rank dying cannot leave the others (and this
     # process) waiting in a collective for ever: the survivors are terminated, as a launcher would

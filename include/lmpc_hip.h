@@ -31,7 +31,7 @@ extern "C" {
 #define LMPC_OK 0
 #define LMPC_E_ARG (-1)            /* bad argument / unsupported configuration */
 #define LMPC_E_HIP (-2)            /* a HIP runtime call failed (see lmpc_last_error) */
-#define LMPC_E_CAPACITY (-3)       /* lap store / batch capacity exceeded */
+#define LMPC_E_CAPACITY (-3)       /* (no longer returned: the lap stores grow on demand; kept so that the numbering of the codes is stable) */
 #define LMPC_E_STATE (-4)          /* call not valid in the current state (e.g. no laps stored) */
 #define LMPC_E_VARIANT (-5)        /* lmpc_create: the solve kernels for this (N, numSS_points) are not part of the library and their shared object
                                       liblmpc_var_N<N>_S<S>.so (next to liblmpc_hip.so) has not been built yet; racinglmpc_amd builds it on demand */
@@ -43,6 +43,9 @@ extern "C" {
 #define LMPC_ST_WINDOW 8           /* safe-set window runs past the end of a stored lap (reference: IndexError, :497) */
 #define LMPC_ST_NUMERIC 16         /* NaN / non-positive pivot inside the KKT factorisation */
 #define LMPC_ST_NOT_INTERIOR 32    /* u = 0 is not strictly inside Fu u <= bu (solver start point) */
+#define LMPC_ST_INFEASIBLE 128      /* lmpc_config.slacks = 0 (MPCParams.slacks = False): a hard lane row is exceeded by more than 1e-8 at the optimum of the penalised
+                                    * problem, i.e. the hard problem has no feasible point (e.g. x0 already outside the lane: its k = 0 row is fixed by the
+                                    * equality).  Reference: OSQP reports primal infeasible and MPC.solve sets feasible = 0 (PredictiveControllers.py:277-280). */
 #define LMPC_ST_INEXACT 64         /* returned iterate is optimal to working accuracy only (gap < 1e-9, dual residual < 1e-5 rel., equality
                                       residual < 1e-7) because the factorisation broke down or the iteration limit was hit at that point;
                                       the solution is usable (the reference's own solver tolerance is 1e-3) */
@@ -65,7 +68,9 @@ typedef struct {
     double track[LMPC_MAX_TRACK_ROWS * 6]; int track_rows; double trackLength;
     int device;                 /* HIP device ordinal */
     int max_batch;              /* capacity of internal work buffers */
-    int max_laps, max_lap_len;  /* lap-store capacity (rows per lap include addPoint extensions) */
+    int max_laps, max_lap_len;  /* INITIAL lap-store capacity (rows per lap include addPoint extensions).  The reference's stores are Python lists
+                                 * (PredictiveControllers.py:418-445, :466-474; PredictiveModel.py:35-46): when a lap or a row does not fit, the
+                                 * device stores are reallocated at >= twice the size (lmpc_*_add_trajectory, lmpc_ss_add_point, lmpc_ss_extend_lap) */
     /* solver: structure-exploiting primal-dual interior point on the block-banded KKT system */
     double tol_gap, tol_res, reg_lambda; int max_iter;
     int slacks;                 /* MPCParams.slacks (:184-198, 218-221, 248-254): 1 = lane rows softened by slack variables (main.py always);
@@ -175,6 +180,9 @@ int lmpc_rollout_fetch(lmpc_ctx *, int t0, int t1, double *X /*(t1-t0) x B x 6*/
 int lmpc_rollout_end(lmpc_ctx *);
         /* Simulator.sim with one LMPC controller per rollout, SysModel.py:22-54, state resident on the device */
 int lmpc_ss_extend_lap(lmpc_ctx *, int lap, const double *x /*n x 6*/, const double *u /*n x 2*/, int n);
+/* Undo extensions: keep the first T rows of stored lap `lap` (LapTime <= T <= current rows).  rollout.LmpcGeneration rolls a failed
+ * generation back with it, so that a generation either completes or leaves the safe set as it found it.  No reference counterpart. */
+int lmpc_ss_truncate_lap(lmpc_ctx *, int lap, int T);
         /* LMPC.addPoint (:466-474) applied to any stored lap: n points appended with s + TrackLength, Qfun counting down */
 int lmpc_lti_regression(int device, const double *x /*T x 6*/, const double *u /*T x 2*/, int T, double lamb,
                         double *A /*6 x 6*/, double *B /*6 x 2*/, double *Error /*2 x 6: max; min of the fit residual*/, int *status /*or NULL*/);

@@ -1,6 +1,9 @@
-"""Drop-in for `Regression` of the reference's fnc/Utilities.py (the LTI model of main.py's path-following MPC stage,
-main.py:74-77): same signature and return value, the ridge least-squares fit runs in lmpc_lti_regress_kernel on the GPU.
-`PID` and `wrap` are caller-side helpers of the reference and stay where they are."""
+"""Drop-in for the reference's fnc/Utilities.py: `Regression` (the LTI model of main.py's path-following MPC stage, main.py:74-77) with the same
+signature and return value, its ridge least-squares fit running in lmpc_lti_regress_kernel on the GPU; `PID` and `wrap`, the two caller-side helpers
+main.py:32 / SysModel.py:4 import from the same module, are restated here (a few lines of host arithmetic) so that a module named `Utilities` on the
+path seam (racinglmpc_amd/dropin) can stand in for the reference's file as a whole."""
+import datetime
+
 import numpy as np
 
 from . import _capi
@@ -13,3 +16,32 @@ def Regression(x, u, lamb):
     if status & _capi.ST_REG_SINGULAR:
         raise np.linalg.LinAlgError("Singular matrix")          # what np.linalg.inv raises in the reference
     return A, B, Error
+
+
+def wrap(angle):
+    """Angle folded back by one turn if it left [-pi, pi] (reference Utilities.py:31-39)."""
+    if angle < -np.pi:
+        return 2 * np.pi + angle
+    if angle > np.pi:
+        return angle - 2 * np.pi
+    return angle
+
+
+class PID:
+    """Path-following controller of main.py's first stage (reference Utilities.py:42-67): steering from (ey, epsi), acceleration from the speed
+    error, each with clipped Gaussian exploration noise drawn from the global NumPy generator (steering first), so that a seeded run of the
+    reference draws the same numbers.  Same attributes as the predictive controllers (uPred (1, 2), solverTime, linearizationTime, feasible)."""
+
+    def __init__(self, vt):
+        self.vt = vt
+        self.uPred = np.zeros([1, 2])
+        zero = datetime.timedelta(0)
+        self.solverTime = zero
+        self.linearizationTime = zero
+        self.feasible = 1
+
+    def solve(self, x0):
+        steer_noise = float(np.clip(np.random.randn() * 0.25, -0.9, 0.9))
+        acc_noise = float(np.clip(np.random.randn() * 0.10, -0.2, 0.2))
+        self.uPred[0, 0] = - 0.6 * x0[5] - 0.9 * x0[3] + steer_noise
+        self.uPred[0, 1] = 1.5 * (self.vt - x0[0]) + acc_noise

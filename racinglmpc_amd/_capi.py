@@ -16,7 +16,7 @@ MAX_USED_LAPS = 8
 COMM_ID_BYTES = 128
 E_VARIANT = -5
 
-ST_MAXITER, ST_REG_SINGULAR, ST_NO_SEGMENT, ST_WINDOW, ST_NUMERIC, ST_NOT_INTERIOR, ST_INEXACT = 1, 2, 4, 8, 16, 32, 64
+ST_MAXITER, ST_REG_SINGULAR, ST_NO_SEGMENT, ST_WINDOW, ST_NUMERIC, ST_NOT_INTERIOR, ST_INEXACT, ST_INFEASIBLE = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class LmpcConfig(C.Structure):
@@ -51,7 +51,7 @@ EXPORTS = [
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
     "lmpc_lti_regression", "lmpc_comm_unique_id", "lmpc_comm_init", "lmpc_comm_destroy", "lmpc_comm_info", "lmpc_comm_allgather_dev", "lmpc_comm_allgather",
     "lmpc_comm_allreduce_max", "lmpc_comm_barrier", "lmpc_rollout_exchange",
-    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_solver_waves", "lmpc_plant_step_batch", "lmpc_global_position_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap",
+    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_solver_waves", "lmpc_plant_step_batch", "lmpc_global_position_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap", "lmpc_ss_truncate_lap",
 ]
 
 _lib = None
@@ -362,6 +362,19 @@ class Context:
     def ss_extend_lap(self, lap, x, u):
         x = _f64(x); u = _f64(u)
         _chk(self.lib.lmpc_ss_extend_lap(self._h, C.c_int(int(lap)), _d(x), _d(u), C.c_int(x.shape[0])))
+
+    def ss_truncate_lap(self, lap, T):
+        _chk(self.lib.lmpc_ss_truncate_lap(self._h, C.c_int(int(lap)), C.c_int(int(T))))
+
+    def ss_num_laps(self):
+        n = C.c_int()
+        _chk(self.lib.lmpc_ss_num_laps(self._h, C.byref(n)))
+        return n.value
+
+    def ss_lap_rows(self, lap):
+        T = C.c_int()
+        _chk(self.lib.lmpc_ss_get_qfun(self._h, C.c_int(int(lap)), None, C.byref(T)))
+        return T.value
 
     # ---- multi-GPU exchange (RCCL behind the C ABI; see parallel.py for the rendezvous)
     def comm_init(self, id_bytes, rank, world):

@@ -241,8 +241,50 @@ int lmpc_destroy(lmpc_ctx *c) {
 }
 
 // ---------------------------------------------------------------------------------------------- stores
-static int upload_lap(lmpc_ctx *c, double *store, int slot, const double *x, const double *u, const double *qf, int T) {
-    if (T > c->cfg.max_lap_len) return set_err(LMPC_E_CAPACITY, "lap longer than max_lap_len", "");
+// The reference keeps its laps in Python lists that grow without bound (PredictiveControllers.py:418-445, PredictiveModel.py:35-46; addPoint
+// appends a row per closed-loop step, :466-474).  max_laps / max_lap_len of lmpc_config are therefore INITIAL capacities: when a lap or a row
+// does not fit, both stores (and the K1 prefilter image) move to allocations of at least twice the size -- strided device-to-device copies,
+// [lap][column][row] with the new row stride -- and the device parameter block is rebuilt.  Amortised O(1) per stored row; no kernel is in
+// flight while it happens (the stream is drained first).
+static int grow_stores(lmpc_ctx *c, int need_laps, int need_len) {
+    const int old_laps = c->cfg.max_laps, old_len = c->cfg.max_lap_len;
+    int new_laps = old_laps, new_len = old_len;
+    while (new_laps < need_laps) new_laps *= 2;
+    while (new_len < need_len) new_len *= 2;
+    if (new_laps == old_laps && new_len == old_len) return LMPC_OK;
+    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    const int old_chunks = c->mq_chunks, new_chunks = (new_len + K1_CHUNK - 1) / K1_CHUNK;
+    const size_t elems = (size_t)new_laps * LMPC_COLS * new_len;
+    double *nm = nullptr, *ns = nullptr, *np_ = nullptr; unsigned *nq = nullptr;
+    auto fail = [&](int rc) { if (nm) (void)hipFree(nm); if (ns) (void)hipFree(ns); if (nq) (void)hipFree(nq); if (np_) (void)hipFree(np_); return rc; };
+#define GROWCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(set_err(LMPC_E_HIP, #call, hipGetErrorString(e_))); } while (0)
+    GROWCHK(hipMalloc(&nm, elems * sizeof(double))); GROWCHK(hipMalloc(&ns, elems * sizeof(double)));
+    GROWCHK(hipMalloc(&nq, (size_t)new_laps * 3 * new_len * sizeof(unsigned))); GROWCHK(hipMalloc(&np_, (size_t)new_laps * new_chunks * 6 * sizeof(double)));
+    GROWCHK(hipMemset(nm, 0, elems * sizeof(double))); GROWCHK(hipMemset(ns, 0, elems * sizeof(double)));
+    GROWCHK(hipMemset(nq, 0, (size_t)new_laps * 3 * new_len * sizeof(unsigned))); GROWCHK(hipMemset(np_, 0, (size_t)new_laps * new_chunks * 6 * sizeof(double)));
+    const size_t nml = c->m_len.size(), nsl = c->s_len.size();
+    if (nml) {
+        GROWCHK(hipMemcpy2D(nm, (size_t)new_len * 8, c->mstore, (size_t)old_len * 8, (size_t)old_len * 8, nml * LMPC_COLS, hipMemcpyDeviceToDevice));
+        GROWCHK(hipMemcpy2D(nq, (size_t)new_len * 4, c->mquant, (size_t)old_len * 4, (size_t)old_len * 4, nml * 3, hipMemcpyDeviceToDevice));
+        GROWCHK(hipMemcpy2D(np_, (size_t)new_chunks * 48, c->mqpar, (size_t)old_chunks * 48, (size_t)old_chunks * 48, nml, hipMemcpyDeviceToDevice));
+    }
+    if (nsl) GROWCHK(hipMemcpy2D(ns, (size_t)new_len * 8, c->sstore, (size_t)old_len * 8, (size_t)old_len * 8, nsl * LMPC_COLS, hipMemcpyDeviceToDevice));
+#undef GROWCHK
+    (void)hipFree(c->mstore); (void)hipFree(c->sstore); (void)hipFree(c->mquant); (void)hipFree(c->mqpar);
+    c->mstore = nm; c->sstore = ns; c->mquant = nq; c->mqpar = np_; c->mq_chunks = new_chunks;
+    c->cfg.max_laps = new_laps; c->cfg.max_lap_len = new_len;
+    const lmpc_dev_params keep = c->dp;
+    fill_params(c);
+    // (per-launch parts of the parameter block survive: selected slots / lengths are refreshed by every launch anyway)
+    memcpy(c->dp.mslot, keep.mslot, sizeof(keep.mslot)); memcpy(c->dp.mlen, keep.mlen, sizeof(keep.mlen));
+    memcpy(c->dp.sslot, keep.sslot, sizeof(keep.sslot)); memcpy(c->dp.sslen, keep.sslen, sizeof(keep.sslen)); memcpy(c->dp.sslapid, keep.sslapid, sizeof(keep.sslapid));
+    c->dp.cur_it = keep.cur_it;
+    return LMPC_OK;
+}
+
+static int upload_lap(lmpc_ctx *c, bool model, int slot, const double *x, const double *u, const double *qf, int T) {
+    { const int rc = grow_stores(c, slot + 1, T); if (rc) return rc; }
+    double *store = model ? c->mstore : c->sstore;
     std::vector<double> col((size_t)T);
     double *base = store + (size_t)slot * LMPC_COLS * c->cfg.max_lap_len;
     for (int cI = 0; cI < LMPC_COLS; cI++) {
@@ -291,9 +333,8 @@ int lmpc_model_add_trajectory(lmpc_ctx *c, const double *x, const double *u, int
     ARGCHK(c && x && u && T >= 2);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int slot = (int)c->m_len.size();
-    if (slot >= c->cfg.max_laps) return set_err(LMPC_E_CAPACITY, "model store full", "");
     HIPCHK(hipStreamSynchronize(c->stream));
-    int rc = upload_lap(c, c->mstore, slot, x, u, nullptr, T); if (rc) return rc;
+    int rc = upload_lap(c, true, slot, x, u, nullptr, T); if (rc) return rc;                 // (grows the stores when the lap does not fit)
     rc = quantise_lap(c, slot, x, u, T); if (rc) return rc;
     c->m_len.push_back(T);
     // PredictiveModel.addTrajectory (PredictiveModel.py:35-46): append if empty or T >= last, else insert before first longer lap
@@ -306,7 +347,7 @@ int lmpc_model_replace_lap(lmpc_ctx *c, int pos, const double *x, const double *
     ARGCHK(c && x && u && pos >= 0 && pos < (int)c->m_order.size());
     HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
     ARGCHK(T == c->m_len[c->m_order[pos]]);
-    int rc = upload_lap(c, c->mstore, c->m_order[pos], x, u, nullptr, T); if (rc) return rc;
+    int rc = upload_lap(c, true, c->m_order[pos], x, u, nullptr, T); if (rc) return rc;
     return quantise_lap(c, c->m_order[pos], x, u, T);
 }
 
@@ -314,7 +355,6 @@ int lmpc_ss_add_trajectory(lmpc_ctx *c, const double *x, const double *u, int T)
     ARGCHK(c && x && u && T >= 1);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int lap = (int)c->s_len.size();
-    if (lap >= c->cfg.max_laps) return set_err(LMPC_E_CAPACITY, "safe-set store full", "");
     // LMPC.computeCost (PredictiveControllers.py:447-464)
     std::vector<double> cost((size_t)T, 10000.0);
     for (int i = 0; i < T; i++) {
@@ -324,7 +364,7 @@ int lmpc_ss_add_trajectory(lmpc_ctx *c, const double *x, const double *u, int T)
         else cost[r] = 0;
     }
     HIPCHK(hipStreamSynchronize(c->stream));
-    int rc = upload_lap(c, c->sstore, lap, x, u, cost.data(), T); if (rc) return rc;
+    int rc = upload_lap(c, false, lap, x, u, cost.data(), T); if (rc) return rc;
     c->s_len.push_back(T); c->s_laptime.push_back(T); c->s_qlast.push_back(cost[T - 1]); c->s_q0.push_back(cost[0]);
     return LMPC_OK;
 }
@@ -339,7 +379,7 @@ int lmpc_ss_add_point(lmpc_ctx *c, const double *x, const double *u) {
     if (c->s_len.empty()) return set_err(LMPC_E_STATE, "addPoint before any addTrajectory", "");
     HIPCHK(hipSetDevice(c->cfg.device));
     const int lap = (int)c->s_len.size() - 1, row = c->s_len[lap];
-    if (row >= c->cfg.max_lap_len) return set_err(LMPC_E_CAPACITY, "lap longer than max_lap_len", "");
+    if (row >= c->cfg.max_lap_len) { const int rc = grow_stores(c, c->cfg.max_laps, row + 1); if (rc) return rc; }
     const double q = c->s_qlast[lap] - 1.0;                        // :474
     double *base = c->sstore + (size_t)lap * LMPC_COLS * c->cfg.max_lap_len;
     hipLaunchKernelGGL(lmpc_store_row_kernel, dim3(1), dim3(64), 0, c->stream, base, c->cfg.max_lap_len, row,
@@ -351,7 +391,7 @@ int lmpc_ss_add_point(lmpc_ctx *c, const double *x, const double *u) {
 int lmpc_ss_replace_lap(lmpc_ctx *c, int lap, const double *x, const double *u, const double *qfun, int T) {
     ARGCHK(c && x && u && qfun && lap >= 0 && lap < (int)c->s_len.size() && T >= 1);
     HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
-    int rc = upload_lap(c, c->sstore, lap, x, u, qfun, T); if (rc) return rc;
+    int rc = upload_lap(c, false, lap, x, u, qfun, T); if (rc) return rc;
     c->s_len[lap] = T; c->s_qlast[lap] = qfun[T - 1]; c->s_q0[lap] = qfun[0];
     return LMPC_OK;
 }
@@ -831,7 +871,7 @@ int lmpc_ss_extend_lap(lmpc_ctx *c, int lap, const double *x, const double *u, i
     ARGCHK(c && lap >= 0 && lap < (int)c->s_len.size() && n >= 0 && (n == 0 || (x && u)));
     if (n == 0) return LMPC_OK;
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (c->s_len[lap] + n > c->cfg.max_lap_len) return set_err(LMPC_E_CAPACITY, "lap longer than max_lap_len", "");
+    if (c->s_len[lap] + n > c->cfg.max_lap_len) { const int rc = grow_stores(c, c->cfg.max_laps, c->s_len[lap] + n); if (rc) return rc; }
     std::vector<double> rows((size_t)n * LMPC_COLS);
     double q = c->s_qlast[lap];
     for (int i = 0; i < n; i++) {
@@ -851,6 +891,16 @@ int lmpc_ss_extend_lap(lmpc_ctx *c, int lap, const double *x, const double *u, i
     (void)hipFree(d_rows);
     if (e != hipSuccess) return set_err(LMPC_E_HIP, "lmpc_ss_extend_lap", hipGetErrorString(e));
     c->s_len[lap] += n; c->s_qlast[lap] = q;
+    return LMPC_OK;
+}
+
+int lmpc_ss_truncate_lap(lmpc_ctx *c, int lap, int T) {
+    ARGCHK(c && lap >= 0 && lap < (int)c->s_len.size() && T >= c->s_laptime[lap] && T <= c->s_len[lap]);
+    if (T == c->s_len[lap]) return LMPC_OK;
+    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    double q = 0.0;                                                  // Qfun of the new last row (addPoint counts on from it, :474)
+    HIPCHK(hipMemcpy(&q, c->sstore + ((size_t)lap * LMPC_COLS + 8) * c->cfg.max_lap_len + (T - 1), sizeof(double), hipMemcpyDeviceToHost));
+    c->s_len[lap] = T; c->s_qlast[lap] = q;
     return LMPC_OK;
 }
 

@@ -1020,9 +1020,12 @@ __device__ __forceinline__ void k2_select(const lmpc_dev_params &p, const lmpc_s
         const int hasPred = io.hasPred ? io.hasPred[b] : 0;                     // Q-function shift bookkeeping (:502-512)
         int crossed = 0;
         if (hasPred) {
-            int c_ = 0;
-            if (lane <= N) c_ = (io.xPredPrev[((size_t)b * (N + 1) + lane) * 6 + 4] > p.TL) ? 1 : 0;
-            crossed = (int)__popcll(__ballot(c_));
+#pragma unroll
+            for (int r0 = 0; r0 <= N; r0 += WAVE) {                               // N + 1 predicted rows: 65 at the largest horizon, one more than a wave has lanes
+                const int r = r0 + lane;
+                const int c_ = (r <= N && io.xPredPrev[((size_t)b * (N + 1) + (r <= N ? r : 0)) * 6 + 4] > p.TL) ? 1 : 0;
+                crossed += (int)__popcll(__ballot(c_));
+            }
         }
         const int tstep = io.timeStep ? io.timeStep[b] : 0;
         const int ppl = p.ppl, npw = ppl + 1;                                   // numSS_Points/numSS_it + 1 (=13)
@@ -1691,6 +1694,15 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     TSTAMP(20);
     if (!converged && lane == 0 && !(st_sh & (LMPC_ST_NUMERIC | LMPC_ST_INEXACT)))
         atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_MAXITER);
+    if (!p.slacks) {
+        // hard lane rows (MPCParams.slacks = False) are imposed through slack variables with a 1e12 quadratic weight: at the optimum a slack is
+        // mu / 2e12 ~ 1e-11 unless the hard problem is infeasible -- then it is the violation itself, and the reference's solver reports
+        // "primal infeasible" (feasible = 0, PredictiveControllers.py:277-280)
+        double smax = 0.0;
+        FOR_LANES(i, 2 * N) smax = fmax(smax, s[i]);
+        smax = wmax(smax);
+        if (smax > 1e-8 && lane == 0) atomicOr(&st_sh, LMPC_ST_INFEASIBLE);
+    }
     __syncthreads();
 
     // ---- unpackSolution (:364-379) and feasibleStateInput (:382-384) -------------------------------------

@@ -744,6 +744,12 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     }
     if (!converged && tid == 0 && !(st_sh & (LMPC_ST_NUMERIC | LMPC_ST_INEXACT)))
         atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_MAXITER);
+    if (!p.slacks && w0) {                                   // hard lane rows exceeded: the hard problem is infeasible (see lmpc_solve_kernel)
+        double smax = 0.0;
+        for (int i = lane; i < 2 * N; i += WAVE) smax = fmax(smax, s[i]);
+        smax = wmax(smax);
+        if (smax > 1e-8 && lane == 0) atomicOr(&st_sh, LMPC_ST_INFEASIBLE);
+    }
     __syncthreads();
 
     TSMW(20); TSMW(21);

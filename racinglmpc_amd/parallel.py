@@ -47,9 +47,31 @@ class LocalComm:
 
 
 def _rdzv_file(port):
-    """Same-node hand-off file: every rank of one launch has the same parent process (the launcher's agent, or bench.py --gpus N itself)."""
+    """Same-node hand-off file: every rank of one launch has the same parent process (the launcher's agent, or bench.py --gpus N itself).
+    It lives in a directory of the user's own (mode 0700: the RCCL id is not world-readable) and carries the launch's nonce if the launcher
+    supplies one (LMPC_RDZV_NONCE, or torchrun's TORCHELASTIC_RUN_ID)."""
     import tempfile
-    return os.path.join(tempfile.gettempdir(), "lmpc_rdzv_%d_%d.id" % (os.getppid(), int(port)))
+    d = os.path.join(tempfile.gettempdir(), "lmpc_rdzv_u%d" % os.getuid())
+    try:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        if os.stat(d).st_uid != os.getuid():
+            raise OSError("rendezvous directory %s belongs to another user" % d)
+        os.chmod(d, 0o700)
+    except OSError:
+        d = tempfile.gettempdir()                                   # (no private directory: the file itself is still created 0600 / O_EXCL)
+    nonce = os.environ.get("LMPC_RDZV_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID") or "none"
+    nonce = "".join(ch for ch in nonce if ch.isalnum() or ch in "-_")[:48]
+    return os.path.join(d, "lmpc_rdzv_%d_%d_%s.id" % (os.getppid(), int(port), nonce))
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    return True
 
 
 def _is_local(addr):
@@ -63,23 +85,32 @@ def _rendezvous_id(rank, world, addr, port, make_id, timeout=120.0):
     ranks share a node (no port to collide on, nothing to resolve; a rank acknowledges with a file of its own), and over TCP (addr, port)
     for ranks on other nodes or without a shared temporary directory.  Rank 0 returns once every other rank has the id."""
     path = _rdzv_file(port)
+    if not 0 < int(port) < 65536:
+        raise ValueError("rendezvous port %r is not a TCP port (LMPC_RDZV_PORT / MASTER_PORT + 117, see env_world)" % (port,))
     if rank == 0:
         uid = make_id()
         if world == 1:
             return uid
+        for f in [path] + [path + ".ack%d" % r for r in range(1, world)]:     # left-overs of a killed launch with the same parent and port
+            try:
+                os.remove(f)
+            except OSError:
+                pass
         try:
+            # payload: the 128-byte id + this process's pid -- a reader rejects a file whose writer is gone (a stale id would hang ncclCommInitRank)
             tmp = path + ".tmp%d" % os.getpid()
-            with open(tmp, "wb") as f:
-                f.write(uid)
-            os.replace(tmp, path)                                   # atomic: a reader sees all 128 bytes or no file
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+            with os.fdopen(fd, "wb") as f:
+                f.write(uid + int(os.getpid()).to_bytes(8, "little"))
+            os.replace(tmp, path)                                   # atomic: a reader sees the whole payload or no file
         except OSError:
             pass
         try:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, port)); srv.listen(world); srv.settimeout(0.05)
-        except OSError:
-            srv = None                                              # port taken: the file is the hand-off
+        except (OSError, OverflowError, ValueError):
+            srv = None                                              # port taken / not bindable: the file is the hand-off
         served, t0 = set(), time.time()
         try:
             while len(served) < world - 1:
@@ -119,10 +150,11 @@ def _rendezvous_id(rank, world, addr, port, make_id, timeout=120.0):
                     buf = f.read()
             except OSError:
                 buf = b""
-            if len(buf) == 128:
-                with open(path + ".ack%d" % rank, "wb") as f:
+            if len(buf) == 136 and _alive(int.from_bytes(buf[128:], "little")):
+                fd = os.open(path + ".ack%d" % rank, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+                with os.fdopen(fd, "wb") as f:
                     f.write(b"1")
-                return buf
+                return buf[:128]
         if not local or time.time() - t0 > 15.0:                   # another node, or no shared temporary directory: ask rank 0
             try:
                 s = socket.create_connection((addr, port), timeout=5.0)
@@ -170,7 +202,9 @@ def env_world():
     """(rank, world, local_rank, addr, rendezvous port) from the launcher's environment (the driver's distributed launcher or bench.py --gpus)."""
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", str(rank)))
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    port = int(os.environ.get("LMPC_RDZV_PORT", str(int(os.environ.get("MASTER_PORT", "29500")) + 117)))   # MASTER_PORT itself belongs to the launcher's store
+    port = int(os.environ.get("LMPC_RDZV_PORT", "0")) or int(os.environ.get("MASTER_PORT", "29500")) + 117   # MASTER_PORT itself belongs to the launcher's store
+    if port > 65535:                                                # MASTER_PORT near the top of the range: stay a valid port, still off MASTER_PORT
+        port -= 2 * 117
     return rank, world, local, addr, port
 
 

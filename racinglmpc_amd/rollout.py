@@ -5,7 +5,8 @@ the hot path (reference SysModel.Simulator.sim, SysModel.py:22-54; plant: Simula
 Rank-local: each rank owns a contiguous shard of the rollouts (parallel.shard) and its own device context; after a lap the
 ranks exchange their fastest VALID laps once (lmpc_rollout_exchange: device-packed records, one RCCL all-gather) and apply
 identical inserts.  A lap is valid when the car crossed the finish line and no status bit other than LMPC_ST_INEXACT was
-raised up to the crossing step; anything else never reaches a lap store.
+raised up to the crossing step; anything else never reaches a lap store -- neither as a new lap nor as the rows that extend a
+stored lap past the finish line (the batched LMPC.addPoint): those are checked for status bits and finiteness first.
 """
 import numpy as np
 
@@ -78,6 +79,7 @@ class LmpcGeneration:
         self.parents = None            # [(x, u, x_glob, final12, stored_lap_index)] of the previous generation
         self.last_exchange = None      # (bytes per rank, seconds) of the last all-gather
         self.last_status = self.last_done = None
+        self.skipped_extensions = []   # [(k, status bits)]: stored laps NOT extended in the last generation because the continuing rollout was flagged
 
     def run(self, x0_all=None, xLin0=None, uLin0=None):
         import time
@@ -96,36 +98,58 @@ class LmpcGeneration:
             xl = np.stack([self.parents[k][0][1:N + 2] for k in par]); ul = np.stack([self.parents[k][1][1:N + 1] for k in par])
             ext = self.ext
         ro.begin(x0, xl, ul, xg0, self.T_max)
-        if ext > 0:
-            # the rollout with GLOBAL index k (k < K) continues stored lap k: its first ext points extend that lap on every rank.
-            # Each row is taken from the rank whose shard holds rollout k; every rank takes part in the gather.
-            t, _ = ctx.rollout_run(ext)
-            X, U, G, done, st, fx, fg = ctx.rollout_fetch(0, t)
-            n = min(t, ext)
-            buf = np.zeros((K, ext, 8)); mask = np.zeros(K, dtype=np.int64)
-            for k in range(K):
-                if lo <= k < hi:
-                    buf[k, :n, 0:6] = X[:n, k - lo]; buf[k, :n, 6:8] = U[:n, k - lo]; mask[k] = 1
-            rows, owned = parallel.gather_owned_rows(buf, mask, self.comm)
-            nmin = int(self.comm.allreduce_max(-float(n))[0] * -1)                 # rows every owner really logged
-            for k in range(K):
-                if owned[k] and nmin > 0:
-                    ctx.ss_extend_lap(self.parents[k][4], rows[k, :nmin, 0:6], rows[k, :nmin, 6:8])
-        ctx.rollout_run(self.T_max)
-        _, _, _, self.last_done, self.last_status, _, _ = ctx.rollout_fetch(0, 0)     # per-rollout finish step / accumulated status bits
-        t0 = time.perf_counter()
-        recs, lens, n_valid = ctx.rollout_exchange(K, self.T_max) if self.comm.backend != "gloo" else self._host_exchange()
-        self.last_exchange = (recs[0].nbytes + lens[0].nbytes, time.perf_counter() - t0)
-        ctx.rollout_end()
-        best = parallel.top_k(recs, lens, K, self.T_max)
-        if len(best) < K:
-            raise RuntimeError("only %d valid laps among %d rollouts (need K = %d): the others did not finish within %d steps or were flagged"
-                               % (len(best), self.total, K, self.T_max))
+        undo = []                      # (stored lap, rows before this generation's extension): a generation completes or leaves the safe set as it found it
+        try:
+            if ext > 0:
+                # the rollout with GLOBAL index k (k < K) continues stored lap k: its first ext points extend that lap on every rank.
+                # Each row is taken from the rank whose shard holds rollout k, together with that rollout's accumulated status bits: a row of a
+                # flagged rollout (anything but INEXACT) or a non-finite row never reaches a lap store -- decided from the gathered data, hence
+                # identically on every rank.
+                t, _ = ctx.rollout_run(ext)
+                X, U, G, done, st, fx, fg = ctx.rollout_fetch(0, t)
+                n = min(t, ext)
+                buf = np.zeros((K, ext, 9)); mask = np.zeros(K, dtype=np.int64)
+                for k in range(K):
+                    if lo <= k < hi:
+                        buf[k, :n, 0:6] = X[:n, k - lo]; buf[k, :n, 6:8] = U[:n, k - lo]; buf[k, :, 8] = float(st[k - lo]); mask[k] = 1
+                rows, owned = parallel.gather_owned_rows(buf, mask, self.comm)
+                nmin = int(self.comm.allreduce_max(-float(n))[0] * -1)                 # rows every owner really logged
+                self.skipped_extensions = []
+                for k in range(K):
+                    if not owned[k] or nmin <= 0:
+                        continue
+                    clean = (int(rows[k, 0, 8]) & ~_capi.ST_INEXACT) == 0 and bool(np.all(np.isfinite(rows[k, :nmin, 0:8])))
+                    if not clean:
+                        self.skipped_extensions.append((k, int(rows[k, 0, 8])))
+                        continue
+                    lap = self.parents[k][4]
+                    undo.append((lap, ctx.ss_lap_rows(lap)))
+                    ctx.ss_extend_lap(lap, rows[k, :nmin, 0:6], rows[k, :nmin, 6:8])
+            ctx.rollout_run(self.T_max)
+            _, _, _, self.last_done, self.last_status, _, _ = ctx.rollout_fetch(0, 0)     # per-rollout finish step / accumulated status bits
+            t0 = time.perf_counter()
+            # The device-packed exchange needs the context's own RCCL communicator spanning the same world as `comm` (or a single process);
+            # any other communicator object (parallel.py: "any object with rank / world / allgather / ...") takes the host-packed path.
+            c_rank, c_world, c_rccl = ctx.comm_info()
+            if self.world > 1 and c_rccl and c_world != self.world:
+                raise RuntimeError("communicator world %d does not match the context's RCCL communicator (world %d)" % (self.world, c_world))
+            device_path = self.world == 1 or (c_rccl and c_world == self.world)
+            recs, lens, n_valid = ctx.rollout_exchange(K, self.T_max) if device_path else self._host_exchange()
+            self.last_exchange = (recs[0].nbytes + lens[0].nbytes, time.perf_counter() - t0)
+            ctx.rollout_end()
+            best = parallel.top_k(recs, lens, K, self.T_max)
+            if len(best) < K:
+                raise RuntimeError("only %d valid laps among %d rollouts (need K = %d): the others did not finish within %d steps or were flagged"
+                                   % (len(best), self.total, K, self.T_max))
+        except Exception:
+            for lap, rows_before in undo:
+                ctx.ss_truncate_lap(lap, rows_before)
+            raise
         self.parents = []
         for x, u, xg, src, T, extra in best:
             ctx.ss_add_trajectory(x, u)
             ctx.model_add_trajectory(x, u)
-            self.parents.append((x, u, xg, extra[:12], self._n_ss() - 1))
+            self.parents.append((x, u, xg, extra[:12], ctx.ss_num_laps() - 1))
         return best
 
     def _host_exchange(self):
@@ -136,12 +160,6 @@ class LmpcGeneration:
                 if done[b] >= 0 and (st[b] & ~_capi.ST_INEXACT) == 0]
         rec, ln = parallel.pack_laps(laps, self.K, self.T_max)
         return self.comm.allgather(rec), self.comm.allgather(ln), len(laps)
-
-    def _n_ss(self):
-        import ctypes as C
-        n = C.c_int()
-        self.ro.ctx.lib.lmpc_ss_num_laps(self.ro.ctx._h, C.byref(n))
-        return n.value
 
 
 def lap_and_exchange(rollouts, x0_all, xLin0, uLin0, K, T_max, comm=None):

@@ -454,6 +454,13 @@ def test_dropin_mpc_variants(built):
     assert Ph.shape == Pr.shape and Ah.shape == Ar.shape and np.array_equal(Ph, Pr) and np.array_equal(qh, qr)
     assert np.array_equal(Ah[:6 * N], Ar[:6 * N]) and np.array_equal(uh[:6 * N], ur[:6 * N])     # F, b: exact; G carries the regression's A_i, B_i (1e-9 parity)
     assert np.allclose(Ah, Ar, rtol=0, atol=1e-8) and np.allclose(uh, ur, rtol=0, atol=1e-8)
+    # ... and an INFEASIBLE hard problem: x0 outside the 1 cm lane (its k = 0 row is fixed by x_0 = x0).  The reference's OSQP reports primal
+    # infeasible and MPC.solve sets feasible = 0 (:277-280); the penalised problem the kernels solve has an optimum, so the library says so itself
+    x_out = gn["x0"][0].copy(); x_out[5] = 5 * bxn
+    hard2 = MPC(p3, pm3)
+    hard2.solve(x_out)
+    assert hard2.feasible == 0 and (int(hard2._out["status"][0]) & _flag("ST_INFEASIBLE"))
+    assert hard2.xPred.shape == (N + 1, 6) and np.all(np.isfinite(hard2.xPred))                  # the penalised optimum is still returned
     lti = MPC(p2)
     lti.solve(gl["x0"][0])
     P, q, A, l, u = orc.assemble_mpc_qp(par, gl["A"][0][0], gl["B"][0][0], None, gl["x0"][0], np.zeros(2))

@@ -118,3 +118,34 @@ def test_bench_gpus_flag_spawns_ranks():
     bad = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, timeout=300,
                          env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
     assert bad.returncode != 0 and b"WORLD_SIZE=1" in bad.stderr
+
+
+def test_rendezvous_rejects_a_stale_id_file(tmp_path, monkeypatch):
+    """A killed launch can leave its id file behind (same parent process, same port).  The file carries its writer's pid: a rank that starts
+    before rank 0 has replaced it must not take the dead writer's id (ncclCommInitRank would hang), and it is created 0600 in a 0700 directory."""
+    import stat
+    import time
+    from racinglmpc_amd import parallel
+    port = 29685
+    monkeypatch.setattr(os, "getppid", os.getpid)                  # the workers' parent is this process
+    monkeypatch.delenv("LMPC_RDZV_NONCE", raising=False); monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    path = parallel._rdzv_file(port)
+    dead = subprocess.Popen([sys.executable, "-c", "pass"]); dead.wait()
+    with open(path, "wb") as f:
+        f.write(b"\xff" * 128 + int(dead.pid).to_bytes(8, "little"))
+    assert stat.S_IMODE(os.stat(os.path.dirname(path)).st_mode) == 0o700
+    script = tmp_path / "rdzv.py"
+    script.write_text(RDZV_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("LMPC_RDZV_NONCE", "TORCHELASTIC_RUN_ID")}
+    late = [subprocess.Popen([sys.executable, str(script), common.ROOT, "1", "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)]
+    time.sleep(1.5)                                                # rank 1 is polling the stale file by now
+    assert late[0].poll() is None
+    late.append(subprocess.Popen([sys.executable, str(script), common.ROOT, "0", "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env))
+    for p in late:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0 and out.decode().startswith("ok"), err.decode()
+    assert not os.path.exists(path)
+    with pytest.raises(ValueError):
+        parallel._rendezvous_id(0, 2, "127.0.0.1", 70000, lambda: bytes(128))
+    monkeypatch.setenv("MASTER_PORT", "65500"); monkeypatch.delenv("LMPC_RDZV_PORT", raising=False)
+    assert 0 < parallel.env_world()[4] < 65536
