@@ -41,6 +41,7 @@ struct lmpc_ctx {
     void *var_dl;                            // dlopen handle when that instantiation lives in its own shared object (lmpc_variant.hip)
     int mw_max_batch, mw2_max_batch, n_cu;   // largest batch served by the four-wave / the two-wave solve kernel
     int fuse_k1;                             // fused step for one-wave batches (LMPC_FUSE=0 turns it off)
+    int cd_ok, cd_hasq, cd_mode;             // condensed one-wave kernel: usable for this configuration / state cost present / LMPC_CD: 0 never, 1 always, (default) by batch size
     int profiling; bool ev_open; std::vector<evpair> events; lmpc_stats stats;
     struct lmpc_rollout_session *ro;
     void *comm; int comm_rank, comm_world;   // RCCL communicator of this rank (lmpc_comm.hip.h); null = single process
@@ -162,6 +163,16 @@ static int create_body(lmpc_ctx *c) {
     // at batch 8192 with eight: the regression's short dependent chains (DPP minima, 5 x 5 Cholesky, scattered L2 reads) want the four waves
     // per SIMD its own kernel gets, the solve kernel runs two.  Off unless LMPC_FUSE=1.
     { const char *e = getenv("LMPC_FUSE"); c->fuse_k1 = e ? atoi(e) : 0; }
+    {   // condensed kernel (lmpc_solve_cd.hip.h): built for 2N <= 32 and one terminal-block column per lane; it takes the state cost as diagonal Q, Qf
+        bool diag = true; c->cd_hasq = 0;
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {
+            if (i != j && (cfg->Q[i * 6 + j] != 0.0 || cfg->Qf[i * 6 + j] != 0.0)) diag = false;
+            if (cfg->Q[i * 6 + j] != 0.0 || cfg->Qf[i * 6 + j] != 0.0) c->cd_hasq = 1;
+            if (i == j && (cfg->Q[i * 6 + j] < 0.0 || cfg->Qf[i * 6 + j] < 0.0)) diag = false;
+        }
+        c->cd_ok = c->var.lds_cd > 0 && diag;
+        const char *e = getenv("LMPC_CD"); c->cd_mode = e ? atoi(e) : 0;
+    }
     HIPCHK(hipStreamCreate(&c->stream));
     const size_t store_elems = (size_t)cfg->max_laps * LMPC_COLS * cfg->max_lap_len;
     HIPCHK(hipMalloc(&c->mstore, store_elems * sizeof(double)));
@@ -477,7 +488,8 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
         rc = nw == 4 ? c->var.launch_mw4(c->stream, c->dp, B, io) : nw == 2 ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     } else
 #endif
-    rc = (io.mode & 4) ? c->var.launch_1w(c->stream, c->dp, B, io)        // fused step: the one-wave kernel runs the regression itself
+    rc = (c->cd_ok && c->cd_mode == 1 && !(io.mode & 4)) ? c->var.launch_cd(c->stream, c->dp, B, io, c->cd_hasq)
+       : (io.mode & 4) ? c->var.launch_1w(c->stream, c->dp, B, io)        // fused step: the one-wave kernel runs the regression itself
        : (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->var.launch_mw4(c->stream, c->dp, B, io)
        : (lmpc_solver_waves(c, B) == 2 && !io.tbuf) ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     ev_end(c);

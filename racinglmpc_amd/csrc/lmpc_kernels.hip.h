@@ -17,7 +17,7 @@
 #include "../../include/lmpc_hip.h"
 
 #define WAVE 64
-#define LMPC_VARIANT_ABI 4              // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change
+#define LMPC_VARIANT_ABI 5              // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change
 #define LMPC_COLS 9                 // lap-store columns: x0..x5, u0, u1, Qfun
 
 struct lmpc_dev_params {

@@ -8,6 +8,7 @@
 #pragma once
 #include "lmpc_kernels.hip.h"
 #include "lmpc_solve_mw.hip.h"
+#include "lmpc_solve_cd.hip.h"
 
 struct lmpc_variant_api {
     int N, S;
@@ -16,6 +17,9 @@ struct lmpc_variant_api {
     int (*launch_retry)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &);   // lmpc_solve_kernel<N,S,true>
     int (*launch_mw4)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &);     // lmpc_solve_kernel_mw<N,S,4>
     int (*launch_mw2)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &);     // lmpc_solve_kernel_mw<N,S,2>
+    size_t lds_cd;                            // condensed one-wave kernel (lmpc_solve_cd.hip.h): dynamic LDS per QP without the state-cost block; 0 = not built for this (N, S)
+    size_t lds_cd_q;                          //   ... with it (Q or Qf non-zero)
+    int (*launch_cd)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &, int hasQ);   // lmpc_solve_kernel_cd<N,S>
 };
 
 template <int N, int S> struct lmpc_variant_launchers {
@@ -34,6 +38,13 @@ template <int N, int S> struct lmpc_variant_launchers {
         hipLaunchKernelGGL((lmpc_solve_kernel<N, S, true>), dim3(B), dim3(WAVE), lds_for(p, io), st, p, B, io); return 0; }
     static int l4(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
         if constexpr (has_mw) { hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 4>), dim3(B), dim3(WAVE * 4), ldsm, st, p, B, io); return 0; } else return l1(st, p, B, io); }
+    static constexpr bool has_cd = 2 * N <= 32 && S + 6 <= WAVE;          // condensed kernel: short horizons, one terminal-block column per lane
+    static int lc(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io, int hasQ) {
+        if constexpr (has_cd) {
+            const size_t lds = (size_t)(hasQ ? solve_ldsc<N, S>::tot_q : solve_ldsc<N, S>::tot) * sizeof(double);
+            hipLaunchKernelGGL((lmpc_solve_kernel_cd<N, S>), dim3(B), dim3(WAVE), lds, st, p, B, io, hasQ); return 0;
+        } else return l1(st, p, B, io);
+    }
     static int l2(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
         if constexpr (has_mw) { hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 2>), dim3(B), dim3(WAVE * 2), ldsm, st, p, B, io); return 0; } else return l1(st, p, B, io); }
 };
@@ -51,5 +62,10 @@ template <int N, int S> static bool lmpc_variant_fill(lmpc_variant_api *v) {
         if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_mw) != hipSuccess) return false;
     }
     v->launch_1w = &L::l1; v->launch_retry = &L::lr; v->launch_mw4 = &L::l4; v->launch_mw2 = &L::l2;
+    v->lds_cd = 0; v->lds_cd_q = 0; v->launch_cd = &L::lc;
+    if constexpr (L::has_cd) {
+        v->lds_cd = (size_t)solve_ldsc<N, S>::tot * sizeof(double); v->lds_cd_q = (size_t)solve_ldsc<N, S>::tot_q * sizeof(double);
+        if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_cd<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_cd_q) != hipSuccess) return false;
+    }
     return true;
 }

@@ -252,3 +252,166 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
                mu=np.concatenate([m_lane.ravel(), m_u.ravel(), m_s.ravel(), m_l]), nu=nu, eta=eta_m)
     out.update(info)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Condensed form (round 3): the states are eliminated, x = X(u) by roll-out, so the only equality row left is sum(lambda) = 1 and the
+# Newton matrix is DENSE in du (2N x 2N: 24 x 24 at N = 12) -- Cholesky instead of the Riccati recursion, dense mat-vecs instead of the
+# backward / forward sweeps.  Same interior-point rules as ipm_solve (start point, capped barrier weights, Mehrotra predictor-corrector,
+# step-length rules, termination).  lmpc_solve_kernel_cd follows this function.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def condense(qp):
+    """Per-QP constants: Su_k = d x_k / d u (6 x 2N, k = 0..N), V_k = Fx Su_k (2 x 2N), G = Su_N, and the constant part of the reduced Hessian
+    Hc0 = blockdiag(R2) + input-rate coupling + sum_k Su_k' Q2 Su_k + G' Qf2 G."""
+    par = qp.par; N = qp.N; nv = 2 * N
+    Su = np.zeros((N + 1, 6, nv))
+    for k in range(N):
+        Su[k + 1] = qp.A[k] @ Su[k]
+        Su[k + 1][:, 2 * k:2 * k + 2] += qp.B[k]
+    V = np.einsum("jc,kcv->kjv", par.Fx, Su[:N])                     # row (k, j) of the lane constraints as a function of du
+    G = Su[N]
+    R2, dR2, Q2, Qf2 = 2 * par.R, 2 * par.dR, 2 * par.Q, 2 * par.Qf
+    H0 = np.zeros((nv, nv))
+    for k in range(N):
+        H0[2 * k:2 * k + 2, 2 * k:2 * k + 2] += R2 + np.diag(dR2) * (2 if k < N - 1 else 1)
+        if k < N - 1:
+            H0[2 * k:2 * k + 2, 2 * k + 2:2 * k + 4] -= np.diag(dR2); H0[2 * k + 2:2 * k + 4, 2 * k:2 * k + 2] -= np.diag(dR2)
+    for k in range(1, N):
+        H0 += Su[k].T @ Q2 @ Su[k]
+    H0 += G.T @ Qf2 @ G
+    return V, G, H0
+
+
+def ipm_solve_cd(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11):
+    par = qp.par; N = qp.N; S = qp.S; Fx, Fu = par.Fx, par.Fu; bx, bu = par.bx, par.bu; nv = 2 * N
+    dR2 = 2 * par.dR; a = 2 * par.Qslack[0]; c1 = par.Qslack[1]
+    Q2, Qf2, R2 = 2 * par.Q, 2 * par.Qf, 2 * par.R; xRef = par.xRef
+    A, B, C = qp.A, qp.B, qp.C
+    T = np.diag(2 * par.QterminalSlack) if qp.term else None
+    V, G, H0 = condense(qp)
+
+    def rollout(u):
+        x = np.zeros((N + 1, 6)); x[0] = qp.x0
+        for k in range(N):
+            x[k + 1] = A[k] @ x[k] + B[k] @ u[k] + C[k]
+        return x
+    u = np.zeros((N, 2)); x = rollout(u)
+    viol = x[:N] @ Fx.T - bx
+    s = np.where(viol > 0, viol + 1.0, 1.0 / c1 if c1 > 1.0 else 1.0)
+    lam = np.ones(S) / S if qp.term else np.zeros(0)
+    eta_m = 0.0
+    t_lane, t_u, t_s, t_l = bx - (x[:N] @ Fx.T - s), bu - u @ Fu.T, s.copy(), lam.copy()
+    mu0 = max(1.0, 0.01 * (np.max(np.abs(qp.Qsel)) if qp.term else 1.0))
+    m_lane, m_u, m_s, m_l = mu0 / t_lane, mu0 / t_u, mu0 / t_s, (mu0 / t_l if qp.term else np.zeros(0))
+    mtot = 8 * N + S
+    sep = False; gap_prev = None
+    qscale = max(1.0, float(np.max(np.abs(qp.Qsel)))) if qp.term else 1.0
+    info = {}
+    E7 = np.vstack([qp.SS, np.ones(S)]) if qp.term else None
+    for it in range(maxit):
+        ts = (t_lane, t_u, t_s, t_l); ms = (m_lane, m_u, m_s, m_l)
+        gap = sum(t.ravel() @ m.ravel() for t, m in zip(ts, ms)) / mtot
+        if gap_prev is not None:
+            sep = gap > 0.1 * gap_prev
+        gap_prev = gap
+        # ---- residuals: adjoint recursion p_k = w_k + A_k' p_{k+1} gives the state part of the u rows
+        sT = qp.SS @ lam - x[N] if qp.term else None
+        p = Qf2 @ (x[N] - xRef) - (T * sT if qp.term else 0)
+        ru = np.zeros((N, 2))
+        for k in range(N - 1, -1, -1):
+            upv = u[k - 1] if k > 0 else qp.uOld
+            g = R2 @ u[k] + dR2 * (u[k] - upv) + Fu.T @ m_u[k]
+            if k < N - 1:
+                g = g + dR2 * (u[k] - u[k + 1])
+            ru[k] = g + B[k].T @ p
+            if k > 0:
+                p = Q2 @ (x[k] - xRef) + Fx.T @ m_lane[k] + A[k].T @ p
+        rs = a * s + c1 - m_lane - m_s
+        rl = (qp.Qsel - m_l + qp.SS.T @ (T * sT) + eta_m) if qp.term else np.zeros(0)
+        re_sum = (lam.sum() - 1.0) if qp.term else 0.0
+        rd = max(np.abs(ru).max(), np.abs(rs).max(), np.abs(rl).max() if qp.term else 0)
+        re = abs(re_sum)
+        if verbose:
+            print("it %2d gap %.2e rd %.2e re %.2e" % (it, gap, rd, re))
+        info = dict(iters=it, gap=gap, rd=rd, re=re)
+        if gap < tol_gap and rd < tol_res * qscale and re < tol_res:
+            break
+        cap = (lambda t, m: np.maximum(t, m / th_max))
+        rts = [1.0 / cap(t, m) if t.size else t for t, m in zip(ts, ms)]
+        th_lane, th_u, th_s, th_l = ths = [m * rt for m, rt in zip(ms, rts)]
+        # ---- factorisation: terminal 7 x 7 block as before, then the dense reduced Hessian
+        Ds = a + th_lane + th_s; kap = th_lane * (a + th_s) / Ds
+        Hc = H0.copy()
+        for k in range(N):
+            Hc[2 * k:2 * k + 2, 2 * k:2 * k + 2] += (Fu.T * th_u[k]) @ Fu
+            Hc += (V[k].T * kap[k]) @ V[k]
+        if qp.term:
+            D = th_l + reg_l; sqD = np.sqrt(D)
+            Mt = np.vstack([(E7 / sqD).T, np.diag(np.concatenate([1 / np.sqrt(T), [0]]))[:6]])
+            Qm, R = mgs_QR(Mt); Ri = tri_inv_upper(R)
+            PiT = (Ri @ Ri.T)[:6, :6]
+            Hc += G.T @ PiT @ G
+        L = np.linalg.cholesky(Hc)
+
+        def solve(h_lane, h_u, h_s, h_l):
+            e = -(rs + h_lane + h_s)
+            eta = h_lane + th_lane * e / Ds
+            g = ru.ravel() - (h_u @ Fu).ravel() - np.einsum("kjv,kj->v", V, eta)
+            if qp.term:
+                ct = np.concatenate([(rl + h_l) / sqD, np.zeros(6)])
+                y7 = Qm.T @ ct
+                d0 = np.concatenate([np.zeros(6), [-re_sum]])
+                g = g + G.T @ (Ri @ (Ri.T @ d0 + y7))[:6]
+            du = -np.linalg.solve(L.T, np.linalg.solve(L, g))
+            fl = np.einsum("kjv,v->kj", V, du)
+            ds = (th_lane * fl + e) / Ds
+            dl = None; dxN = G @ du
+            if qp.term:
+                d7 = np.concatenate([dxN, [-re_sum]])
+                v = -(ct - Qm @ y7) + Qm @ (Ri.T @ d7)
+                dl = v[:S] / sqD
+            return du.reshape(N, 2), fl, ds, dl, dxN
+
+        hp = [t * m * rt for t, m, rt in zip(ts, ms, rts)]
+        dua, fla, dsa, dla, _ = solve(*hp)
+        steps = lambda du, fl, ds, dl: (-(fl - ds), -(du @ Fu.T), ds, (dl if qp.term else np.zeros(0)))
+        dt = steps(dua, fla, dsa, dla)
+        dma = [-h_ - th * d for h_, th, d in zip(hp, ths, dt)]
+
+        def maxstep(vs, dvs):
+            al = np.inf
+            for v, dv in zip(vs, dvs):
+                v = v.ravel(); dv = dv.ravel(); neg = dv < 0
+                if neg.any():
+                    al = min(al, np.min(-v[neg] / dv[neg]))
+            return al
+        aap = min(1.0, maxstep(ts, dt)); aad = min(1.0, maxstep(ms, dma))
+        if not sep:
+            aap = aad = min(aap, aad)
+        gap_aff = sum(((t + aap * d).ravel() @ (m + aad * dm).ravel()) for t, d, m, dm in zip(ts, dt, ms, dma)) / mtot
+        sig = (gap_aff / gap) ** 3
+        tgt = max(sig * gap, 0.01 * tol_gap)
+        rc = [t * m - tgt + d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]
+        hs = [r * rt for r, rt in zip(rc, rts)]
+        du, fl, ds, dl, dxN = solve(*hs)
+        dt = steps(du, fl, ds, dl)
+        dm = [-h_ - th * d for h_, th, d in zip(hs, ths, dt)]
+        frac = max(0.995, 1.0 - 10.0 * gap) if sig < 1e-3 else 0.995
+        al = min(1.0, frac * maxstep(ts, dt)); ald = min(1.0, frac * maxstep(ms, dm))
+        if not sep:
+            al = ald = min(al, ald)
+        deta = 0.0
+        if qp.term:
+            dsT = qp.SS @ dl - dxN
+            deta = np.mean(-rl + dm[3] - qp.SS.T @ (T * dsT))
+        u = u + al * du; s = s + al * ds
+        if qp.term:
+            lam = lam + al * dl
+        x = rollout(u)
+        t_lane, t_u, t_s, t_l = [t + al * d for t, d in zip(ts, dt)]
+        m_lane, m_u, m_s, m_l = [m + ald * d for m, d in zip(ms, dm)]
+        eta_m += ald * deta
+    out = dict(x=x, u=u, s=s, lam=lam, sT=(qp.SS @ lam - x[N]) if qp.term else None,
+               mu=np.concatenate([m_lane.ravel(), m_u.ravel(), m_s.ravel(), m_l]), eta=eta_m)
+    out.update(info)
+    return out
