@@ -84,6 +84,7 @@ typedef struct {
     long long qp_solved;              /* problems passed through the solve kernel */
     long long ipm_iters;              /* interior-point iterations accumulated by the host-buffer entry points (lmpc_step_batch, lmpc_qp_solve_batch) */
     long long n_regress_timed, n_solve_timed;   /* launches that carried events: ms_regress / n_regress_timed is the average kernel duration */
+    long long n_retry;                /* retry passes launched on demand (a problem of the batch ended at the iteration limit / broke down; see lmpc_capi.hip) */
 } lmpc_stats;
 
 int lmpc_config_default(lmpc_config *cfg);                       /* reference defaults, N = 12 */

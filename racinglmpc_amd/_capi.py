@@ -34,7 +34,7 @@ class LmpcConfig(C.Structure):
 
 class LmpcStats(C.Structure):
     _fields_ = [("ms_regress", C.c_double), ("ms_solve", C.c_double), ("n_regress", C.c_longlong), ("n_solve", C.c_longlong),
-                ("qp_solved", C.c_longlong), ("ipm_iters", C.c_longlong), ("n_regress_timed", C.c_longlong), ("n_solve_timed", C.c_longlong)]
+                ("qp_solved", C.c_longlong), ("ipm_iters", C.c_longlong), ("n_regress_timed", C.c_longlong), ("n_solve_timed", C.c_longlong), ("n_retry", C.c_longlong)]
 
 
 class StepDevArgs(C.Structure):

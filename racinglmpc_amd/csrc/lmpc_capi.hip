@@ -43,6 +43,9 @@ struct lmpc_ctx {
     int fuse_k1;                             // fused step for one-wave batches (LMPC_FUSE=0 turns it off)
     int cd_ok, cd_hasq, cd_mode;             // condensed one-wave kernel: usable for this configuration / state cost present / LMPC_CD: 0 never, 1 always, (default) by batch size
     int profiling; bool ev_open; std::vector<evpair> events; lmpc_stats stats;
+    // retry pass on demand: launches since the last drain of the stream, the host-mapped ring the kernels flag themselves in, launch counter
+    struct pending_solve { lmpc_solve_io io; int B; int epoch; };
+    std::vector<pending_solve> pending; int *h_retry, *d_retry; int epoch;
     struct lmpc_rollout_session *ro;
     void *comm; int comm_rank, comm_world;   // RCCL communicator of this rank (lmpc_comm.hip.h); null = single process
 };
@@ -131,6 +134,7 @@ static void fill_params(lmpc_ctx *c) {
 
 }  // extern "C" (helpers)
 
+#define LMPC_RETRY_RING 64
 #define LMPC_SLAB_COPY_MAX ((size_t)256 * 1024)     // one-copy path of lmpc_step_batch up to this many output bytes (batch 1 .. ~16)
 
 // everything of lmpc_create that can fail; the caller destroys the context on any error (one failure path, no leaks)
@@ -174,6 +178,9 @@ static int create_body(lmpc_ctx *c) {
         const char *e = getenv("LMPC_CD"); c->cd_mode = e ? atoi(e) : 0;
     }
     HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipHostMalloc(&c->h_retry, sizeof(int) * LMPC_RETRY_RING, hipHostMallocMapped));
+    memset(c->h_retry, 0, sizeof(int) * LMPC_RETRY_RING);
+    HIPCHK(hipHostGetDevicePointer((void **)&c->d_retry, c->h_retry, 0));
     const size_t store_elems = (size_t)cfg->max_laps * LMPC_COLS * cfg->max_lap_len;
     HIPCHK(hipMalloc(&c->mstore, store_elems * sizeof(double)));
     HIPCHK(hipMalloc(&c->sstore, store_elems * sizeof(double)));
@@ -243,6 +250,7 @@ int lmpc_destroy(lmpc_ctx *c) {
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     void *ptrs[] = {c->mstore, c->sstore, c->mquant, c->mqpar, c->slab_in, c->slab_out};      // (the w_* work buffers are ranges of the two slabs)
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (c->h_retry) (void)hipHostFree(c->h_retry);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -476,7 +484,35 @@ static int launch_regress(lmpc_ctx *c, int B, const double *d_xLin, int xstride,
     return LMPC_OK;
 }
 extern "C" int lmpc_solver_waves(lmpc_ctx *c, int B);
-static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
+// Retry pass on demand.  The adaptive equal / separate step rule can fall into a two-cycle (a separate step feeds (alpha_p - alpha_d) H dw into
+// the dual residual, the next equal step is blocked): a few problems per million ended at the iteration limit that way in round 1, and most
+// of them converge in 10-12 iterations from the start point with equal steps only (lmpc_solve_kernel<N, S, true>).  Rounds 1-2 launched that
+// retry kernel behind EVERY solve -- 4.4 us per step in which all work-groups return at once (1.9 % of a batch-256 step, 3 % at batch 1).  Now a
+// problem that needs it says so itself: it writes the launch's epoch into a host-mapped ring (flag_retry, system-scope atomic), and the host
+// looks at the ring at its next drain of the stream, before any result of the launch can be read: lmpc_step_batch / lmpc_qp_solve_batch
+// right after the solve, the device-resident path in lmpc_dev_sync / lmpc_dev_download / lmpc_dev_free.  The retry kernel skips problems
+// whose CURRENT status word is clean, so a flagged launch whose buffers a later launch reused is handled correctly.  Closed-loop rollouts
+// (lmpc_rollout_run), where the plant consumes uPred without a host round trip, keep the unconditional launch (immediate = true).
+static int resolve_retries(lmpc_ctx *c) {
+    if (c->pending.empty()) return LMPC_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &pe : c->pending) {
+        if (c->h_retry[pe.epoch % LMPC_RETRY_RING] != pe.epoch) continue;
+        pe.io.retry_flag = nullptr;
+        int rc = c->var.launch_retry(c->stream, c->dp, pe.B, pe.io); if (rc) { c->pending.clear(); return rc; }
+        HIPCHK(hipGetLastError());
+        c->stats.n_retry++;
+    }
+    c->pending.clear();
+    return LMPC_OK;
+}
+static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io_in, bool immediate = false) {
+    lmpc_solve_io io = io_in;
+    const bool deferred = (io.mode & 2) && !immediate && !io.tbuf;
+    if (deferred) {
+        if ((int)c->pending.size() >= LMPC_RETRY_RING - 1) { int rc = resolve_retries(c); if (rc) return rc; }
+        c->epoch++; io.retry_epoch = c->epoch; io.retry_flag = c->d_retry + (c->epoch % LMPC_RETRY_RING);
+    }
     const bool term = c->cfg.numSS_it > 0;
     int rc = refresh_params(c, false, term && (io.mode & 1)); if (rc) return rc;
     ev_begin(c, 1);
@@ -496,11 +532,8 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io) {
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     c->stats.n_solve++; if (io.mode & 2) c->stats.qp_solved += B;
-    if (io.mode & 2) {
-        // Retry pass: the adaptive equal / separate step rule can fall into a two-cycle (a separate step feeds (alpha_p - alpha_d) H dw
-        // into the dual residual, the next equal step is blocked) -- about 6 problems per million in closed loop end at the iteration
-        // limit that way, and most of them converge in 10-12 iterations from the start point with equal steps only.  A second launch
-        // (1-wave kernel, equal-step variant) re-runs exactly those: every other work-group returns at once (~1.5 us per launch).
+    if (deferred) c->pending.push_back({io, B, io.retry_epoch});
+    else if (io.mode & 2) {
         rc = c->var.launch_retry(c->stream, c->dp, B, io);
         if (rc) return rc;
         HIPCHK(hipGetLastError());
@@ -571,6 +604,7 @@ int lmpc_qp_solve_batch(lmpc_ctx *c, int B, const double *A, const double *Bm, c
     io.xPred = c->w_xPred; io.uPred = c->w_uPred; io.slack = c->w_slack; io.lambda = c->w_lam; io.sTerm = c->w_sT; io.mu = c->w_mu; io.resid = c->w_resid;
     io.status = c->w_status; io.iters = c->w_iters;
     int rc = launch_solve(c, B, io); if (rc) return rc;
+    rc = resolve_retries(c); if (rc) return rc;          // drains the stream; a flagged problem gets its retry pass before anything is copied out
     D2H(xPred, c->w_xPred, (size_t)B * (N + 1) * 6); D2H(uPred, c->w_uPred, (size_t)B * N * 2); D2H(slack, c->w_slack, (size_t)B * N * 2);
     if (S > 0) { D2H(lambda, c->w_lam, (size_t)B * S); D2H(sTerm, c->w_sT, (size_t)B * 6); }
     D2H(mu, c->w_mu, (size_t)B * M); D2H(status, c->w_status, B); D2H(resid, c->w_resid, (size_t)B * 3);
@@ -636,6 +670,7 @@ int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, co
     a.xPred = c->w_xPred; a.uPred = c->w_uPred; a.slack = c->w_slack; a.lambda = c->w_lam; a.sTerm = c->w_sT; a.ztNext = c->w_ztN; a.ztuNext = c->w_ztuN;
     a.ssSel = c->w_ssSel; a.qSel = c->w_qSel; a.A = c->w_A; a.Bm = c->w_B; a.C = c->w_C; a.mu = c->w_mu; a.resid = c->w_resid; a.status = c->w_status; a.iters = c->w_iters;
     int rc = lmpc_step_batch_dev(c, B, &a); if (rc) return rc;
+    rc = resolve_retries(c); if (rc) return rc;          // drains the stream; a flagged problem gets its retry pass before anything is copied out
     if (one_copy) {
         // everything up to (not including) the selection-only buffers w_succ ..: one copy into the pinned mirror, then plain memcpys
         const size_t nbytes = (size_t)((char *)c->w_succ - c->slab_out);
@@ -695,10 +730,10 @@ int lmpc_assemble_batch(lmpc_ctx *c, int B, const double *A, const double *Bm, c
 
 // ---------------------------------------------------------------------------------------------- device buffers
 int lmpc_dev_alloc(lmpc_ctx *c, long long bytes, void **dptr) { ARGCHK(c && dptr && bytes > 0); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipMalloc(dptr, (size_t)bytes)); return LMPC_OK; }
-int lmpc_dev_free(lmpc_ctx *c, void *dptr) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipFree(dptr)); return LMPC_OK; }
+int lmpc_dev_free(lmpc_ctx *c, void *dptr) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); { int rc = resolve_retries(c); if (rc) return rc; } HIPCHK(hipFree(dptr)); return LMPC_OK; }
 int lmpc_dev_upload(lmpc_ctx *c, void *dptr, const void *host, long long bytes) { ARGCHK(c && dptr && host); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipMemcpyAsync(dptr, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
-int lmpc_dev_download(lmpc_ctx *c, void *host, const void *dptr, long long bytes) { ARGCHK(c && dptr && host); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipMemcpyAsync(host, dptr, (size_t)bytes, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
-int lmpc_dev_sync(lmpc_ctx *c) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
+int lmpc_dev_download(lmpc_ctx *c, void *host, const void *dptr, long long bytes) { ARGCHK(c && dptr && host); HIPCHK(hipSetDevice(c->cfg.device)); { int rc = resolve_retries(c); if (rc) return rc; } HIPCHK(hipMemcpyAsync(host, dptr, (size_t)bytes, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
+int lmpc_dev_sync(lmpc_ctx *c) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); { int rc = resolve_retries(c); if (rc) return rc; } HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
 
 // timing build only: one solve of problem 0 of a host batch with cycle stamps (tools/phase_timing.py)
 int lmpc_debug_timing(lmpc_ctx *c, const double *A, const double *Bm, const double *C, const double *x0, const double *uOld,
@@ -839,7 +874,7 @@ int lmpc_rollout_run(lmpc_ctx *c, int max_steps, int *steps_total, int *n_done) 
         io.timeStep = r->d_tstep; io.xPred = r->d_xPred; io.uPred = r->d_uPred; io.slack = r->d_slack; io.lambda = r->d_lam; io.sTerm = r->d_sT; io.ztNext = r->d_ztN;
         io.ztuNext = r->d_ztuN; io.resid = r->d_resid; io.status = r->d_status; io.iters = r->d_iters; io.rstatus = r->d_rst;
         if (r->t > 0) HIPCHK(hipStreamWaitEvent(c->stream, r->e_plant, 0));          // the solve needs the plant's new state
-        rc = launch_solve(c, B, io); if (rc) return rc;
+        rc = launch_solve(c, B, io, true); if (rc) return rc;      // (the plant consumes uPred without a host round trip: unconditional retry pass)
         HIPCHK(hipEventRecord(r->e_solved, c->stream));
         HIPCHK(hipStreamWaitEvent(r->pstream, r->e_solved, 0));
         hipLaunchKernelGGL(lmpc_rollout_plant_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, r->pstream, c->dp, B, r->t, st);

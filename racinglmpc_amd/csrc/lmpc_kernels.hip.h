@@ -17,7 +17,7 @@
 #include "../../include/lmpc_hip.h"
 
 #define WAVE 64
-#define LMPC_VARIANT_ABI 5              // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change
+#define LMPC_VARIANT_ABI 6              // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change
 #define LMPC_COLS 9                 // lap-store columns: x0..x5, u0, u1, Qfun
 
 struct lmpc_dev_params {
@@ -96,7 +96,12 @@ struct lmpc_solve_io {
     int *selStartOut;         // optional: first row of the 13-row window per selected lap (B x numSS_it)
     int *status, *iters;
     long long *tbuf;          // optional cycle stamps of problem 0 (builds with -DLMPC_TIMING only)
+    int *retry_flag;          // optional (host-mapped): a problem that ends at the iteration limit / breaks down writes retry_epoch here (atomic max, system
+    int retry_epoch;          // scope), so that the host launches the retry pass only when one is needed (lmpc_capi.hip: resolve_retries)
 };
+__device__ __forceinline__ void flag_retry(const lmpc_solve_io &io, int st) {
+    if (io.retry_flag && (st & (LMPC_ST_MAXITER | LMPC_ST_NUMERIC))) __hip_atomic_fetch_max(io.retry_flag, io.retry_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 #ifdef LMPC_TIMING
 #define TSTAMP(id) do { if (io.tbuf && b == 0 && lane == 0 && tcnt < 4000) { io.tbuf[2 * tcnt] = (id); io.tbuf[2 * tcnt + 1] = (long long)__builtin_readcyclecounter(); tcnt++; } } while (0)
@@ -999,6 +1004,41 @@ __device__ __forceinline__ double term_costate(const double *Ri, double mc, doub
     return sum_over_c(on2 ? r2 * b2 : 0.0);
 }
 
+// Terminal factor, small part, one row per lane (used by the condensed kernel, lmpc_solve_cd.hip.h): W7 = M M' (7 x 7, symmetric, 8 x 8 row-major in
+// LDS) -> Ri = R^-1 with R'R = W7 (upper triangular, 7 x 7 row-major in LDS, zeros below the diagonal).  Lane i < 7 holds row i of L7 = R' (Cholesky
+// W7 = L7 L7', pivot column broadcast by v_readlane), then row i of X = L7^-1 (forward elimination on the identity); Ri = X'.  Returns non-zero if a
+// pivot is not positive.  (In the Riccati kernels the wave-uniform form below measured better: there this version costs 28 VGPRs of a full file.)
+__device__ __forceinline__ int term_factor7(const double *Wl, double *Ri, int lane) {
+    const int r7 = lane < 7 ? lane : 0;
+    int bad = 0;
+    double wr[7], xr[7], rd7 = 1.0;
+#pragma unroll
+    for (int j = 0; j < 7; j++) { wr[j] = (lane < 7 && j <= lane) ? Wl[r7 * 8 + j] : 0.0; xr[j] = lane == j ? 1.0 : 0.0; }
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        double d_ = rdlane(wr[j], j);
+        if (!(d_ > 0.0)) { bad = 1; d_ = 1.0; }
+        const double ri = frsqrt(d_);
+        const double lij = lane == j ? d_ * ri : ((lane > j && lane < 7) ? wr[j] * ri : 0.0);
+        wr[j] = lij; rd7 = lane == j ? ri : rd7;
+#pragma unroll
+        for (int k = j + 1; k < 7; k++) wr[k] = fma(-lij, rdlane(lij, k), wr[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) {                                     // row k of X is final once scaled by 1 / L[k][k]; the rows below subtract L[i][k] times it
+#pragma unroll
+        for (int c = 0; c <= k; c++) {
+            const double xk = rdlane(xr[c] * rd7, k);
+            xr[c] = lane == k ? xk : ((lane > k && lane < 7) ? fma(-wr[k], xk, xr[c]) : xr[c]);
+        }
+    }
+    if (lane < 7) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) Ri[i * 7 + lane] = xr[i];          // Ri[i][j] = X[j][i]
+    }
+    return bad;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: safe-set selection.  LMPC.addTerminalComponents :392-412 and selectPoints :478-514.  Shared by the one-wave and the
 // multi-wave solve kernels: wave `wave` of NW handles laps wave, wave + NW, ...; results go to SS (6 x S, row-major), Qsel (S),
@@ -1744,7 +1784,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     }
     TSTAMP(21);
     if (lane == 0) {
-        io.status[b] = st_sh; io.iters[b] = it;
+        io.status[b] = st_sh; io.iters[b] = it; flag_retry(io, st_sh);
         if (io.resid) { io.resid[(size_t)b * 3] = gap; io.resid[(size_t)b * 3 + 1] = rdn; io.resid[(size_t)b * 3 + 2] = ren; }
     }
 }

@@ -460,35 +460,7 @@ __global__ __launch_bounds__(WAVE, 2) void lmpc_solve_kernel_cd(lmpc_dev_params 
             }
             __syncthreads();
             TSTAMP(50);
-            {   // W7 = L7 L7' with one row per lane (lanes 0 .. 6; pivot column broadcast by v_readlane), X = L7^-1 row by row, Ri = R^-1 = X' for R = L7'.
-                // (The uniform-across-lanes form of lmpc_solve_kernel keeps the 28 + 28 entries of R and R^-1 in scalar registers: 100+ SGPRs, spilled.)
-                const int r7 = lane < 7 ? lane : 0;
-                double wr[7], xr[7], rd7 = 1.0;
-#pragma unroll
-                for (int j = 0; j < 7; j++) { wr[j] = (lane < 7 && j <= lane) ? Wl[r7 * 8 + j] : 0.0; xr[j] = lane == j ? 1.0 : 0.0; }
-#pragma unroll
-                for (int j = 0; j < 7; j++) {
-                    double d_ = rdlane(wr[j], j);
-                    if (!(d_ > 0.0)) { numeric_bad = 1; d_ = 1.0; }
-                    const double ri = frsqrt(d_);
-                    const double lij = lane == j ? d_ * ri : ((lane > j && lane < 7) ? wr[j] * ri : 0.0);
-                    wr[j] = lij; rd7 = lane == j ? ri : rd7;
-#pragma unroll
-                    for (int k = j + 1; k < 7; k++) wr[k] = fma(-lij, rdlane(lij, k), wr[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 7; k++) {                                     // row k of X is final once scaled by 1 / L[k][k]; rows below subtract L[i][k] times it
-#pragma unroll
-                    for (int c = 0; c <= k; c++) {
-                        const double xk = rdlane(xr[c] * rd7, k);
-                        xr[c] = lane == k ? xk : ((lane > k && lane < 7) ? fma(-wr[k], xk, xr[c]) : xr[c]);
-                    }
-                }
-                if (lane < 7) {
-#pragma unroll
-                    for (int i = 0; i < 7; i++) Ri[i * 7 + lane] = xr[i];          // Ri[i][j] = X[j][i]
-                }
-            }
+            numeric_bad |= term_factor7(Wl, Ri, lane);                                   // R'R = W7 (Cholesky), Ri = R^-1: one row per lane
             __syncthreads();
             TSTAMP(51);
             // Y = P' G, P = Ri[0:6, 0:7]:  rows 2N .. 2N + 6 of W
@@ -705,7 +677,7 @@ __global__ __launch_bounds__(WAVE, 2) void lmpc_solve_kernel_cd(lmpc_dev_params 
     }
     TSTAMP(21);
     if (lane == 0) {
-        io.status[b] = st_sh; io.iters[b] = it;
+        io.status[b] = st_sh; io.iters[b] = it; flag_retry(io, st_sh);
         if (io.resid) { io.resid[(size_t)b * 3] = gap; io.resid[(size_t)b * 3 + 1] = rdn; io.resid[(size_t)b * 3 + 2] = ren; }
     }
 }

@@ -789,7 +789,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         if (tid < 2 && io.ztuNext) io.ztuNext[(size_t)b * 2 + tid] = u[(N - 1) * 2 + tid];
     }
     if (tid == 0) {
-        io.status[b] = st_sh; io.iters[b] = it;
+        io.status[b] = st_sh; io.iters[b] = it; flag_retry(io, st_sh);
         if (io.resid) { io.resid[(size_t)b * 3] = gap; io.resid[(size_t)b * 3 + 1] = rdn; io.resid[(size_t)b * 3 + 2] = ren; }
     }
 #undef FOR_OFF
