@@ -275,8 +275,19 @@ def main():
     if args.dry_run:
         uid = parallel._rendezvous_id(rank, world, addr, port, lambda: bytes(range(128)))
         assert uid == bytes(range(128))
+        # the host-side wait the ranks without extras use while rank 0 runs its extra configurations (no collective involved)
+        if rank == 0:
+            time.sleep(0.3); sig = parallel.host_signal("extras", port)
+        else:
+            parallel.host_wait("extras", port, timeout=60.0)
         if rank == 0:   # rank 0 has served the id to world - 1 peers: every rank started and reached the rendezvous
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_at_rendezvous": world}))
+            time.sleep(0.3)
+            try:
+                os.remove(sig)
+            except OSError:
+                pass
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_at_rendezvous": world, "host_wait": "file",
+                              "multi_rank_keys": ["per_rank_ms_per_step", "barrier_us", "timed_region_ms", "rccl_ranks", "exchange_seconds"]}))
         return
 
     import __graft_entry__ as ge
@@ -294,7 +305,12 @@ def main():
         comm.barrier()
 
     dt, st = time_steps(ctx, B, a, args.steps, args.warmup, sync=sync_all)
-    dt = float(comm.allreduce_max(dt)[0])
+    dt_ranks = comm.allgather(np.array([dt], dtype=np.float64)).reshape(-1)         # every rank's own clock around the same K steps
+    dt = float(dt_ranks.max())
+    tb = time.perf_counter()
+    for _ in range(5):
+        sync_all()                                     # what ends the timed region: one all-reduce enqueued on the stream + one drain (empty stream here)
+    barrier_us = (time.perf_counter() - tb) / 5 * 1e6
 
     status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32)
     ctx.dev_download(a.status, status); ctx.dev_download(a.iters, iters)
@@ -321,6 +337,8 @@ def main():
             "metric": "QP solves/sec (N=%d, nx=6, nu=2)" % N, "value": world * B * args.steps / dt, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "timed_region_ms": dt * 1e3, "per_rank_ms_per_step": [float(v) / args.steps * 1e3 for v in dt_ranks], "barrier_us": barrier_us,
+            "rccl_ranks": comm_info[1] if comm_info[2] else 0,
             "config": {"workload": "batch=%d LMPC QPs per GPU, N=%d, fixed safe-set (4x PID seed lap, 48 points from 4 laps), full step a3-a19" % (B, N),
                        "batch_per_gpu": B, "N": N, "numSS_points": S, "laps_scanned": 4, "rows_per_lap": 1000,
                        "solver": "Riccati-structured primal-dual interior point to certified optimum (gap<1e-11, res<1e-9)",
@@ -344,8 +362,11 @@ def main():
     for p in keep:
         ctx.dev_free(p)
 
-    # ---- extra configurations (rank 0's GPU; the other ranks wait at the rollout leg's first barrier) ------------------------------
+    # ---- extra configurations (rank 0's GPU; the other ranks sleep on a host-side event meanwhile: no rank spins in a collective) ----------
     if not args.no_extras:
+        host_event = world > 1 and parallel._is_local(addr)
+        if rank != 0 and host_event:
+            parallel.host_wait("extras", port)
         if rank == 0:
             try:                                       # (an extra configuration that fails must not cost the headline line)
                 sweep = {}
@@ -363,6 +384,8 @@ def main():
                 out["config_N40_batch1024"] = dict(run_config(g, 40, 1024, local, steps=5, warmup=2), note="BASELINE configs[4]")
             except Exception as e:                     # noqa: BLE001
                 out["extras_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+            if host_event:
+                sig_path = parallel.host_signal("extras", port)
         try:                                         # (deterministic failures -- e.g. too few valid laps -- occur on every rank alike)
             leg = rollout_leg(g, comm, ctx, args.rollouts_per_gpu)
         except RuntimeError as e:
@@ -380,6 +403,11 @@ def main():
     # the JSON line must be the LAST thing on the job's stdout: every rank drains its buffers, THEN the ranks meet at the barrier, then rank 0 prints
     drain_stdio()
     comm.barrier()
+    if rank == 0 and not args.no_extras and world > 1 and parallel._is_local(addr):
+        try:
+            os.remove(sig_path)
+        except (OSError, NameError):
+            pass
     comm.close()
     ctx.close()
     drain_stdio()

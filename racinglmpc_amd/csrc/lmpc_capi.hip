@@ -48,6 +48,8 @@ struct lmpc_ctx {
     std::vector<pending_solve> pending; int *h_retry, *d_retry; int epoch;
     struct lmpc_rollout_session *ro;
     void *comm; int comm_rank, comm_world;   // RCCL communicator of this rank (lmpc_comm.hip.h); null = single process
+    double *ext_rows; size_t ext_rows_bytes;   // staging buffer of lmpc_ss_extend_lap
+    void *comm_scr, *comm_scr_h; size_t comm_scr_bytes;   // communicator scratch: device allocation + pinned host mirror (lmpc_comm.hip.h: comm_scratch)
 };
 
 #ifdef LMPC_DEV_FAST
@@ -247,6 +249,9 @@ int lmpc_destroy(lmpc_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rollout_free(c);
     if (c->comm) { (void)ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+    if (c->ext_rows) (void)hipFree(c->ext_rows);
+    if (c->comm_scr) (void)hipFree(c->comm_scr);
+    if (c->comm_scr_h) (void)hipHostFree(c->comm_scr_h);
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     void *ptrs[] = {c->mstore, c->sstore, c->mquant, c->mqpar, c->slab_in, c->slab_out};      // (the w_* work buffers are ranges of the two slabs)
     for (void *q : ptrs) if (q) (void)hipFree(q);
@@ -927,15 +932,20 @@ int lmpc_ss_extend_lap(lmpc_ctx *c, int lap, const double *x, const double *u, i
         for (int j = 0; j < 6; j++) r[j] = x[(size_t)i * 6 + j];
         r[4] += c->cfg.trackLength; r[6] = u[(size_t)i * 2]; r[7] = u[(size_t)i * 2 + 1]; r[8] = q;
     }
-    double *d_rows; HIPCHK(hipMalloc(&d_rows, rows.size() * sizeof(double)));
+    if (rows.size() * sizeof(double) > c->ext_rows_bytes) {       // staging buffer of the batched addPoint: grown once, kept
+        if (c->ext_rows) (void)hipFree(c->ext_rows);
+        c->ext_rows = nullptr; c->ext_rows_bytes = 0;
+        const size_t want = std::max<size_t>(rows.size() * sizeof(double), (size_t)64 * LMPC_COLS * sizeof(double));
+        HIPCHK(hipMalloc(&c->ext_rows, want)); c->ext_rows_bytes = want;
+    }
+    double *d_rows = c->ext_rows;
     hipError_t e = hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         double *base = c->sstore + (size_t)lap * LMPC_COLS * c->cfg.max_lap_len;
         hipLaunchKernelGGL(lmpc_store_rows_kernel, dim3((n * LMPC_COLS + 255) / 256), dim3(256), 0, c->stream, base, c->cfg.max_lap_len, c->s_len[lap], n, (const double *)d_rows);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // rows (host) and d_rows are released below
-    (void)hipFree(d_rows);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // (the pageable host rows must outlive the copy)
     if (e != hipSuccess) return set_err(LMPC_E_HIP, "lmpc_ss_extend_lap", hipGetErrorString(e));
     c->s_len[lap] += n; c->s_qlast[lap] = q;
     return LMPC_OK;

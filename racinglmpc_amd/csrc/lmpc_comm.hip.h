@@ -29,6 +29,22 @@ __global__ void lmpc_pack_laps_kernel(int B, int K, int T_max, const int *__rest
     }
 }
 
+// Scratch of the communicator: one device allocation and one pinned host mirror, made by lmpc_comm_init (and on first use in a single process),
+// grown only if a call needs more -- no hipMalloc / hipFree inside allreduce / allgather / the per-lap exchange (each costs tens of microseconds
+// and a device-wide synchronisation, which would read as "scaling loss" at the end of a 5 ms timed region).
+static int comm_scratch(lmpc_ctx *c, size_t bytes) {
+    if (bytes <= c->comm_scr_bytes) return LMPC_OK;
+    size_t want = std::max<size_t>(bytes, (size_t)64 * 1024);
+    want = (want + 4095) & ~(size_t)4095;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->comm_scr) { (void)hipFree(c->comm_scr); c->comm_scr = nullptr; }
+    if (c->comm_scr_h) { (void)hipHostFree(c->comm_scr_h); c->comm_scr_h = nullptr; }
+    c->comm_scr_bytes = 0;
+    HIPCHK(hipMalloc(&c->comm_scr, want)); HIPCHK(hipHostMalloc(&c->comm_scr_h, want));
+    c->comm_scr_bytes = want;
+    return LMPC_OK;
+}
+
 extern "C" {
 
 int lmpc_comm_unique_id(unsigned char *id /*LMPC_COMM_ID_BYTES*/) {
@@ -47,7 +63,7 @@ int lmpc_comm_init(lmpc_ctx *c, const unsigned char *id, int rank, int world) {
     ncclComm_t comm;
     NCCLCHK(ncclCommInitRank(&comm, world, u, rank));
     c->comm = comm; c->comm_rank = rank; c->comm_world = world;
-    return LMPC_OK;
+    return comm_scratch(c, (size_t)64 * 1024);
 }
 
 int lmpc_comm_destroy(lmpc_ctx *c) {
@@ -72,20 +88,19 @@ int lmpc_comm_allgather_dev(lmpc_ctx *c, const void *send, void *recv, long long
     return LMPC_OK;
 }
 
-// host buffers (small control data: lap lengths, timings): staged through a scratch allocation, same collective
+// host buffers (small control data: lap lengths, timings): staged through the communicator's scratch, same collective
 int lmpc_comm_allgather(lmpc_ctx *c, const void *send_host, void *recv_host, long long bytes) {
     ARGCHK(c && send_host && recv_host && bytes > 0);
     HIPCHK(hipSetDevice(c->cfg.device));
     const int world = c->comm ? c->comm_world : 1;
-    char *d; HIPCHK(hipMalloc(&d, (size_t)bytes * (world + 1)));
-    hipError_t e = hipMemcpyAsync(d, send_host, (size_t)bytes, hipMemcpyHostToDevice, c->stream);
-    int rc = LMPC_OK;
-    if (e == hipSuccess) rc = lmpc_comm_allgather_dev(c, d, d + bytes, bytes);
-    if (e == hipSuccess && rc == LMPC_OK) e = hipMemcpyAsync(recv_host, d + bytes, (size_t)bytes * world, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    if (rc) return rc;
-    if (e != hipSuccess) return set_err(LMPC_E_HIP, "lmpc_comm_allgather", hipGetErrorString(e));
+    int rc = comm_scratch(c, (size_t)bytes * (world + 1)); if (rc) return rc;
+    char *d = (char *)c->comm_scr, *hm = (char *)c->comm_scr_h;
+    memcpy(hm, send_host, (size_t)bytes);
+    HIPCHK(hipMemcpyAsync(d, hm, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    rc = lmpc_comm_allgather_dev(c, d, d + bytes, bytes); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(hm + bytes, d + bytes, (size_t)bytes * world, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(recv_host, hm + bytes, (size_t)bytes * world);
     return LMPC_OK;
 }
 
@@ -93,21 +108,29 @@ int lmpc_comm_allreduce_max(lmpc_ctx *c, double *v, int n) {
     ARGCHK(c && v && n >= 1);
     HIPCHK(hipSetDevice(c->cfg.device));
     if (!c->comm) { HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
-    double *d; HIPCHK(hipMalloc(&d, sizeof(double) * n));
-    hipError_t e = hipMemcpyAsync(d, v, sizeof(double) * n, hipMemcpyHostToDevice, c->stream);
-    ncclResult_t r = ncclSuccess;
-    if (e == hipSuccess) r = ncclAllReduce(d, d, (size_t)n, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream);
-    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(v, d, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    if (r != ncclSuccess) return set_err(LMPC_E_HIP, "ncclAllReduce", ncclGetErrorString(r));
-    if (e != hipSuccess) return set_err(LMPC_E_HIP, "lmpc_comm_allreduce_max", hipGetErrorString(e));
+    int rc = comm_scratch(c, sizeof(double) * (size_t)n); if (rc) return rc;
+    double *d = (double *)c->comm_scr, *hm = (double *)c->comm_scr_h;
+    memcpy(hm, v, sizeof(double) * n);
+    HIPCHK(hipMemcpyAsync(d, hm, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(ncclAllReduce(d, d, (size_t)n, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(hm, d, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(v, hm, sizeof(double) * n);
     return LMPC_OK;
 }
 
-int lmpc_comm_barrier(lmpc_ctx *c) {             // every rank's stream has drained, then a one-element all-reduce has completed everywhere
-    double z = 0.0;
-    return lmpc_comm_allreduce_max(c, &z, 1);
+// Barrier: a one-element all-reduce ENQUEUED on the context's stream behind whatever the rank has launched (no host staging, no allocation),
+// then one drain of the stream: when it returns, every rank's stream had reached the same point.
+int lmpc_comm_barrier(lmpc_ctx *c) {
+    ARGCHK(c);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    { int rc = resolve_retries(c); if (rc) return rc; }
+    if (c->comm) {
+        int rc = comm_scratch(c, sizeof(double)); if (rc) return rc;
+        NCCLCHK(ncclAllReduce(c->comm_scr, c->comm_scr, 1, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LMPC_OK;
 }
 
 // The per-lap exchange on the current rollout session: this rank's K fastest VALID laps (finished, at most T_max steps,
@@ -131,9 +154,12 @@ int lmpc_rollout_exchange(lmpc_ctx *c, int K, int T_max, double *records, long l
     for (int j = 0; j < K && j < (int)cand.size(); j++) { sel[j] = cand[j]; sel[K + j] = done[cand[j]]; }
     const size_t rec_doubles = (size_t)K * (T_max + 1) * 14;
     int *d_sel; double *d_send, *d_recv, *d_len;
-    HIPCHK(hipMalloc(&d_sel, sizeof(int) * 2 * K));
-    hipError_t e = hipMalloc(&d_send, sizeof(double) * (rec_doubles + K) * (size_t)(world + 1));
-    if (e != hipSuccess) { (void)hipFree(d_sel); return set_err(LMPC_E_HIP, "hipMalloc", "exchange buffers"); }
+    {   // exchange buffers in the communicator's scratch (grown once, kept): [send block | world x recv block | 2K selection ints]
+        const size_t blk = sizeof(double) * (rec_doubles + K);
+        int rc_ = comm_scratch(c, blk * (size_t)(world + 1) + sizeof(int) * 2 * K + 64); if (rc_) return rc_;
+        d_send = (double *)c->comm_scr; d_sel = (int *)((char *)c->comm_scr + blk * (size_t)(world + 1));
+    }
+    hipError_t e = hipSuccess;
     d_len = d_send + rec_doubles;                                // send block: records | lengths (as doubles), one gather for both
     d_recv = d_send + rec_doubles + K;
     std::vector<double> lenv((size_t)K); for (int j = 0; j < K; j++) lenv[j] = (double)sel[K + j];
@@ -152,7 +178,6 @@ int lmpc_rollout_exchange(lmpc_ctx *c, int K, int T_max, double *records, long l
         e = hipMemcpyAsync(host.data(), d_recv, sizeof(double) * host.size(), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }
-    (void)hipFree(d_sel); (void)hipFree(d_send);
     if (rc) return rc;
     if (e != hipSuccess) return set_err(LMPC_E_HIP, "lmpc_rollout_exchange", hipGetErrorString(e));
     for (int w = 0; w < world; w++) {

@@ -74,6 +74,26 @@ def _alive(pid):
     return True
 
 
+def host_signal(tag, port):
+    """Same-node host-side event (a file next to the rendezvous file): ranks that have nothing to do on their GPU while another rank works
+    alone wait for it in host_wait -- sleeping -- instead of spinning inside a collective for seconds."""
+    path = _rdzv_file(port) + "." + "".join(ch for ch in tag if ch.isalnum())
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+    with os.fdopen(fd, "wb") as f:
+        f.write(int(os.getpid()).to_bytes(8, "little"))
+    return path
+
+
+def host_wait(tag, port, timeout=3600.0, poll=0.05):
+    path = _rdzv_file(port) + "." + "".join(ch for ch in tag if ch.isalnum())
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout:
+            raise TimeoutError("host_wait(%s): no signal within %.0f s" % (tag, timeout))
+        time.sleep(poll)
+    return path
+
+
 def _is_local(addr):
     if os.environ.get("LMPC_RDZV_TCP") == "1":                      # (tests: force the TCP hand-off)
         return False

@@ -114,7 +114,9 @@ def test_bench_gpus_flag_spawns_ranks():
     import json
     out = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "2", "--dry-run"], check=True, capture_output=True, timeout=300)
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
-    assert line == {"dry_run": True, "n_gpus": 2, "ranks_at_rendezvous": 2}
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["ranks_at_rendezvous"] == 2
+    assert line["host_wait"] == "file"                     # the ranks without extras sleep on a host-side event, not inside a collective
+    assert set(line["multi_rank_keys"]) >= {"per_rank_ms_per_step", "barrier_us", "rccl_ranks", "exchange_seconds"}
     bad = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, timeout=300,
                          env=dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
     assert bad.returncode != 0 and b"WORLD_SIZE=1" in bad.stderr
