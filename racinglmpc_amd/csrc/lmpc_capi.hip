@@ -41,6 +41,7 @@ struct lmpc_ctx {
     void *var_dl;                            // dlopen handle when that instantiation lives in its own shared object (lmpc_variant.hip)
     int mw_max_batch, mw2_max_batch, n_cu;   // largest batch served by the four-wave / the two-wave solve kernel
     int fuse_k1;                             // fused step for one-wave batches (LMPC_FUSE=0 turns it off)
+    double *ab_pack;                         // global scratch of the one-wave kernel's long-horizon variant ([A_k | B_k] per problem), max_batch x 48 N doubles
     int cd_ok, cd_hasq, cd_mode;             // condensed one-wave kernel: usable for this configuration / state cost present / LMPC_CD: 0 never, 1 always, (default) by batch size
     int profiling; bool ev_open; std::vector<evpair> events; lmpc_stats stats;
     // retry pass on demand: launches since the last drain of the stream, the host-mapped ring the kernels flag themselves in, launch counter
@@ -152,7 +153,7 @@ static int create_body(lmpc_ctx *c) {
     }
     // a variant whose LDS footprint leaves room for one QP per CU (N = 40) keeps three SIMDs idle in the 1-wave kernel at any
     // batch size: always run it with four waves per QP (measured at N=40, B=1024: 2.80 vs 3.52 ms; N=20 and N=14 prefer 1 wave)
-    if (!getenv("LMPC_MW_MAX_BATCH") && 2 * c->var.lds_1w > 160 * 1024) c->mw_max_batch = 1 << 30;
+    if (!getenv("LMPC_MW_MAX_BATCH") && 2 * (c->var.lds_1w_abg ? c->var.lds_1w_abg : c->var.lds_1w) > 160 * 1024) c->mw_max_batch = 1 << 30;
     // Two waves per QP between the four-wave and the one-wave regime: how far up depends on the horizon -- the longer the horizon, the
     // larger the share of the Newton step that is sequential (the helper wave only waits) and the fewer QPs of the multi-wave LDS layout fit a
     // CU.  Measured (solve kernel, ms; two waves | one wave): N=12 B=1024 0.30 | 0.40, B=2048 (two rounds | one round) 0.56 | 0.47;  N=14 B=512 0.33 | 0.42, B=1024 0.48 | 0.44;
@@ -180,6 +181,7 @@ static int create_body(lmpc_ctx *c) {
         const char *e = getenv("LMPC_CD"); c->cd_mode = e ? atoi(e) : 0;
     }
     HIPCHK(hipStreamCreate(&c->stream));
+    if (c->var.lds_1w_abg > 0 && !getenv("LMPC_NO_ABG")) HIPCHK(hipMalloc(&c->ab_pack, sizeof(double) * 48 * (size_t)cfg->N * (size_t)cfg->max_batch));
     HIPCHK(hipHostMalloc(&c->h_retry, sizeof(int) * LMPC_RETRY_RING, hipHostMallocMapped));
     memset(c->h_retry, 0, sizeof(int) * LMPC_RETRY_RING);
     HIPCHK(hipHostGetDevicePointer((void **)&c->d_retry, c->h_retry, 0));
@@ -253,7 +255,7 @@ int lmpc_destroy(lmpc_ctx *c) {
     if (c->comm_scr) (void)hipFree(c->comm_scr);
     if (c->comm_scr_h) (void)hipHostFree(c->comm_scr_h);
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    void *ptrs[] = {c->mstore, c->sstore, c->mquant, c->mqpar, c->slab_in, c->slab_out};      // (the w_* work buffers are ranges of the two slabs)
+    void *ptrs[] = {c->mstore, c->sstore, c->mquant, c->mqpar, c->slab_in, c->slab_out, c->ab_pack};      // (the w_* work buffers are ranges of the two slabs)
     for (void *q : ptrs) if (q) (void)hipFree(q);
     if (c->h_retry) (void)hipHostFree(c->h_retry);
     if (c->h_in) (void)hipHostFree(c->h_in);
@@ -513,6 +515,7 @@ static int resolve_retries(lmpc_ctx *c) {
 }
 static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io_in, bool immediate = false) {
     lmpc_solve_io io = io_in;
+    io.abPack = c->ab_pack;
     const bool deferred = (io.mode & 2) && !immediate && !io.tbuf;
     if (deferred) {
         if ((int)c->pending.size() >= LMPC_RETRY_RING - 1) { int rc = resolve_retries(c); if (rc) return rc; }

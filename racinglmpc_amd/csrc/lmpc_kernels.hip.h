@@ -96,6 +96,7 @@ struct lmpc_solve_io {
     int *selStartOut;         // optional: first row of the 13-row window per selected lap (B x numSS_it)
     int *status, *iters;
     long long *tbuf;          // optional cycle stamps of problem 0 (builds with -DLMPC_TIMING only)
+    double *abPack;           // one-wave kernel, long horizons (ABG): global scratch for [A_k | B_k] in the kernel's 6 x 8 layout, 48 N doubles per problem
     int *retry_flag;          // optional (host-mapped): a problem that ends at the iteration limit / breaks down writes retry_epoch here (atomic max, system
     int retry_epoch;          // scope), so that the host launches the retry pass only when one is needed (lmpc_capi.hip: resolve_retries)
 };
@@ -866,11 +867,13 @@ template <int N, int S> struct solve_lds {
 // Arrays that only ever meet their own lane -- C_k (monitoring residual), the residual of the lambda rows, the lambda scalings D^-1/2
 // and the selected Q-function values -- live in registers (row or column = lane + 64 t), which is what brings the
 // footprint under 160 KB / 7.
-template <int N, int S> struct solve_lds1 {
+// ABG (long horizons): [A_k | B_k] stays in global memory (io.abPack, L2-resident: 15 KB per QP at N = 40, re-read every iteration) instead of
+// 48 N doubles of LDS -- at N = 40 that is the difference between two and four QPs per CU (53.5 KB -> 38.2 KB), i.e. between two and four busy SIMDs.
+template <int N, int S, bool ABG = false> struct solve_lds1 {
     static constexpr int M = 8 * N + S;
     static constexpr int CH = (S + 6 + WAVE - 1) / WAVE, CW = CH * WAVE;       // the terminal block's S + 6 columns: CH per lane (column = lane + 64 ch)
     static constexpr int oAB = 0;
-    static constexpr int ox = oAB + 48 * N, ou = ox + 6 * (N + 1), os = ou + 2 * N, olam = os + 2 * N, onu = olam + S;
+    static constexpr int ox = oAB + (ABG ? 0 : 48 * N), ou = ox + 6 * (N + 1), os = ou + 2 * N, olam = os + 2 * N, onu = olam + S;
     static constexpr int oCk1 = ox;                                             // fused step only: the regression leaves C_k here (then its work space), before x .. exist
     static constexpr int om = onu, oth = om + M;                               // (the equality multipliers nu live in registers; scratch copy at residual time)
     static constexpr int orx = oth + M;
@@ -1117,12 +1120,12 @@ __device__ __forceinline__ void k2_select(const lmpc_dev_params &p, const lmpc_s
     }
 }
 
-template <int N, int S, bool EQ = false>
+template <int N, int S, bool EQ = false, bool ABG = false>
 // (two waves per SIMD -- at most 256 registers -- only where the LDS footprint lets more than four QPs share a CU and the terminal
 // block keeps one column per lane)
-__global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 && solve_lds1<N, S>::CH == 1) ? 2 : 1) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
+__global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 1024 && solve_lds1<N, S, ABG>::CH == 1) ? 2 : 1) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
     extern __shared__ double sm[];
-    using LL = solve_lds1<N, S>;
+    using LL = solve_lds1<N, S, ABG>;
     constexpr int M = LL::M;
     constexpr bool term = S > 0;
     constexpr int RPL = (M + WAVE - 1) / WAVE;              // inequality rows per lane
@@ -1134,7 +1137,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     if constexpr (EQ) { if (!(io.status[b] & (LMPC_ST_MAXITER | LMPC_ST_NUMERIC))) return; }
     const int lane = threadIdx.x;
     const int lg = lane >> 3, lc = lane & 7;                // lane = 8 g + c  (8 x 8 tile coordinates)
-    double *AB = sm + LL::oAB, *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
+    double *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
+    double *AB;                                            // [A_k | B_k], 6 x 8 per stage: LDS, or (ABG) this problem's slice of io.abPack in global memory
+    if constexpr (ABG) AB = io.abPack + (size_t)b * 48 * N; else AB = sm + LL::oAB;
     double *dx = sm + LL::odx, *du = sm + LL::odu, *ds = sm + LL::ods, *dl = sm + LL::odl, *nu = sm + LL::onus, *dnu = sm + LL::odnu;
     double *m = sm + LL::om, *th = sm + LL::oth, *h = sm + LL::oh, *dm = sm + LL::odm;
     double *rx = sm + LL::orx;
@@ -1154,7 +1159,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     int tcnt = 0; (void)tcnt;
     TSTAMP(0);
     if (lane == 0) st_sh = 0;
-    if (io.mode & 4) {
+    static_assert(!ABG || !EQ, "the retry variant keeps [A_k | B_k] in LDS");
+    if (!ABG && (io.mode & 4)) {
         // K1 (fused step): LTV regression of this QP's N points by this wave, in the LDS behind AB / C that the solve needs only later
         __syncthreads();
         const int rst = k1_wave_problem(p, b, lane, io.xLin + (size_t)b * (N + 1) * 6, io.uLin + (size_t)b * N * 2, sm + LL::oCk1 + 6 * N, AB, sm + LL::oCk1,
@@ -1199,6 +1205,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S>::tot * 8 * 5 <= 160 * 1024 
     if (preload) {
         FOR_LANES_T(i, t, 36 * N) { const int k = i / 36, r = (i % 36) / 6, c = i % 6; AB[k * 48 + r * 8 + c] = preA[t]; }
         FOR_LANES_T(i, t, 12 * N) { const int k = i / 12, r = (i % 12) >> 1, c = i & 1; AB[k * 48 + r * 8 + 6 + c] = preB[t]; }
+        if constexpr (ABG) __threadfence();                   // (global scratch written and read by this wave only: make the stores visible to its later loads)
     }
     double *Cs = sm + LL::oCs;                             // C_k for the roll-out below (scratch; afterwards C lives in c_r only)
     FOR_LANES_T(i, t, 6 * N) Cs[i] = c_r[t];

@@ -17,6 +17,7 @@ struct lmpc_variant_api {
     int (*launch_retry)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &);   // lmpc_solve_kernel<N,S,true>
     int (*launch_mw4)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &);     // lmpc_solve_kernel_mw<N,S,4>
     int (*launch_mw2)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &);     // lmpc_solve_kernel_mw<N,S,2>
+    size_t lds_1w_abg;                        // one-wave kernel with [A_k | B_k] in global memory (long horizons): dynamic LDS per QP; 0 = not used for this (N, S)
     size_t lds_cd;                            // condensed one-wave kernel (lmpc_solve_cd.hip.h): dynamic LDS per QP without the state-cost block; 0 = not built for this (N, S)
     size_t lds_cd_q;                          //   ... with it (Q or Qf non-zero)
     int (*launch_cd)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &, int hasQ);   // lmpc_solve_kernel_cd<N,S>
@@ -32,7 +33,15 @@ template <int N, int S> struct lmpc_variant_launchers {
         return f > lds1 ? f : lds1;
     }
     static constexpr size_t lds1_max() { const size_t f = (size_t)(54 * N + k1_fused_doubles(N, LMPC_MAX_USED_LAPS, 8)) * sizeof(double); return f > lds1 ? f : lds1; }
+    // long horizons: [A_k | B_k] in global memory where that lets more QPs share a CU than the 160 KB of LDS otherwise hold and fewer than four do (idle SIMDs)
+    static constexpr size_t lds1g = (size_t)solve_lds1<N, S, true>::tot * sizeof(double);
+    // (measured, solve kernel, ms at batch 1024 / 4096: N = 40 LDS 1.467 / 4.073, global 1.092 / 3.398 -- two -> four QPs per CU;  N = 20 LDS 0.655 / 1.571,
+    //  global 0.725 / 1.554 -- five -> seven per CU, but every SIMD was busy already and the variant spills: only where fewer than four QPs fit)
+    static constexpr bool use_abg = (160 * 1024 / lds1) < 4 && (160 * 1024 / lds1g) > (160 * 1024 / lds1) && solve_lds1<N, S>::CH == 1;
     static int l1(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
+        if constexpr (use_abg) {
+            if (!(io.mode & 4) && io.abPack) { hipLaunchKernelGGL((lmpc_solve_kernel<N, S, false, true>), dim3(B), dim3(WAVE), lds1g, st, p, B, io); return 0; }
+        }
         hipLaunchKernelGGL((lmpc_solve_kernel<N, S>), dim3(B), dim3(WAVE), lds_for(p, io), st, p, B, io); return 0; }
     static int lr(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
         hipLaunchKernelGGL((lmpc_solve_kernel<N, S, true>), dim3(B), dim3(WAVE), lds_for(p, io), st, p, B, io); return 0; }
@@ -62,6 +71,11 @@ template <int N, int S> static bool lmpc_variant_fill(lmpc_variant_api *v) {
         if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_mw) != hipSuccess) return false;
     }
     v->launch_1w = &L::l1; v->launch_retry = &L::lr; v->launch_mw4 = &L::l4; v->launch_mw2 = &L::l2;
+    v->lds_1w_abg = 0;
+    if constexpr (L::use_abg) {
+        v->lds_1w_abg = L::lds1g;
+        if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::lds1g) != hipSuccess) return false;
+    }
     v->lds_cd = 0; v->lds_cd_q = 0; v->launch_cd = &L::lc;
     if constexpr (L::has_cd) {
         v->lds_cd = (size_t)solve_ldsc<N, S>::tot * sizeof(double); v->lds_cd_q = (size_t)solve_ldsc<N, S>::tot_q * sizeof(double);
