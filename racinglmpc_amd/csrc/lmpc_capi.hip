@@ -151,8 +151,9 @@ static int create_body(lmpc_ctx *c) {
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         c->mw_max_batch = e ? atoi(e) : cus; c->n_cu = cus;
     }
-    // a variant whose LDS footprint leaves room for one QP per CU (N = 40) keeps three SIMDs idle in the 1-wave kernel at any
-    // batch size: always run it with four waves per QP (measured at N=40, B=1024: 2.80 vs 3.52 ms; N=20 and N=14 prefer 1 wave)
+    // a variant whose one-wave LDS footprint leaves room for ONE QP per CU only would keep three SIMDs idle at any batch size and runs four waves
+    // per QP throughout.  None of the built-in horizons is in that class any more: N = 40 fits two QPs per CU with [A_k | B_k] in LDS (53.5 KB)
+    // and four with it in global memory (38.2 KB, lmpc_variant.hip.h: use_abg), so N = 40 follows the ordinary rule below (one wave from batch 257)
     if (!getenv("LMPC_MW_MAX_BATCH") && 2 * (c->var.lds_1w_abg ? c->var.lds_1w_abg : c->var.lds_1w) > 160 * 1024) c->mw_max_batch = 1 << 30;
     // Two waves per QP between the four-wave and the one-wave regime: how far up depends on the horizon -- the longer the horizon, the
     // larger the share of the Newton step that is sequential (the helper wave only waits) and the fewer QPs of the multi-wave LDS layout fit a
@@ -515,7 +516,9 @@ static int resolve_retries(lmpc_ctx *c) {
 }
 static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io_in, bool immediate = false) {
     lmpc_solve_io io = io_in;
-    io.abPack = c->ab_pack;
+    // [A_k | B_k] from global memory only when the batch does not fit the CUs with it in LDS (N = 40: more than two QPs per CU); a batch that
+    // fits runs 3 % faster from LDS (measured at N = 40, batch 512: 0.997 vs 1.030 ms)
+    io.abPack = (c->ab_pack && (long long)B > (long long)(160 * 1024 / c->var.lds_1w) * c->n_cu) ? c->ab_pack : nullptr;
     const bool deferred = (io.mode & 2) && !immediate && !io.tbuf;
     if (deferred) {
         if ((int)c->pending.size() >= LMPC_RETRY_RING - 1) { int rc = resolve_retries(c); if (rc) return rc; }

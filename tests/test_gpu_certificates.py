@@ -68,8 +68,8 @@ def test_bench_batch_certificate_all_kernels(built, B):
 
 @pytest.mark.parametrize("N,B", [(40, 1024), (14, 256), (14, 2048), (20, 300), (8, 64), (8, 1500)])
 def test_other_horizons_certificate(built, N, B):
-    """BASELINE config 'N=40, batch=1024' and the other built horizons, every problem certified (N = 40 always runs four waves per QP,
-    the others the kernel their batch size selects)."""
+    """BASELINE config 'N=40, batch=1024' and the other built horizons, every problem certified, each through the kernel its batch size
+    selects (N = 40, batch 1024: the one-wave kernel with [A_k | B_k] in global memory, four QPs per CU)."""
     g = common.load_lmpc_golden()
     ctx, par = _ctx_pid(g, N, B)
     xP, uP = g["xPID"], g["uPID"]
