@@ -151,7 +151,8 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         t_r[j] = 1.0; rt_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
         if (r < M) {
             const double tt = rowb(r) - rowF(r, x, u, s, lam), mm = mu0 / tt; t_r[j] = tt; m[r] = mm;
-            rt_r[j] = barrier_rt(tt, mm); th[r] = mm * rt_r[j]; h[r] = tt * th[r]; gsum_c = fma(tt, mm, gsum_c);      // h: the predictor's right-hand side, see the step
+            const double rt = barrier_rt(tt, mm), thv = mm * rt;
+            rt_r[j] = rt; th[r] = thv; h[r] = tt * thv; gsum_c = fma(tt, mm, gsum_c);      // h: the predictor's right-hand side, see the step
         }
     }
     if (w0) gs0[lane] = gsum_c;                            // wave 0's share of sum t mu: folded into the gap by wave 1 (wave 0 skips the residual reductions)
@@ -732,8 +733,9 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             const int r = tid + NT * j;
             if (r < M) {
                 const double tt = fma(al, dt_r[j], t_r[j]), mm = fma(ald, dm[r], m[r]);
-                t_r[j] = tt; m[r] = mm; rt_r[j] = barrier_rt(tt, mm); th[r] = mm * rt_r[j]; gsum_c = fma(tt, mm, gsum_c);
-                h[r] = tt * th[r];                              // next predictor's right-hand side (dm[r], which shares the place, was consumed one line up)
+                const double rt = barrier_rt(tt, mm), thv = mm * rt;
+                t_r[j] = tt; m[r] = mm; rt_r[j] = rt; th[r] = thv; gsum_c = fma(tt, mm, gsum_c);
+                h[r] = tt * thv;                                // next predictor's right-hand side (dm[r], which shares the place, was consumed one line up)
             }
         }
         if (w0) gs0[lane] = gsum_c;

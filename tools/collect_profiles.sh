@@ -11,10 +11,11 @@ BATCHES=${@:-256 4096}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
-python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+H=${HORIZON:-12}                                   # HORIZON=40 tools/collect_profiles.sh r3m_N40 1024: kernel stats + PMC passes of another horizon only
+if [ "$H" = "12" ]; then python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; fi
 cd /tmp && export TMPDIR=/tmp
 for B in $BATCHES; do
-  CMD="python $ROOT/bench.py --batch $B --steps 30 --warmup 5 --no-cpu-baseline --no-extras"
+  CMD="python $ROOT/bench.py --batch $B --horizon $H --steps 30 --warmup 5 --no-cpu-baseline --no-extras"
   rm -rf /tmp/prof_stats
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- $CMD > /dev/null 2>&1
   cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_B${B}_kernel_stats.csv
@@ -30,6 +31,7 @@ for B in $BATCHES; do
 done
 cd $ROOT
 ls -la $OUT | grep $TAG
+if [ "$H" != "12" ]; then exit 0; fi
 # phase timings of one QP (developer build with cycle stamps) and the RCCL branch on one rank
 LMPC_TIMING_MW=1 python tools/phase_timing.py > $OUT/${TAG}_phase_timing_mw4.txt 2>&1
 python tools/phase_timing.py > $OUT/${TAG}_phase_timing_1w.txt 2>&1

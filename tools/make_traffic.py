@@ -7,7 +7,8 @@ import csv, json, sys, collections
 
 import re, os
 tag = sys.argv[1]
-BK = "B%s_N12" % (re.search(r"_B(\d+)$", tag).group(1) if re.search(r"_B(\d+)$", tag) else "256")
+BK = "B%s_N%s" % (re.search(r"_B(\d+)$", tag).group(1) if re.search(r"_B(\d+)$", tag) else "256",
+                  re.search(r"_N(\d+)_B", tag).group(1) if re.search(r"_N(\d+)_B", tag) else "12")
 
 
 def mean_counter(path, name):
@@ -25,7 +26,8 @@ out = {}
 if os.path.exists("profiles/traffic.json") and os.environ.get("TRAFFIC_MERGE", "1") == "1":
     out = json.load(open("profiles/traffic.json"))
 def short_name(kname):
-    if "lmpc_solve_kernel<" in kname and "true>" in kname:                      # the retry variant lmpc_solve_kernel<N, S, true>: every work-group exits at once
+    m = re.search(r"lmpc_solve_kernel<([^>]*)>", kname)                          # the retry variant lmpc_solve_kernel<N, S, true[, false]>: not a bench kernel
+    if m and len(m.group(1).split(",")) >= 3 and m.group(1).split(",")[2].strip() == "true":
         return None
     return "lmpc_solve_kernel" if "lmpc_solve_kernel" in kname else ("lmpc_regress_kernel" if "lmpc_regress_kernel" in kname else None)
 
@@ -66,5 +68,13 @@ for short, d in cnt.items():
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, %s_pmc_pass1/2.csv), mean over the bench launches, N=12; "
                "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950; "
                "WRITE_SIZE uncalibrated; Infinity-Cache hits are included)." % tag)
+import subprocess
+try:      # the commit the counters belong to (collected from a snapshot of the working tree: HEAD at collection time, "+" if it was dirty)
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = subprocess.run(["git", "status", "--porcelain", "racinglmpc_amd/csrc"], capture_output=True, text=True).stdout.strip() != ""
+    out["commit"] = os.environ.get("TRAFFIC_COMMIT") or (head + ("+" if dirty else ""))
+    out["collected_with_tag"] = os.path.basename(tag).rsplit("_B", 1)[0].replace("_N40", "")
+except Exception:
+    pass
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
