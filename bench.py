@@ -324,13 +324,14 @@ def main():
         achieved = B * bytes_per_solve / (ms_solve * 1e-3) / 1e9
         nw = ctx.solver_waves(B)
         kname = "lmpc_solve_kernel_mw<%d,%d,%d>" % (N, S, nw) if nw > 1 else "lmpc_solve_kernel<%d,%d>" % (N, S)
-        traffic = None; counters = None
+        traffic = None; counters = None; prof_commit = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 traffic = tj.get("lmpc_solve_kernel_bytes_per_launch_B%d_N%d" % (B, N))
                 counters = tj.get("lmpc_solve_kernel_counters_B%d_N%d" % (B, N))
+                prof_commit = tj.get("commit")
             except Exception:
                 traffic = None
         out = {
@@ -349,6 +350,7 @@ def main():
             "solver_only_solves_per_s": B / (ms_solve * 1e-3), "regression_only_solves_per_s": B / (ms_reg * 1e-3) if ms_reg else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": kname, "algorithmic_bytes_per_launch": B * bytes_per_solve,
+                         "counters_commit": prof_commit,      # commit the PMC passes behind `traffic` / `fp64` were collected on (profiles/traffic.json)
                          # the other fraction SURVEY 8(d) asks for: FP64 work per launch from the rocprofv3 instruction-mix pass
                          # (profiles/, static) over the launch time measured live; plus VALU utilisation and the LDS bank-conflict rate
                          "fp64": None if not counters or "fp64_flop_per_launch" not in counters else {
