@@ -297,6 +297,11 @@ def main():
     ctx = make_ctx(g, N, max(B, 1 if args.no_extras else args.rollouts_per_gpu), local)
     S = ctx.S
     comm = parallel.comm_from_env(ctx, force_rccl=os.environ.get("LMPC_BENCH_FORCE_DIST") == "1")
+    if rank == 0 and world > 1:                       # a left-over "extras done" event of a killed launch (same parent, same port) must not release the other ranks early
+        try:
+            os.remove(parallel._rdzv_file(port) + ".extras")
+        except OSError:
+            pass
     inp = synth_batch(g, B, N, seed=1234 + rank)
     a, keep = ctx.step_dev_buffers(inp, diagnostics=False)      # the outputs MPC.solve produces (xPred, uPred, slack, lambda, s_T, zt, zt_u, SS_sel); no mu / residual dumps
 
