@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
     double *SS = sm + LL::oSS, *Qsel = sm + LL::oQs, *y7 = sm + LL::oy7, *z7 = sm + LL::oz7, *w7 = sm + LL::ow7, *PiT = sm + LL::oPiT, *sT = sm + LL::osT;
     double *par = sm + LL::opar;
     constexpr int T2N = (2 * N + WAVE - 1) / WAVE, T6N = (6 * N + WAVE - 1) / WAVE;
-    double c_r[T6N], nu_r[T6N], ru_r[T2N], rs_r[T2N], rDs_r[T2N], rl_r[CH], qsel_r[CH];      // own-lane arrays (element lane + 64 t in slot t)
+    double c_r[T6N], ru_r[T2N], rs_r[T2N], rDs_r[T2N], rl_r[CH], qsel_r[CH];      // own-lane arrays (element lane + 64 t in slot t)
     const double *Fx = par + PAR_FX, *Fu = par + PAR_FU, *bx = par + PAR_BX, *bu = par + PAR_BU, *Q2 = par + PAR_Q2, *Qf2 = par + PAR_QF2,
                  *R2 = par + PAR_R2, *dR2 = par + PAR_DR2, *T2p = par + PAR_T2, *xRef = par + PAR_XREF;
     __shared__ int st_sh;
@@ -1210,7 +1210,6 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
     double *Cs = sm + LL::oCs;                             // C_k for the roll-out below (scratch; afterwards C lives in c_r only)
     FOR_LANES_T(i, t, 6 * N) Cs[i] = c_r[t];
     if constexpr (term) { FOR_LANES_T(c, t, S) qsel_r[t] = Qsel[c]; }
-    FOR_LANES_T(i, t, 6 * N) nu_r[t] = 0.0;
     if (lane < 6) x[lane] = io.x0[(size_t)b * 6 + lane];
     FOR_LANES(i, 2 * N) u[i] = 0.0;
     const double uOld0 = wave_uniform(io.uOld[(size_t)b * 2 + 0]), uOld1 = wave_uniform(io.uOld[(size_t)b * 2 + 1]);
@@ -1304,7 +1303,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
         FOR_LANES(i, 8 * N) {                                   // gamma_k = [gx' - Kx' gu' ; -Ku' gu'] = [gx';0] + Phi[6:8,:]' gu'
             const int k = i >> 3, c = i & 7;
             double v = 0.0;
-            if (c < 6) { v = rx[k * 6 + c]; v -= Fx[c] * eta[2 * k] + Fx[6 + c] * eta[2 * k + 1]; }
+            if (c < 6) v = -(Fx[c] * eta[2 * k] + Fx[6 + c] * eta[2 * k + 1]);       // (the x rows of the dual residual vanish identically: exact nu)
             v = fma(PhiK[k * 16 + c], gup[2 * k], v);
             v = fma(PhiK[k * 16 + 8 + c], gup[2 * k + 1], v);
             gam[i] = v;
@@ -1313,7 +1312,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
         {
             double v = 0.0;
             if constexpr (term) v = term_costate(Ri, mc_g, re_sum, lg, lc, y7v);                 // (in registers: no LDS round trip, no barrier)
-            pN = lg < 6 ? rx[N * 6 + lg] + v : 0.0;
+            pN = lg < 6 ? v : 0.0;
             if (lc == 0) pst[N * 8 + lg] = pN;                  // (k0 of the last stage reads it from LDS, two barriers from here)
         }
         __syncthreads();
@@ -1428,24 +1427,37 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             if (r < M) gsum = fma(t_r[j], m[r], gsum);      // (the row slacks are iterates of their own: t <- t + alpha dt at the step, never b - F w)
         }
         if constexpr (term) ss_times<S>(SS, lam, x + N * 6, sT, lane);
-        FOR_LANES_T(i, t, 6 * N) nu[i] = nu_r[t];               // (scratch is free between the step and the factorisation)
         __syncthreads();
-        FOR_LANES(i, 6 * (N + 1)) {
-            const int k = i / 6, c = i % 6; double v = 0.0;
-            if (k >= 1) {
-                const double *Qk = k < N ? Q2 : Qf2;
+        // Multipliers of the dynamics rows (round 3: not iterates of their own any more).  The x rows of the dual residual read
+        //   w_k + nu_{k-1} - A_k' nu_k = 0,  w_k = 2Q (x_k - xRef) + Fx' mu_k  (k < N),  w_N = 2Qf (x_N - xRef) - T s_T,
+        // so nu follows from the iterate by an adjoint recursion, nu_{N-1} = -w_N, nu_{k-1} = A_k' nu_k - w_k: the rows vanish identically, the Newton
+        // direction in (u, s, lambda, mu) is the one of the condensed form (tests/ipm_model.py: exact_nu), and the costate recursion for d nu
+        // (6.1 k of 64 k cycles per iteration) is gone.  w goes through the rx array; lane c < 6 carries nu_k[c], entries broadcast by v_readlane.
+        FOR_LANES(i, 6 * N) {
+            const int k = i / 6 + 1, c = i % 6;
+            const double *Qk = k < N ? Q2 : Qf2;
+            double v = 0.0;
 #pragma unroll
-                for (int j = 0; j < 6; j++) v = fma(Qk[c * 6 + j], x[k * 6 + j] - xRef[j], v);
-                v += nu[(k - 1) * 6 + c];
-                if (k < N) {
-                    v += Fx[c] * m[2 * k] + Fx[6 + c] * m[2 * k + 1];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) v -= AB[k * 48 + j * 8 + c] * nu[k * 6 + j];
-                } else if (term) v -= T2p[c] * sT[c];
-                rmax = fmax(rmax, fabs(v));
-            }
-            rx[i] = v;
+            for (int j = 0; j < 6; j++) v = fma(Qk[c * 6 + j], x[k * 6 + j] - xRef[j], v);
+            if (k < N) v += Fx[c] * m[2 * k] + Fx[6 + c] * m[2 * k + 1];
+            else if (term) v -= T2p[c] * sT[c];
+            rx[k * 6 + c] = v;
         }
+        __syncthreads();
+        {
+            const int c = lane < 6 ? lane : 0;
+            double nc = -rx[N * 6 + c];                                          // nu_{N-1}[c]
+            if (lane < 6) nu[(N - 1) * 6 + lane] = nc;
+#pragma unroll
+            for (int k = N - 1; k >= 1; k--) {
+                double v = -rx[k * 6 + c];
+#pragma unroll
+                for (int r = 0; r < 6; r++) v = fma(AB[k * 48 + r * 8 + c], rdlane(nc, r), v);
+                nc = v;
+                if (lane < 6) nu[(k - 1) * 6 + lane] = v;
+            }
+        }
+        __syncthreads();
         FOR_LANES_T(i, t, 2 * N) {
             const int k = i >> 1, c = i & 1;
             const double up = k > 0 ? u[(k - 1) * 2 + c] : (c == 0 ? uOld0 : uOld1);
@@ -1671,59 +1683,13 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             }
         }
         TSTAMP(17);
-        // ---- multipliers of the equality rows (costates) -------------------------------------------------------------------
-        // The x-rows of the Newton system read  2Q dx_k + Fx' dmu_k + dnu_k - A_k' dnu_{k+1} = -rx_k  (dmu_k: the step of the stage's two
-        // lane-boundary multipliers, just computed), so y_k = -dnu_k obeys  y_k = A_k' y_{k+1} + tt_k,  tt_k = rx_k + 2Q dx_k + Fx' dmu_k,
-        // y_N = tt_N = rx_N + 2Qf dx_N - T ds_T: a backward recursion over stage data that is in LDS anyway -- the cost-to-go Hessians
-        // Pi_k need not be kept (6 KB per QP at N = 12).  Same register scheme as the sweeps (alternating sum over c / sum over g).
+        // ---- step.  (The multipliers of the dynamics rows are recomputed from the new iterate by the adjoint recursion at the top of the loop:
+        //      no costate recursion here any more.) -----------------------------------------------------------------------------------
         if constexpr (term) {
             ss_times<S>(SS, dl, dx + N * 6, w7, lane);                                                // d s_T
         }
         __syncthreads();
-        FOR_LANES(i, 6 * N) {
-            const int k = i / 6 + 1, c = i % 6;                  // row defining x_k, k = 1..N
-            double g = rx[k * 6 + c];
-            if (k == N) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) g = fma(Qf2[c * 6 + j], dx[N * 6 + j], g);
-                if constexpr (term) g -= T2p[c] * w7[c];
-            } else {
-                g += Fx[c] * dm[2 * k] + Fx[6 + c] * dm[2 * k + 1];                      // Fx' dmu of the stage's two lane rows
-#pragma unroll
-                for (int j = 0; j < 6; j++) g = fma(Q2[c * 6 + j], dx[k * 6 + j], g);
-            }
-            tt[i] = g;
-        }
-        __syncthreads();
-        // the primal / inequality-dual part of the step does not wait for the costates: issued here, it fills the recursion's latency
-        FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
-        FOR_LANES(i, 2 * N) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
-        if constexpr (term) { FOR_LANES(c, S) lam[c] = fma(al, dl[c], lam[c]); }
-#pragma unroll
-        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) { m[r] = fma(ald, dm[r], m[r]); t_r[j] = fma(al, dt_r[j], t_r[j]); } }
-        {
-            double aa[N], tm[N];
-#pragma unroll
-            for (int k = 1; k < N; k++) {
-                const bool in = lg < 6 && lc < 6;
-                const double a_ = (k & 1) ? AB[k * 48 + (in ? lc : 0) * 8 + (in ? lg : 0)] : AB[k * 48 + (in ? lg : 0) * 8 + (in ? lc : 0)];
-                aa[k] = in ? a_ : 0.0;
-                const int ix = (k & 1) ? lg : lc;
-                const double t_ = tt[(k - 1) * 6 + (ix < 6 ? ix : 0)];
-                tm[k] = ix < 6 ? t_ : 0.0;
-            }
-            const int i0 = ((N - 1) & 1) ? lc : lg;
-            double pv = tt[(N - 1) * 6 + (i0 < 6 ? i0 : 0)];
-            pv = i0 < 6 ? pv : 0.0;
-            if (lane < 6) dnu[(N - 1) * 6 + lane] = -tt[(N - 1) * 6 + lane];
-#pragma unroll
-            for (int k = N - 1; k >= 1; k--) {
-                double pr = aa[k] * pv;
-                if (k & 1) { pr = sum_over_c(pr); pv = pr + tm[k]; if (lc == 0 && lg < 6) dnu[(k - 1) * 6 + lg] = -pv; }
-                else { pr = sum_over_g(pr); pv = pr + tm[k]; if (lg == 0 && lc < 6) dnu[(k - 1) * 6 + lc] = -pv; }
-            }
-        }
-        double deta = 0.0;
+        double deta = 0.0;                                     // multiplier of sum(lambda) = 1: mean over the lambda rows of  -rl + dmu - SS' T ds_T
         if constexpr (term) {
             double v = 0.0;
             FOR_LANES_T(c, t, S) { v += -rl_r[t] + dm[8 * N + c];
@@ -1731,10 +1697,12 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
                 for (int j = 0; j < 6; j++) v -= SS[j * S + c] * T2p[j] * w7[j]; }
             deta = wsum(v) / (double)S;
         }
-        __syncthreads();
+        FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
+        FOR_LANES(i, 2 * N) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
+        if constexpr (term) { FOR_LANES(c, S) lam[c] = fma(al, dl[c], lam[c]); }
+#pragma unroll
+        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) { m[r] = fma(ald, dm[r], m[r]); t_r[j] = fma(al, dt_r[j], t_r[j]); } }
         TSTAMP(18);
-        // ---- step ------------------------------------------------------------------------------------------
-        FOR_LANES_T(i, t, 6 * N) nu_r[t] = fma(ald, dnu[i], nu_r[t]);
         eta_m = wave_uniform(fma(ald, deta, eta_m));
         __syncthreads();
     }

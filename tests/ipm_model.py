@@ -128,8 +128,11 @@ def kkt_solve(qp, f, th_lane, th_s, gx, gu, gs, h_lane, h_u, h_s, gl, re_dyn, re
     return dx, du, ds, dl
 
 
-def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True):
-    """Returns dict(x,u,s,lam,sT, mu (ineq duals in reference row order), iters, gap, rd, re)."""
+def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True):
+    """Returns dict(x,u,s,lam,sT, mu (ineq duals in reference row order), iters, gap, rd, re).
+    exact_nu (round 3): the multipliers of the dynamics rows are not iterates of their own; every iteration takes them from the adjoint recursion
+    nu_{k-1} = A_k' nu_k - w_k (w_k: gradient of the state rows' other terms), so the x rows of the dual residual vanish identically and the
+    costate recursion for d nu is gone -- the same Newton direction in (u, s, lambda, mu) as the condensed form below."""
     par = qp.par; N = qp.N; S = qp.S; Fx, Fu = par.Fx, par.Fu; bx, bu = par.bx, par.bu
     dR2 = 2 * par.dR; a = 2 * par.Qslack[0]; c1 = par.Qslack[1]
     Q2, Qf2, R2 = 2 * par.Q, 2 * par.Qf, 2 * par.R; xRef = par.xRef
@@ -163,9 +166,14 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         # ---- residuals
         sT = qp.SS @ lam - x[N] if qp.term else None
         rx = np.zeros((N + 1, 6))
-        for k in range(1, N):
-            rx[k] = Q2 @ (x[k] - xRef) + Fx.T @ m_lane[k] + nu[k - 1] - A[k].T @ nu[k]
-        rx[N] = Qf2 @ (x[N] - xRef) + nu[N - 1] - (T * sT if qp.term else 0)
+        if exact_nu:
+            nu[N - 1] = -(Qf2 @ (x[N] - xRef) - (T * sT if qp.term else 0))
+            for k in range(N - 1, 0, -1):
+                nu[k - 1] = A[k].T @ nu[k] - (Q2 @ (x[k] - xRef) + Fx.T @ m_lane[k])
+        else:
+            for k in range(1, N):
+                rx[k] = Q2 @ (x[k] - xRef) + Fx.T @ m_lane[k] + nu[k - 1] - A[k].T @ nu[k]
+            rx[N] = Qf2 @ (x[N] - xRef) + nu[N - 1] - (T * sT if qp.term else 0)
         ru = np.zeros((N, 2))
         for k in range(N):
             upv = u[k - 1] if k > 0 else qp.uOld
@@ -247,7 +255,9 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         if qp.term:
             lam += al * dl
         m_lane, m_u, m_s, m_l = [m + ald * d for m, d in zip(ms, dm)]
-        nu += ald * dnu; eta_m += ald * deta
+        if not exact_nu:
+            nu += ald * dnu
+        eta_m += ald * deta
     out = dict(x=x, u=u, s=s, lam=lam, sT=(qp.SS @ lam - x[N]) if qp.term else None,
                mu=np.concatenate([m_lane.ravel(), m_u.ravel(), m_s.ravel(), m_l]), nu=nu, eta=eta_m)
     out.update(info)
