@@ -1448,13 +1448,26 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             const int c = lane < 6 ? lane : 0;
             double nc = -rx[N * 6 + c];                                          // nu_{N-1}[c]
             if (lane < 6) nu[(N - 1) * 6 + lane] = nc;
+            if constexpr (ABG || N > 20) {
+                // long horizons: a rolled loop (unrolled, the 6 N loads -- global ones with ABG -- were hoisted together: 281 spilled VGPRs at N = 40)
+#pragma unroll 1
+                for (int k = N - 1; k >= 1; k--) {
+                    double v = -rx[k * 6 + c];
+                    const double *Ak = AB + k * 48 + c;
 #pragma unroll
-            for (int k = N - 1; k >= 1; k--) {
-                double v = -rx[k * 6 + c];
+                    for (int r = 0; r < 6; r++) v = fma(Ak[r * 8], rdlane(nc, r), v);
+                    nc = v;
+                    if (lane < 6) nu[(k - 1) * 6 + lane] = v;
+                }
+            } else {
 #pragma unroll
-                for (int r = 0; r < 6; r++) v = fma(AB[k * 48 + r * 8 + c], rdlane(nc, r), v);
-                nc = v;
-                if (lane < 6) nu[(k - 1) * 6 + lane] = v;
+                for (int k = N - 1; k >= 1; k--) {
+                    double v = -rx[k * 6 + c];
+#pragma unroll
+                    for (int r = 0; r < 6; r++) v = fma(AB[k * 48 + r * 8 + c], rdlane(nc, r), v);
+                    nc = v;
+                    if (lane < 6) nu[(k - 1) * 6 + lane] = v;
+                }
             }
         }
         __syncthreads();
