@@ -8,7 +8,11 @@ LTV-MPC QP of the reference (PredictiveControllers.py:166-257, 340-362):
   * Newton system = block-banded KKT, solved by a Riccati recursion on the augmented state
     xi_k = (x_k, u_{k-1}) (input-rate cost), lane slacks eliminated analytically,
     terminal block (lambda, s_T) eliminated through a 7x7 square-root (MGS-QR) factor.
-The kernel in racinglmpc_amd/csrc/lmpc_kernels.hip follows this file step by step.
+The kernels in racinglmpc_amd/csrc follow this file step by step:
+  ipm_solve(exact_nu=True)   lmpc_solve_kernel (one wave per QP): multipliers of the dynamics rows from the adjoint recursion, no costate recursion (round 3)
+  ipm_solve(exact_nu=False)  lmpc_solve_kernel_mw (two / four waves per QP): the same multipliers as a damped iterate
+  ipm_solve_cd               lmpc_solve_kernel_cd (condensed form, experimental)
+Round 3: barrier weights capped at th_max in the Newton matrix with consistent right-hand sides, row slacks carried as iterates (carry_t).
 """
 import numpy as np
 
