@@ -180,15 +180,15 @@ def _cpu_worker(args):
     return done, time.perf_counter() - t0
 
 
-def cpu_baseline(N, B, seconds=6.0, max_procs=64):
+def cpu_baseline(N, B, seconds=6.0, max_procs=None):
     """The reference's algorithm for this path as restated in oracle/ (NumPy regression + selection + assembly, restated
     OSQP at the reference's settings eps=1e-3 + polish -- what main.py does per step), timed on the host cores of this
-    box for a fixed wall budget: first ONE core (the reference itself is single-threaded), then min(cores, max_procs)
-    single-threaded processes working through the same batch concurrently."""
+    box for a fixed wall budget: first ONE core (the reference itself is single-threaded), then one
+    single-threaded process per host core (count stated in the line) working through the same batch concurrently."""
     import multiprocessing as mp
     n1, t1 = _cpu_worker((0, min(seconds, 3.0), N, B))
     one = n1 / t1
-    cores = min(os.cpu_count() or 1, max_procs)
+    cores = min(os.cpu_count() or 1, max_procs or (os.cpu_count() or 1))      # every host core, one single-threaded process each
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(i * 7, seconds, N, B) for i in range(cores)])
     done = sum(r[0] for r in res); busy = max(r[1] for r in res)
@@ -386,8 +386,12 @@ def main():
                                                       note="BASELINE configs[2]: 30 PID laps (vt = 0.6 + 0.02 i) in both stores, reference semantics = the 4 fastest are used")
                 out["config_batch4096_30laps_wide"] = dict(
                     run_config(g, N, 4096, local, steps=5, warmup=2, laps=laps30, query_lap=laps30[29], max_laps=40, max_lap_len=1024, numSS_it=8, numSS_points=96, trToUse=8),
-                    note="SURVEY 8(d) scan-heavy variant within the library's limits (8 laps used by regression and safe set, 96 safe-set points, 30 laps stored); "
+                    note="an intermediate point of SURVEY 8(d)'s scan-heavy variant (8 laps used by regression and safe set, 96 safe-set points, 30 laps stored); "
                          "more than 58 safe-set points: several terminal-block columns per lane")
+                out["config_batch4096_30laps_stress"] = dict(
+                    run_config(g, N, 4096, local, steps=3, warmup=1, laps=laps30, query_lap=laps30[29], max_laps=40, max_lap_len=1024, numSS_it=30, numSS_points=360, trToUse=30),
+                    note="SURVEY 8(d) scan-heavy stress variant as stated: numSS_it = trToUse = 30 (every stored lap in the regression and in the safe set), "
+                         "numSS_Points = 360: 366 terminal-block columns, six per lane")
                 out["config_N40_batch1024"] = dict(run_config(g, 40, 1024, local, steps=5, warmup=2), note="BASELINE configs[4]")
             except Exception as e:                     # noqa: BLE001
                 out["extras_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])

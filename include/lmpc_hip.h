@@ -23,9 +23,9 @@ extern "C" {
 #define LMPC_NX 6
 #define LMPC_NU 2
 #define LMPC_MAX_TRACK_ROWS 16
-#define LMPC_MAX_USED_LAPS 8       /* trToUse / numSS_it upper bound */
+#define LMPC_MAX_USED_LAPS 32      /* trToUse / numSS_it upper bound (the reference takes any: PredictiveControllers.py:293-311, PredictiveModel.py:31) */
 #define LMPC_MAX_N 64
-#define LMPC_MAX_SS_POINTS 250     /* numSS_points upper bound (beyond 58 the terminal block takes several columns per lane) */
+#define LMPC_MAX_SS_POINTS 384     /* numSS_points upper bound = 32 laps x 12 points (beyond 58 the terminal block takes several columns per lane) */
 
 /* error codes (function return values) */
 #define LMPC_OK 0

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMPC_LIB") or os.path.join(_HERE, "liblmpc_hip.so")      # LMPC_LIB: developer builds (build.build_flavour)
 
 MAX_TRACK_ROWS = 16
-MAX_USED_LAPS = 8
+MAX_USED_LAPS = 32
 COMM_ID_BYTES = 128
 E_VARIANT = -5
 
@@ -291,7 +291,7 @@ class Context:
     def step_dev_buffers(self, inp, diagnostics=True):
         """HBM-resident inputs/outputs of lmpc_step_batch_dev for a batch given as host arrays (keys x0, xLin, uLin, uOld, zt,
         xPredPrev, hasPred, timeStep).  Returns (StepDevArgs, device pointers to free with dev_free).  diagnostics=False leaves out what
-        the hot path does not need downstream (copies of A_i / B_i / C_i, inequality multipliers mu, residual triple, Q-function values of the selection):
+        the hot path does not need downstream (inequality multipliers mu, residual triple, Q-function values of the selection):
         those pointers stay NULL and the kernels skip the stores."""
         N, S, M = self.N, self.S, self.M
         B = np.asarray(inp["x0"]).shape[0]
@@ -311,8 +311,10 @@ class Context:
         a.lambda_, a.sTerm, a.ztNext, a.ztuNext = alloc(B * S * 8), alloc(B * 6 * 8), alloc(B * 6 * 8), alloc(B * 2 * 8)
         a.ssSel = alloc(B * S * 6 * 8)
         a.status, a.iters = alloc(B * 4), alloc(B * 4)
+        # A_i / B_i / C_i (MPC.A / B / C of the reference): the hand-over from the regression kernel to the solve kernel.  Caller-owned, so that
+        # launches can be queued back to back (a launch that used the context's own hand-over buffers is drained before the next one overwrites them)
+        a.A, a.Bm, a.C = alloc(B * N * 36 * 8), alloc(B * N * 12 * 8), alloc(B * N * 6 * 8)
         if diagnostics:
-            a.A, a.Bm, a.C = alloc(B * N * 36 * 8), alloc(B * N * 12 * 8), alloc(B * N * 6 * 8)      # (copies of the LTV model: MPC.A / B / C lists of the reference)
             a.qSel, a.mu, a.resid = alloc(B * S * 8), alloc(B * M * 8), alloc(B * 3 * 8)
         return a, keep
 

@@ -10,7 +10,7 @@ VSRC = os.path.join(_HERE, "csrc", "lmpc_variant.hip")
 # (N, numSS_points) pairs compiled into liblmpc_hip.so itself (lmpc_capi.hip: builtin_variant) and the extra ones build() prepares as
 # shared objects of their own, in parallel; anything else is built the first time a Context asks for it
 BUILTIN = {(n, s) for n in (8, 12, 14, 20, 40) for s in (0, 48)}
-EXTRA_VARIANTS = [(10, 48), (16, 48), (24, 48), (30, 48), (12, 24), (12, 36), (16, 36), (10, 0), (16, 0), (12, 60), (12, 72), (12, 96), (14, 160)]
+EXTRA_VARIANTS = [(10, 48), (16, 48), (24, 48), (30, 48), (12, 24), (12, 36), (16, 36), (10, 0), (16, 0), (12, 60), (12, 72), (12, 96), (14, 160), (12, 360)]
 OUT = os.path.join(_HERE, "liblmpc_hip.so")
 
 
@@ -57,8 +57,8 @@ def variant_path(N, S):
 def build_variant(N, S, force=False):
     """One (N, numSS_points) instantiation of the solve kernels as liblmpc_var_N<N>_S<S>.so (csrc/lmpc_variant.hip); ~20 s of hipcc."""
     N, S = int(N), int(S)
-    if not (2 <= N <= 64 and 0 <= S <= 250):
-        raise ValueError("solve kernels exist for 2 <= N <= 64 and numSS_points <= 250 (got N=%d, numSS_points=%d)" % (N, S))
+    if not (2 <= N <= 64 and 0 <= S <= 384):
+        raise ValueError("solve kernels exist for 2 <= N <= 64 and numSS_points <= 384 (got N=%d, numSS_points=%d)" % (N, S))
     out = variant_path(N, S)
     deps = [VSRC] + KDEPS
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):

@@ -37,16 +37,20 @@ struct lmpc_ctx {
     // the work buffers are ranges of two device slabs (inputs | outputs); small batches move each slab with ONE copy through pinned host
     // mirrors (h_in / h_out) instead of one pageable copy per array -- 24 copies of ~10 us each were 60 % of a batch-1 lmpc_step_batch call
     char *slab_in, *slab_out, *h_in, *h_out; size_t slab_in_bytes, slab_out_bytes;
+    char *dm_in, *dm_out;                    // device addresses of the host-mapped mirrors h_in / h_out (small contexts: the step kernels read / write them directly)
     lmpc_variant_api var;                    // launchers of the (N, numSS_points) instantiation of the solve kernels in use
     void *var_dl;                            // dlopen handle when that instantiation lives in its own shared object (lmpc_variant.hip)
     int mw_max_batch, mw2_max_batch, n_cu;   // largest batch served by the four-wave / the two-wave solve kernel
     int fuse_k1;                             // fused step for one-wave batches (LMPC_FUSE=0 turns it off)
     double *ab_pack;                         // global scratch of the one-wave kernel's long-horizon variant ([A_k | B_k] per problem), max_batch x 48 N doubles
-    int cd_ok, cd_hasq, cd_mode;             // condensed one-wave kernel: usable for this configuration / state cost present / LMPC_CD: 0 never, 1 always, (default) by batch size
+    int cd_ok, cd_hasq, cd_mode;             // condensed one-wave kernel (opt-in: libraries built with -DLMPC_WITH_CD only): usable for this configuration / state cost present / LMPC_CD=1 in the environment selects it, at every batch size
     int profiling; bool ev_open; std::vector<evpair> events; lmpc_stats stats;
     // retry pass on demand: launches since the last drain of the stream, the host-mapped ring the kernels flag themselves in, launch counter
-    struct pending_solve { lmpc_solve_io io; int B; int epoch; };
+    struct pending_solve { lmpc_solve_io io; int B; int epoch; lmpc_dev_params dp; bool shared_abc; };   // dp: the parameter block (selected laps, store pointers) of the launch
     std::vector<pending_solve> pending; int *h_retry, *d_retry; int epoch;
+    size_t ab_pack_cap;                      // problems ab_pack holds
+    int *w_selStart;                         // lmpc_select_batch: window starts, max_batch x numSS_it
+    void *scr_dev; size_t scr_bytes;         // pooled scratch of the small host-buffer entry points (plant step, global position)
     struct lmpc_rollout_session *ro;
     void *comm; int comm_rank, comm_world;   // RCCL communicator of this rank (lmpc_comm.hip.h); null = single process
     double *ext_rows; size_t ext_rows_bytes;   // staging buffer of lmpc_ss_extend_lap
@@ -171,6 +175,7 @@ static int create_body(lmpc_ctx *c) {
     // at batch 8192 with eight: the regression's short dependent chains (DPP minima, 5 x 5 Cholesky, scattered L2 reads) want the four waves
     // per SIMD its own kernel gets, the solve kernel runs two.  Off unless LMPC_FUSE=1.
     { const char *e = getenv("LMPC_FUSE"); c->fuse_k1 = e ? atoi(e) : 0; }
+    if (c->fuse_k1 && (size_t)(54 * cfg->N + k1_fused_doubles(cfg->N, cfg->trToUse, cfg->maxNumPoint)) * sizeof(double) > (size_t)160 * 1024) c->fuse_k1 = 0;   // (many laps: the regression's work space does not fit beside the solve)
     {   // condensed kernel (lmpc_solve_cd.hip.h): built for 2N <= 32 and one terminal-block column per lane; it takes the state cost as diagonal Q, Qf
         bool diag = true; c->cd_hasq = 0;
         for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {
@@ -182,7 +187,7 @@ static int create_body(lmpc_ctx *c) {
         const char *e = getenv("LMPC_CD"); c->cd_mode = e ? atoi(e) : 0;
     }
     HIPCHK(hipStreamCreate(&c->stream));
-    if (c->var.lds_1w_abg > 0 && !getenv("LMPC_NO_ABG")) HIPCHK(hipMalloc(&c->ab_pack, sizeof(double) * 48 * (size_t)cfg->N * (size_t)cfg->max_batch));
+    if (c->var.lds_1w_abg > 0 && !getenv("LMPC_NO_ABG")) { HIPCHK(hipMalloc(&c->ab_pack, sizeof(double) * 48 * (size_t)cfg->N * (size_t)cfg->max_batch)); c->ab_pack_cap = (size_t)cfg->max_batch; }
     HIPCHK(hipHostMalloc(&c->h_retry, sizeof(int) * LMPC_RETRY_RING, hipHostMallocMapped));
     memset(c->h_retry, 0, sizeof(int) * LMPC_RETRY_RING);
     HIPCHK(hipHostGetDevicePointer((void **)&c->d_retry, c->h_retry, 0));
@@ -209,12 +214,16 @@ static int create_body(lmpc_ctx *c) {
         SLAB(w_qSel, B * S, slab_out, oo); SLAB(w_mu, B * M, slab_out, oo); SLAB(w_A, B * N * 36, slab_out, oo); SLAB(w_B, B * N * 12, slab_out, oo);
         SLAB(w_C, B * N * 6, slab_out, oo); SLAB(w_status, B, slab_out, oo); SLAB(w_iters, B, slab_out, oo); SLAB(w_resid, B * 3, slab_out, oo);
         SLAB(w_succ, B * S * 6, slab_out, oo); SLAB(w_succU, B * S * 2, slab_out, oo); SLAB(w_ztUsed, B * 6, slab_out, oo); SLAB(w_rstatus, B * N, slab_out, oo);
+        SLAB(w_selStart, B * (size_t)std::max(cfg->numSS_it, 1), slab_out, oo);
 #undef SLAB
         if (!pass) {
             c->slab_in_bytes = oi; c->slab_out_bytes = oo;
             HIPCHK(hipMalloc(&c->slab_in, oi)); HIPCHK(hipMalloc(&c->slab_out, oo));
             HIPCHK(hipMemset(c->slab_in, 0, oi)); HIPCHK(hipMemset(c->slab_out, 0, oo));
-            if (oo <= LMPC_SLAB_COPY_MAX) { HIPCHK(hipHostMalloc(&c->h_in, oi)); HIPCHK(hipHostMalloc(&c->h_out, oo)); memset(c->h_in, 0, oi); }
+            if (oo <= LMPC_SLAB_COPY_MAX) {
+                HIPCHK(hipHostMalloc(&c->h_in, oi, hipHostMallocMapped)); HIPCHK(hipHostMalloc(&c->h_out, oo, hipHostMallocMapped)); memset(c->h_in, 0, oi); memset(c->h_out, 0, oo);
+                HIPCHK(hipHostGetDevicePointer((void **)&c->dm_in, c->h_in, 0)); HIPCHK(hipHostGetDevicePointer((void **)&c->dm_out, c->h_out, 0));
+            }
         }
     }
     return LMPC_OK;
@@ -253,6 +262,7 @@ int lmpc_destroy(lmpc_ctx *c) {
     rollout_free(c);
     if (c->comm) { (void)ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
     if (c->ext_rows) (void)hipFree(c->ext_rows);
+    if (c->scr_dev) (void)hipFree(c->scr_dev);
     if (c->comm_scr) (void)hipFree(c->comm_scr);
     if (c->comm_scr_h) (void)hipHostFree(c->comm_scr_h);
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -267,6 +277,13 @@ int lmpc_destroy(lmpc_ctx *c) {
     return LMPC_OK;
 }
 
+static int resolve_retries(lmpc_ctx *c);
+// Every entry point that changes what a deferred retry pass would read -- the lap stores, caller-visible device buffers (lmpc_dev_upload) -- or
+// hands results to someone else (lmpc_comm_allgather_dev, lmpc_ss_get_qfun) first gives the launches still pending their retry pass: a flagged
+// problem is then re-solved against the data of ITS launch, never against a changed safe set or overwritten inputs.  (No launch pending -- the
+// drop-in flow, where lmpc_step_batch resolves before it returns -- costs nothing: no stream drain is added.)
+#define RESOLVE_PENDING() do { const int rc_ = resolve_retries(c); if (rc_) return rc_; } while (0)
+
 // ---------------------------------------------------------------------------------------------- stores
 // The reference keeps its laps in Python lists that grow without bound (PredictiveControllers.py:418-445, PredictiveModel.py:35-46; addPoint
 // appends a row per closed-loop step, :466-474).  max_laps / max_lap_len of lmpc_config are therefore INITIAL capacities: when a lap or a row
@@ -279,7 +296,7 @@ static int grow_stores(lmpc_ctx *c, int need_laps, int need_len) {
     while (new_laps < need_laps) new_laps *= 2;
     while (new_len < need_len) new_len *= 2;
     if (new_laps == old_laps && new_len == old_len) return LMPC_OK;
-    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipSetDevice(c->cfg.device)); RESOLVE_PENDING(); HIPCHK(hipStreamSynchronize(c->stream));
     const int old_chunks = c->mq_chunks, new_chunks = (new_len + K1_CHUNK - 1) / K1_CHUNK;
     const size_t elems = (size_t)new_laps * LMPC_COLS * new_len;
     double *nm = nullptr, *ns = nullptr, *np_ = nullptr; unsigned *nq = nullptr;
@@ -359,6 +376,7 @@ static int quantise_lap(lmpc_ctx *c, int slot, const double *x, const double *u,
 int lmpc_model_add_trajectory(lmpc_ctx *c, const double *x, const double *u, int T) {
     ARGCHK(c && x && u && T >= 2);
     HIPCHK(hipSetDevice(c->cfg.device));
+    RESOLVE_PENDING();
     const int slot = (int)c->m_len.size();
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = upload_lap(c, true, slot, x, u, nullptr, T); if (rc) return rc;                 // (grows the stores when the lap does not fit)
@@ -372,7 +390,7 @@ int lmpc_model_add_trajectory(lmpc_ctx *c, const double *x, const double *u, int
 int lmpc_model_num_laps(lmpc_ctx *c, int *n) { ARGCHK(c && n); *n = (int)c->m_order.size(); return LMPC_OK; }
 int lmpc_model_replace_lap(lmpc_ctx *c, int pos, const double *x, const double *u, int T) {
     ARGCHK(c && x && u && pos >= 0 && pos < (int)c->m_order.size());
-    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipSetDevice(c->cfg.device)); RESOLVE_PENDING(); HIPCHK(hipStreamSynchronize(c->stream));
     ARGCHK(T == c->m_len[c->m_order[pos]]);
     int rc = upload_lap(c, true, c->m_order[pos], x, u, nullptr, T); if (rc) return rc;
     return quantise_lap(c, c->m_order[pos], x, u, T);
@@ -381,6 +399,7 @@ int lmpc_model_replace_lap(lmpc_ctx *c, int pos, const double *x, const double *
 int lmpc_ss_add_trajectory(lmpc_ctx *c, const double *x, const double *u, int T) {
     ARGCHK(c && x && u && T >= 1);
     HIPCHK(hipSetDevice(c->cfg.device));
+    RESOLVE_PENDING();
     const int lap = (int)c->s_len.size();
     // LMPC.computeCost (PredictiveControllers.py:447-464)
     std::vector<double> cost((size_t)T, 10000.0);
@@ -405,6 +424,7 @@ int lmpc_ss_add_point(lmpc_ctx *c, const double *x, const double *u) {
     ARGCHK(c && x && u);
     if (c->s_len.empty()) return set_err(LMPC_E_STATE, "addPoint before any addTrajectory", "");
     HIPCHK(hipSetDevice(c->cfg.device));
+    RESOLVE_PENDING();
     const int lap = (int)c->s_len.size() - 1, row = c->s_len[lap];
     if (row >= c->cfg.max_lap_len) { const int rc = grow_stores(c, c->cfg.max_laps, row + 1); if (rc) return rc; }
     const double q = c->s_qlast[lap] - 1.0;                        // :474
@@ -417,7 +437,7 @@ int lmpc_ss_add_point(lmpc_ctx *c, const double *x, const double *u) {
 }
 int lmpc_ss_replace_lap(lmpc_ctx *c, int lap, const double *x, const double *u, const double *qfun, int T) {
     ARGCHK(c && x && u && qfun && lap >= 0 && lap < (int)c->s_len.size() && T >= 1);
-    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipSetDevice(c->cfg.device)); RESOLVE_PENDING(); HIPCHK(hipStreamSynchronize(c->stream));
     int rc = upload_lap(c, false, lap, x, u, qfun, T); if (rc) return rc;
     c->s_len[lap] = T; c->s_qlast[lap] = qfun[T - 1]; c->s_q0[lap] = qfun[0];
     return LMPC_OK;
@@ -430,7 +450,7 @@ int lmpc_ss_set_selected(lmpc_ctx *c, const int *laps, int n) {
 int lmpc_ss_num_laps(lmpc_ctx *c, int *n) { ARGCHK(c && n); *n = (int)c->s_len.size(); return LMPC_OK; }
 int lmpc_ss_get_qfun(lmpc_ctx *c, int lap, double *qfun, int *T) {
     ARGCHK(c && T && lap >= 0 && lap < (int)c->s_len.size());
-    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipSetDevice(c->cfg.device)); RESOLVE_PENDING(); HIPCHK(hipStreamSynchronize(c->stream));
     *T = c->s_len[lap];
     if (qfun) HIPCHK(hipMemcpy(qfun, c->sstore + ((size_t)lap * LMPC_COLS + 8) * c->cfg.max_lap_len, sizeof(double) * c->s_len[lap], hipMemcpyDeviceToHost));
     return LMPC_OK;
@@ -504,21 +524,36 @@ extern "C" int lmpc_solver_waves(lmpc_ctx *c, int B);
 static int resolve_retries(lmpc_ctx *c) {
     if (c->pending.empty()) return LMPC_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = LMPC_OK, launched = 0;
     for (auto &pe : c->pending) {
         if (c->h_retry[pe.epoch % LMPC_RETRY_RING] != pe.epoch) continue;
         pe.io.retry_flag = nullptr;
-        int rc = c->var.launch_retry(c->stream, c->dp, pe.B, pe.io); if (rc) { c->pending.clear(); return rc; }
-        HIPCHK(hipGetLastError());
-        c->stats.n_retry++;
+        // the retry runs against the parameter block of ITS launch (selected laps, lap lengths, cur_it), not the context's current one
+        rc = c->var.launch_retry(c->stream, pe.dp, pe.B, pe.io); if (rc) break;
+        if (hipGetLastError() != hipSuccess) { rc = set_err(LMPC_E_HIP, "retry launch", ""); break; }
+        c->stats.n_retry++; launched++;
     }
     c->pending.clear();
-    return LMPC_OK;
+    // nothing is in flight that could still write the ring: start the epochs over (they never grow past the ring size, so the signed
+    // counter cannot overflow and `epoch % ring` stays a valid slot)
+    if (rc == LMPC_OK && launched && hipStreamSynchronize(c->stream) != hipSuccess) rc = set_err(LMPC_E_HIP, "hipStreamSynchronize", "retry pass");
+    c->epoch = 0; memset(c->h_retry, 0, sizeof(int) * LMPC_RETRY_RING);
+    return rc;
 }
 static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io_in, bool immediate = false) {
     lmpc_solve_io io = io_in;
     // [A_k | B_k] from global memory only when the batch does not fit the CUs with it in LDS (N = 40: more than two QPs per CU); a batch that
     // fits runs 3 % faster from LDS (measured at N = 40, batch 512: 0.997 vs 1.030 ms)
-    io.abPack = (c->ab_pack && (long long)B > (long long)(160 * 1024 / c->var.lds_1w) * c->n_cu) ? c->ab_pack : nullptr;
+    io.abPack = nullptr;
+    if (c->ab_pack && (long long)B > (long long)(160 * 1024 / c->var.lds_1w) * c->n_cu) {
+        if ((size_t)B > c->ab_pack_cap) {                   // rollout sessions may run more problems than max_batch: the scratch follows
+            int rc = resolve_retries(c); if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->ab_pack); c->ab_pack = nullptr; c->ab_pack_cap = 0;
+            HIPCHK(hipMalloc(&c->ab_pack, sizeof(double) * 48 * (size_t)c->cfg.N * (size_t)B)); c->ab_pack_cap = (size_t)B;
+        }
+        io.abPack = c->ab_pack;
+    }
     const bool deferred = (io.mode & 2) && !immediate && !io.tbuf;
     if (deferred) {
         if ((int)c->pending.size() >= LMPC_RETRY_RING - 1) { int rc = resolve_retries(c); if (rc) return rc; }
@@ -543,7 +578,7 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io_in, bool imm
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     c->stats.n_solve++; if (io.mode & 2) c->stats.qp_solved += B;
-    if (deferred) c->pending.push_back({io, B, io.retry_epoch});
+    if (deferred) c->pending.push_back({io, B, io.retry_epoch, c->dp, io.A == c->w_A || io.Bm == c->w_B || io.C == c->w_C});
     else if (io.mode & 2) {
         rc = c->var.launch_retry(c->stream, c->dp, B, io);
         if (rc) return rc;
@@ -590,10 +625,9 @@ int lmpc_select_batch(lmpc_ctx *c, int B, const double *x0, const double *zt, co
     lmpc_solve_io io; memset(&io, 0, sizeof(io));
     io.mode = 1; io.x0 = c->w_x0; io.zt = c->w_zt; io.xPredPrev = c->w_xPP; io.hasPred = c->w_hasPred; io.timeStep = c->w_tstep;
     io.ssSelOut = c->w_ssSel; io.qSelOut = c->w_qSel; io.succOut = c->w_succ; io.succUOut = c->w_succU; io.ztUsed = c->w_ztUsed; io.status = c->w_status; io.iters = c->w_iters;
-    io.selStartOut = c->w_rstatus;                       // B x numSS_it <= B x N ints fit the regression status buffer when numSS_it <= N
-    ARGCHK(c->cfg.numSS_it <= c->cfg.N);
+    io.selStartOut = c->w_selStart;
     int rc = launch_solve(c, B, io); if (rc) return rc;
-    D2H(selStart, c->w_rstatus, (size_t)B * c->cfg.numSS_it);
+    D2H(selStart, c->w_selStart, (size_t)B * c->cfg.numSS_it);
     D2H(ssSel, c->w_ssSel, (size_t)B * S * 6); D2H(qSel, c->w_qSel, (size_t)B * S); D2H(succ, c->w_succ, (size_t)B * S * 6); D2H(succU, c->w_succU, (size_t)B * S * 2);
     D2H(ztUsed, c->w_ztUsed, (size_t)B * 6); D2H(status, c->w_status, B);
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -634,6 +668,10 @@ int lmpc_step_batch_dev(lmpc_ctx *c, int B, const lmpc_step_dev_args *a) {
     // front of the solve and [A_k | B_k], C_k never leave LDS (see lmpc_create for the measurement that keeps it off by default).
     const bool fused = c->fuse_k1 && lmpc_solver_waves(c, B) == 1;
     double *dA = a->A ? a->A : c->w_A, *dB = a->Bm ? a->Bm : c->w_B, *dC = a->C ? a->C : c->w_C;
+    // A, Bm, C not given: the hand-over goes through the context's own buffers, which this launch's regression overwrites -- a launch still
+    // pending its retry pass that used them is resolved first (a stream drain).  Callers that queue launches back to back pass their own
+    // A / Bm / C (racinglmpc_amd._capi.Context.step_dev_buffers does) and keep every buffer of a launch untouched until lmpc_dev_sync.
+    if (dA == c->w_A || dB == c->w_B || dC == c->w_C) for (const auto &pe : c->pending) if (pe.shared_abc) { RESOLVE_PENDING(); break; }
     if (fused) { io.mode = 4; io.xLin = a->xLin; io.uLin = a->uLin; io.Aout = a->A; io.Bout = a->Bm; io.Cout = a->C; if (int rc = refresh_params(c, true, false)) return rc; }
     else { int rc = launch_regress(c, B, a->xLin, (N + 1) * 6, a->uLin, dA, dB, dC, c->w_rstatus); if (rc) return rc; io.rstatus = c->w_rstatus; }
     int rc = 0;
@@ -666,7 +704,7 @@ int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, co
             if (timeStep) STAGE(w_tstep, timeStep, B);
         }
 #undef STAGE
-        HIPCHK(hipMemcpyAsync(c->slab_in, c->h_in, c->slab_in_bytes, hipMemcpyHostToDevice, c->stream));
+        if (!c->dm_in) HIPCHK(hipMemcpyAsync(c->slab_in, c->h_in, c->slab_in_bytes, hipMemcpyHostToDevice, c->stream));
     } else {
     H2D(c->w_x0, x0, (size_t)B * 6); H2D(c->w_xLin, xLin, (size_t)B * (N + 1) * 6); H2D(c->w_uLin, uLin, (size_t)B * N * 2); H2D(c->w_uOld, uOld, (size_t)B * 2);
     if (term) {
@@ -680,13 +718,29 @@ int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, co
     a.x0 = c->w_x0; a.xLin = c->w_xLin; a.uLin = c->w_uLin; a.uOld = c->w_uOld; a.zt = c->w_zt; a.xPredPrev = c->w_xPP; a.hasPred = c->w_hasPred; a.timeStep = c->w_tstep;
     a.xPred = c->w_xPred; a.uPred = c->w_uPred; a.slack = c->w_slack; a.lambda = c->w_lam; a.sTerm = c->w_sT; a.ztNext = c->w_ztN; a.ztuNext = c->w_ztuN;
     a.ssSel = c->w_ssSel; a.qSel = c->w_qSel; a.A = c->w_A; a.Bm = c->w_B; a.C = c->w_C; a.mu = c->w_mu; a.resid = c->w_resid; a.status = c->w_status; a.iters = c->w_iters;
+    const bool zero_copy = one_copy && c->dm_in && c->dm_out;
+    if (zero_copy) {
+        // Small contexts (the drop-in classes: one QP per call): the kernels read the inputs from and write the outputs to HOST-MAPPED memory --
+        // no hipMemcpyAsync in either direction and ONE drain of the stream per call (two copies and two drains were ~25 us of a 0.24 ms LMPC.solve).
+        // A few KB cross the host link inside the kernels instead (every array is read once at a kernel's start, loads issued together).
+#define MAP_IN(f, w) a.f = (decltype(a.f))(c->dm_in + ((char *)c->w - c->slab_in))
+#define MAP_OUT(f, w) a.f = (decltype(a.f))(c->dm_out + ((char *)c->w - c->slab_out))
+        MAP_IN(x0, w_x0); MAP_IN(xLin, w_xLin); MAP_IN(uLin, w_uLin); MAP_IN(uOld, w_uOld); MAP_IN(zt, w_zt); MAP_IN(xPredPrev, w_xPP); MAP_IN(hasPred, w_hasPred); MAP_IN(timeStep, w_tstep);
+        MAP_OUT(xPred, w_xPred); MAP_OUT(uPred, w_uPred); MAP_OUT(slack, w_slack); MAP_OUT(lambda, w_lam); MAP_OUT(sTerm, w_sT); MAP_OUT(ztNext, w_ztN); MAP_OUT(ztuNext, w_ztuN);
+        MAP_OUT(ssSel, w_ssSel); MAP_OUT(qSel, w_qSel); MAP_OUT(mu, w_mu); MAP_OUT(resid, w_resid); MAP_OUT(status, w_status); MAP_OUT(iters, w_iters);
+        if (Aout || Bout || Cout) { MAP_OUT(A, w_A); MAP_OUT(Bm, w_B); MAP_OUT(C, w_C); }      // (asked for: the regression writes them to the host, the solve reads them back at its start)
+#undef MAP_IN
+#undef MAP_OUT
+    }
     int rc = lmpc_step_batch_dev(c, B, &a); if (rc) return rc;
     rc = resolve_retries(c); if (rc) return rc;          // drains the stream; a flagged problem gets its retry pass before anything is copied out
     if (one_copy) {
-        // everything up to (not including) the selection-only buffers w_succ ..: one copy into the pinned mirror, then plain memcpys
-        const size_t nbytes = (size_t)((char *)c->w_succ - c->slab_out);
-        HIPCHK(hipMemcpyAsync(c->h_out, c->slab_out, nbytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!zero_copy) {
+            // everything up to (not including) the selection-only buffers w_succ ..: one copy into the pinned mirror, then plain memcpys
+            const size_t nbytes = (size_t)((char *)c->w_succ - c->slab_out);
+            HIPCHK(hipMemcpyAsync(c->h_out, c->slab_out, nbytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
 #define UNSTAGE(dst, wptr, n) do { if (dst) memcpy(dst, c->h_out + ((char *)c->wptr - c->slab_out), sizeof(*c->wptr) * (size_t)(n)); } while (0)
         UNSTAGE(xPred, w_xPred, (size_t)B * (N + 1) * 6); UNSTAGE(uPred, w_uPred, (size_t)B * N * 2); UNSTAGE(slack, w_slack, (size_t)B * N * 2);
         if (term) { UNSTAGE(lambda, w_lam, (size_t)B * S); UNSTAGE(sTerm, w_sT, (size_t)B * 6); UNSTAGE(ssSel, w_ssSel, (size_t)B * S * 6); UNSTAGE(qSel, w_qSel, (size_t)B * S); }
@@ -742,7 +796,7 @@ int lmpc_assemble_batch(lmpc_ctx *c, int B, const double *A, const double *Bm, c
 // ---------------------------------------------------------------------------------------------- device buffers
 int lmpc_dev_alloc(lmpc_ctx *c, long long bytes, void **dptr) { ARGCHK(c && dptr && bytes > 0); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipMalloc(dptr, (size_t)bytes)); return LMPC_OK; }
 int lmpc_dev_free(lmpc_ctx *c, void *dptr) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); { int rc = resolve_retries(c); if (rc) return rc; } HIPCHK(hipFree(dptr)); return LMPC_OK; }
-int lmpc_dev_upload(lmpc_ctx *c, void *dptr, const void *host, long long bytes) { ARGCHK(c && dptr && host); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipMemcpyAsync(dptr, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
+int lmpc_dev_upload(lmpc_ctx *c, void *dptr, const void *host, long long bytes) { ARGCHK(c && dptr && host); HIPCHK(hipSetDevice(c->cfg.device)); RESOLVE_PENDING(); HIPCHK(hipMemcpyAsync(dptr, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
 int lmpc_dev_download(lmpc_ctx *c, void *host, const void *dptr, long long bytes) { ARGCHK(c && dptr && host); HIPCHK(hipSetDevice(c->cfg.device)); { int rc = resolve_retries(c); if (rc) return rc; } HIPCHK(hipMemcpyAsync(host, dptr, (size_t)bytes, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
 int lmpc_dev_sync(lmpc_ctx *c) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); { int rc = resolve_retries(c); if (rc) return rc; } HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
 
@@ -783,16 +837,30 @@ int lmpc_debug_k1_timing(lmpc_ctx *c, int B, const double *xLin, const double *u
 #endif
 
 // ---------------------------------------------------------------------------------------------- plant / rollouts
+}  // extern "C"
+// scratch of the small host-buffer entry points below: one device allocation, grown on demand and kept (no hipMalloc / hipFree per call)
+static int pooled_scratch(lmpc_ctx *c, size_t bytes, void **out) {
+    if (bytes > c->scr_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->scr_dev) { (void)hipFree(c->scr_dev); c->scr_dev = nullptr; c->scr_bytes = 0; }
+        const size_t want = std::max<size_t>((bytes + 4095) & ~(size_t)4095, (size_t)64 * 1024);
+        HIPCHK(hipMalloc(&c->scr_dev, want)); c->scr_bytes = want;
+    }
+    *out = c->scr_dev;
+    return LMPC_OK;
+}
+extern "C" {
 int lmpc_plant_step_batch(lmpc_ctx *c, int B, const double *x, const double *xg, const double *u, const double *noise, double *xn, double *xgn, int *status) {
     ARGCHK(c && x && xg && u && noise && xn && xgn && B >= 1);
     HIPCHK(hipSetDevice(c->cfg.device));
-    double *d; HIPCHK(hipMalloc(&d, sizeof(double) * (size_t)B * 29)); int *ds; HIPCHK(hipMalloc(&ds, sizeof(int) * B));
+    double *d; { void *q; const int rc = pooled_scratch(c, sizeof(double) * (size_t)B * 29 + sizeof(int) * (size_t)B, &q); if (rc) return rc; d = (double *)q; }
+    int *ds = (int *)(d + (size_t)B * 29);
     double *dx = d, *dg = d + (size_t)B * 6, *du = d + (size_t)B * 12, *dn = d + (size_t)B * 14, *dxn = d + (size_t)B * 17, *dgn = d + (size_t)B * 23;
     H2D(dx, x, (size_t)B * 6); H2D(dg, xg, (size_t)B * 6); H2D(du, u, (size_t)B * 2); H2D(dn, noise, (size_t)B * 3);
     hipLaunchKernelGGL(lmpc_plant_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, dx, dg, du, dn, dxn, dgn, ds);
     HIPCHK(hipGetLastError());
     D2H(xn, dxn, (size_t)B * 6); D2H(xgn, dgn, (size_t)B * 6); D2H(status, ds, B);
-    HIPCHK(hipStreamSynchronize(c->stream)); hipFree(d); hipFree(ds);
+    HIPCHK(hipStreamSynchronize(c->stream));
     return LMPC_OK;
 }
 
@@ -800,12 +868,13 @@ int lmpc_global_position_batch(lmpc_ctx *c, int n, const double *s, const double
     ARGCHK(c && s && ey && xy && status && n >= 1);
     HIPCHK(hipSetDevice(c->cfg.device));
     int rc = refresh_params(c, false, false); if (rc) return rc;
-    double *d; HIPCHK(hipMalloc(&d, sizeof(double) * (size_t)n * 4)); int *ds; HIPCHK(hipMalloc(&ds, sizeof(int) * (size_t)n));
+    double *d; { void *q; const int rc2 = pooled_scratch(c, sizeof(double) * (size_t)n * 4 + sizeof(int) * (size_t)n, &q); if (rc2) return rc2; d = (double *)q; }
+    int *ds = (int *)(d + (size_t)n * 4);
     H2D(d, s, (size_t)n); H2D(d + n, ey, (size_t)n);
     hipLaunchKernelGGL(lmpc_global_position_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dp, n, d, d + n, d + 2 * (size_t)n, ds);
     HIPCHK(hipGetLastError());
     D2H(xy, d + 2 * (size_t)n, (size_t)n * 2); D2H(status, ds, (size_t)n);
-    HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(d); (void)hipFree(ds);
+    HIPCHK(hipStreamSynchronize(c->stream));
     return LMPC_OK;
 }
 
@@ -929,6 +998,7 @@ int lmpc_ss_extend_lap(lmpc_ctx *c, int lap, const double *x, const double *u, i
     ARGCHK(c && lap >= 0 && lap < (int)c->s_len.size() && n >= 0 && (n == 0 || (x && u)));
     if (n == 0) return LMPC_OK;
     HIPCHK(hipSetDevice(c->cfg.device));
+    RESOLVE_PENDING();
     if (c->s_len[lap] + n > c->cfg.max_lap_len) { const int rc = grow_stores(c, c->cfg.max_laps, c->s_len[lap] + n); if (rc) return rc; }
     std::vector<double> rows((size_t)n * LMPC_COLS);
     double q = c->s_qlast[lap];
@@ -940,6 +1010,7 @@ int lmpc_ss_extend_lap(lmpc_ctx *c, int lap, const double *x, const double *u, i
     }
     if (rows.size() * sizeof(double) > c->ext_rows_bytes) {       // staging buffer of the batched addPoint: grown once, kept
         if (c->ext_rows) (void)hipFree(c->ext_rows);
+    if (c->scr_dev) (void)hipFree(c->scr_dev);
         c->ext_rows = nullptr; c->ext_rows_bytes = 0;
         const size_t want = std::max<size_t>(rows.size() * sizeof(double), (size_t)64 * LMPC_COLS * sizeof(double));
         HIPCHK(hipMalloc(&c->ext_rows, want)); c->ext_rows_bytes = want;
@@ -960,7 +1031,7 @@ int lmpc_ss_extend_lap(lmpc_ctx *c, int lap, const double *x, const double *u, i
 int lmpc_ss_truncate_lap(lmpc_ctx *c, int lap, int T) {
     ARGCHK(c && lap >= 0 && lap < (int)c->s_len.size() && T >= c->s_laptime[lap] && T <= c->s_len[lap]);
     if (T == c->s_len[lap]) return LMPC_OK;
-    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipSetDevice(c->cfg.device)); RESOLVE_PENDING(); HIPCHK(hipStreamSynchronize(c->stream));
     double q = 0.0;                                                  // Qfun of the new last row (addPoint counts on from it, :474)
     HIPCHK(hipMemcpy(&q, c->sstore + ((size_t)lap * LMPC_COLS + 8) * c->cfg.max_lap_len + (T - 1), sizeof(double), hipMemcpyDeviceToHost));
     c->s_len[lap] = T; c->s_qlast[lap] = q;

@@ -83,6 +83,7 @@ int lmpc_comm_info(lmpc_ctx *c, int *rank, int *world, int *is_rccl) {
 int lmpc_comm_allgather_dev(lmpc_ctx *c, const void *send, void *recv, long long bytes) {
     ARGCHK(c && send && recv && bytes > 0);
     HIPCHK(hipSetDevice(c->cfg.device));
+    RESOLVE_PENDING();                              // (what is shipped to the peers has had its retry pass)
     if (!c->comm) { HIPCHK(hipMemcpyAsync(recv, send, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream)); return LMPC_OK; }
     NCCLCHK(ncclAllGather(send, recv, (size_t)bytes, ncclChar, (ncclComm_t)c->comm, c->stream));
     return LMPC_OK;

@@ -251,7 +251,8 @@ __global__ void lmpc_global_position_kernel(lmpc_dev_params p, int n, const doub
 #define K1_QG 12                   // queries per pass
 #define K1_RPL 16                  // rows per lane per chunk
 #define K1_CHUNK (K1_RPL * WAVE)
-#define K1_PTS (K1_QG * 32)        // staged points per pass (32 per query when trToUse * MaxNumPoint <= 32)
+#define K1_PTS (K1_QG * 32)        // staged points per pass (32 per query when trToUse * MaxNumPoint <= 32; fewer queries per pass beyond: 32 laps x 8 points = 256 fit one query)
+#define K1_SEL K1_PTS              // entries of the running selection: queries x laps x MaxNumPoint of one pass
 
 template <int CTRL> __device__ __forceinline__ unsigned dpp_minu(unsigned v) {
     const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
@@ -314,7 +315,7 @@ static __device__ long long *g_k1_tbuf;
 struct k1_smem {
     double (*qf)[5];                 // [QG]        xuLin of the queries in flight (PredictiveModel.py:54)
     int (*cseg)[16]; int *ccnt;      // [waves QG]  prefilter survivors (row indices) per wave and query
-    double *seld; int *seli; int *nsel; int Ls;    // [QG][Ls][8], [QG][Ls][8], [QG][Ls]: running selection per query and lap
+    double *seld; int *seli; int *nsel; int Ls, Sp; // [QG][Ls][Sp], [QG][Ls][Sp], [QG][Ls]: running selection per query and lap (Ls = laps in use, Sp = MaxNumPoint)
     double (*pts)[10];               // [QF PP]     vx vy wz delta a K y_vx y_vy y_wz 1   (PredictiveModel.py:141-168)
     double (*gram)[45];              // [QF]        Q_vx(15) b_vx(5) Q_lat(15) b_vy(5) b_wz(5)
     double (*theta)[15];             // [QF]        three solutions of five coefficients
@@ -402,7 +403,7 @@ __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_s
             const int s = s0 + (lane >> 4), r = lane & 15;
             const bool live = s < nqw;
             const int qi = live ? sgi + s * nsub : 0;
-            double *sd = sm.seld + ((size_t)qi * sm.Ls + c) * 8; int *si = sm.seli + ((size_t)qi * sm.Ls + c) * 8;
+            double *sd = sm.seld + ((size_t)qi * sm.Ls + c) * sm.Sp; int *si = sm.seli + ((size_t)qi * sm.Ls + c) * sm.Sp;
             const int cnt = live ? sm.ccnt[cs0 + (live ? s : 0)] : 0, ns = live ? sm.nsel[qi * sm.Ls + c] : 0;
             const bool ovf = cnt + ns > 16;
             double dv = INFINITY; int iv = 0x7fffffff;
@@ -435,7 +436,7 @@ __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_s
             while (mo) {
                 const int sl = s0 + (__builtin_ctzll(mo) >> 4); mo &= mo - 1;
                 const int qj = sgi + sl * nsub, nsj = sm.nsel[qj * sm.Ls + c];
-                double *sdj = sm.seld + ((size_t)qj * sm.Ls + c) * 8; int *sij = sm.seli + ((size_t)qj * sm.Ls + c) * 8;
+                double *sdj = sm.seld + ((size_t)qj * sm.Ls + c) * sm.Sp; int *sij = sm.seli + ((size_t)qj * sm.Ls + c) * sm.Sp;
                 const double x0 = sm.qf[qj][0], x1 = sm.qf[qj][1], x2 = sm.qf[qj][2], x3 = sm.qf[qj][3], x4 = sm.qf[qj][4];
                 const double od = lane < nsj ? sdj[lane] : INFINITY; const int oi = lane < nsj ? sij[lane] : 0x7fffffff;
                 double pd = -INFINITY; int pi = -1, got = 0;
@@ -476,7 +477,7 @@ __device__ __forceinline__ void k1_fit(const lmpc_dev_params &p, const k1_smem &
     for (int e = tid; e < nf * PP; e += nt) {
         const int ql = e / PP, qi = q0 + ql, sl = e % PP, c = sl / MAXP, r = sl % MAXP;
         const int ns = sm.nsel[qi * sm.Ls + c];
-        const double *sd = sm.seld + ((size_t)qi * sm.Ls + c) * 8; const int *si = sm.seli + ((size_t)qi * sm.Ls + c) * 8;
+        const double *sd = sm.seld + ((size_t)qi * sm.Ls + c) * sm.Sp; const int *si = sm.seli + ((size_t)qi * sm.Ls + c) * sm.Sp;
         double *pt = sm.pts[ql * PP + sl];
         if (r < ns) {
             int pick = r;
@@ -596,14 +597,16 @@ __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_d
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave-uniform by construction: lap pointers, row counts and loop bounds stay in SGPRs
     __shared__ double qf[K1_QG][5];
     __shared__ int cseg[K1_NW * K1_QG][16]; __shared__ int ccnt[K1_NW * K1_QG];
-    __shared__ double seld[K1_QG * LMPC_MAX_USED_LAPS * 8]; __shared__ int seli[K1_QG * LMPC_MAX_USED_LAPS * 8];
-    __shared__ int nsel[K1_QG * LMPC_MAX_USED_LAPS];
+    // running selection per (query, lap): queries x laps x MaxNumPoint <= K1_PTS entries whatever the split (k1_queries_per_block keeps
+    // queries x laps x MaxNumPoint <= K1_PTS, or one query per block when a single query's laps x MaxNumPoint exceed it: K1_PTS_MAX)
+    __shared__ double seld[K1_SEL]; __shared__ int seli[K1_SEL];
+    __shared__ int nsel[K1_SEL];
     __shared__ double pts[K1_PTS][10];
     __shared__ double gram[K1_QG][45];
     __shared__ double theta[K1_QG][15];
     __shared__ double outv[K1_QG][54];
     __shared__ int st_s[K1_QG];
-    k1_smem sm; sm.qf = qf; sm.cseg = cseg; sm.ccnt = ccnt; sm.seld = seld; sm.seli = seli; sm.nsel = nsel; sm.Ls = LMPC_MAX_USED_LAPS;
+    k1_smem sm; sm.qf = qf; sm.cseg = cseg; sm.ccnt = ccnt; sm.seld = seld; sm.seli = seli; sm.nsel = nsel; sm.Ls = p.trToUse; sm.Sp = p.maxNumPoint > 8 ? 8 : p.maxNumPoint;
     sm.pts = pts; sm.gram = gram; sm.theta = theta; sm.outv = outv; sm.st_s = st_s;
 
     const int N = p.N, L = p.trToUse;
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_d
         const int qi = tid / 5, f = tid % 5;
         qf[qi][f] = f < 3 ? xLin[(size_t)b * xstride + (size_t)(i0 + qi) * 6 + f] : uLin[((size_t)b * N + i0 + qi) * 2 + (f - 3)];
     }
-    if (tid < nq * LMPC_MAX_USED_LAPS) nsel[tid] = 0;
+    for (int e = tid; e < nq * L; e += K1_NT) nsel[e] = 0;
     if (tid < nq) st_s[tid] = 0;
     K1STAMP(0);
     __syncthreads();
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_d
     // (two queries per trip in the low-occupancy build.  The occupancy build takes one per trip: with four waves per SIMD the other waves
     //  fill the chain's latency, and the second query's 16 distances cost registers it does not have -- spilled registers are scratch
     //  WRITES: 134 MB per launch at batch 4096 before this)
-    for (int c = myc; c < L && sgi < nsub; c += K1_NW)                    // (c += K1_NW: only when trToUse > 8 waves, never here)
+    for (int c = myc; c < L && sgi < nsub; c += K1_NW)                    // (c += K1_NW: more laps than waves -- trToUse up to 32 -- a wave then scans several laps in turn)
         k1_scan_lap<!OCC>(p, sm, c, wave * K1_QG, sgi, nsub, nq, lane, MAXP);
     __syncthreads();
     K1STAMP(2);
@@ -658,7 +661,7 @@ __device__ __forceinline__ int k1_wave_problem(const lmpc_dev_params &p, int b, 
     const int N = p.N, L = p.trToUse;
     const int MAXP = p.maxNumPoint > 8 ? 8 : p.maxNumPoint, PP = L * MAXP;
     const int QG = N < K1_QG ? N : K1_QG;
-    k1_smem sm; sm.Ls = L;
+    k1_smem sm; sm.Ls = L; sm.Sp = 8;
     double *w = wk;
     sm.qf = (double (*)[5])w; w += QG * 5;
     sm.seld = w; w += QG * L * 8;
@@ -1158,7 +1161,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
     __shared__ int sel_start[LMPC_MAX_USED_LAPS];
     int tcnt = 0; (void)tcnt;
     TSTAMP(0);
-    if (lane == 0) st_sh = 0;
+    // (retry variant: the regression's per-point bits are taken over from the first pass's status word -- the per-point buffer may belong to
+    //  a later launch by the time a deferred retry pass runs)
+    if (lane == 0) st_sh = EQ ? (io.status[b] & (LMPC_ST_REG_SINGULAR | LMPC_ST_NO_SEGMENT)) : 0;
     static_assert(!ABG || !EQ, "the retry variant keeps [A_k | B_k] in LDS");
     if (!ABG && (io.mode & 4)) {
         // K1 (fused step): LTV regression of this QP's N points by this wave, in the LDS behind AB / C that the solve needs only later
@@ -1193,7 +1198,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
     }
     // K2: safe-set selection (k2_select), then the regression status bits of this problem's N points
     if constexpr (term) { k2_select<N, S, 1>(p, io, b, lane, 0, SS, Qsel, sel_start, &st_sh); __syncthreads(); }
-    if (io.rstatus && lane < N) { const int rs_ = io.rstatus[(size_t)b * N + lane]; if (rs_) atomicOr(&st_sh, rs_); }
+    if (!EQ && io.rstatus && lane < N) { const int rs_ = io.rstatus[(size_t)b * N + lane]; if (rs_) atomicOr(&st_sh, rs_); }
     TSTAMP(1);
     if (!(io.mode & 2)) { if (lane == 0) io.status[b] = st_sh; return; }
 

@@ -8,7 +8,9 @@
 #pragma once
 #include "lmpc_kernels.hip.h"
 #include "lmpc_solve_mw.hip.h"
+#ifdef LMPC_WITH_CD                  // the condensed kernel is a measured alternative (not faster), kept out of the default build: racinglmpc_amd.build.build_flavour("cd", ["LMPC_WITH_CD"])
 #include "lmpc_solve_cd.hip.h"
+#endif
 
 struct lmpc_variant_api {
     int N, S;
@@ -47,12 +49,19 @@ template <int N, int S> struct lmpc_variant_launchers {
         hipLaunchKernelGGL((lmpc_solve_kernel<N, S, true>), dim3(B), dim3(WAVE), lds_for(p, io), st, p, B, io); return 0; }
     static int l4(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
         if constexpr (has_mw) { hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 4>), dim3(B), dim3(WAVE * 4), ldsm, st, p, B, io); return 0; } else return l1(st, p, B, io); }
+#ifdef LMPC_WITH_CD
     static constexpr bool has_cd = 2 * N <= 32 && S + 6 <= WAVE;          // condensed kernel: short horizons, one terminal-block column per lane
+#else
+    static constexpr bool has_cd = false;
+#endif
     static int lc(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io, int hasQ) {
+#ifdef LMPC_WITH_CD
         if constexpr (has_cd) {
             const size_t lds = (size_t)(hasQ ? solve_ldsc<N, S>::tot_q : solve_ldsc<N, S>::tot) * sizeof(double);
             hipLaunchKernelGGL((lmpc_solve_kernel_cd<N, S>), dim3(B), dim3(WAVE), lds, st, p, B, io, hasQ); return 0;
-        } else return l1(st, p, B, io);
+        }
+#endif
+        (void)hasQ; return l1(st, p, B, io);
     }
     static int l2(hipStream_t st, const lmpc_dev_params &p, int B, const lmpc_solve_io &io) {
         if constexpr (has_mw) { hipLaunchKernelGGL((lmpc_solve_kernel_mw<N, S, 2>), dim3(B), dim3(WAVE * 2), ldsm, st, p, B, io); return 0; } else return l1(st, p, B, io); }
@@ -77,9 +86,11 @@ template <int N, int S> static bool lmpc_variant_fill(lmpc_variant_api *v) {
         if (hipFuncSetAttribute((const void *)lmpc_solve_kernel<N, S, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::lds1g) != hipSuccess) return false;
     }
     v->lds_cd = 0; v->lds_cd_q = 0; v->launch_cd = &L::lc;
+#ifdef LMPC_WITH_CD
     if constexpr (L::has_cd) {
         v->lds_cd = (size_t)solve_ldsc<N, S>::tot * sizeof(double); v->lds_cd_q = (size_t)solve_ldsc<N, S>::tot_q * sizeof(double);
         if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_cd<N, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_cd_q) != hipSuccess) return false;
     }
+#endif
     return true;
 }

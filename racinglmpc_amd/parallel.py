@@ -84,14 +84,31 @@ def host_signal(tag, port):
     return path
 
 
-def host_wait(tag, port, timeout=3600.0, poll=0.05):
+def host_wait(tag, port, timeout=3600.0, poll=0.05, writer_pid=None):
+    """Sleep until host_signal(tag, port) has been called by a LIVE process of this launch.  The event file carries its writer's pid: a file
+    whose writer is gone -- left behind by a killed launch with the same parent, port and nonce -- is ignored (and removed), so it cannot release
+    the waiters early; writer_pid (the signalling rank's pid, if the caller knows it) turns a dead signaller into an error instead of a sleep
+    until the timeout."""
     path = _rdzv_file(port) + "." + "".join(ch for ch in tag if ch.isalnum())
     t0 = time.time()
-    while not os.path.exists(path):
+    while True:
+        try:
+            with open(path, "rb") as f:
+                buf = f.read()
+            if len(buf) == 8 and _alive(int.from_bytes(buf, "little")):
+                return path
+            if len(buf) == 8:                                        # stale: its writer is dead
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
+        except OSError:
+            pass
+        if writer_pid is not None and not _alive(int(writer_pid)):
+            raise RuntimeError("host_wait(%s): the signalling process %d is gone" % (tag, writer_pid))
         if time.time() - t0 > timeout:
             raise TimeoutError("host_wait(%s): no signal within %.0f s" % (tag, timeout))
         time.sleep(poll)
-    return path
 
 
 def _is_local(addr):

@@ -16,10 +16,14 @@ from . import _capi, parallel
 class BatchedRollouts:
     """B closed-loop LMPC laps against a shared safe set (one GPU context, one rank)."""
 
-    def __init__(self, ctx, track, seed=0):
+    def __init__(self, ctx, track, seed=0, global_noise=False):
+        """global_noise: the plant noise of a lap is drawn for ALL rollouts of the job (same seed on every rank) and this rank keeps the columns
+        of its shard (`noise_shard` = (lo, hi, total), set by LmpcGeneration) -- a rollout then sees the same draws however the job is split over
+        ranks.  Default: every rank draws for its own shard only (seed per rank)."""
         self.ctx, self.track = ctx, np.asarray(track, float)
         self.TL = float(self.track[-1, 3] + self.track[-1, 4])
         self.rng = np.random.default_rng(seed)
+        self.global_noise, self.noise_shard = bool(global_noise), None
         self.last_status = None
         self.last_done = None
 
@@ -31,7 +35,12 @@ class BatchedRollouts:
     def begin(self, x0, xLin0, uLin0, xglob0=None, max_steps=400):
         B = x0.shape[0]
         xl = self._per_rollout(xLin0, B); ul = self._per_rollout(uLin0, B)
-        noise = self.rng.standard_normal((max_steps, B, 3))
+        if self.global_noise and self.noise_shard is not None:
+            lo, hi, total = self.noise_shard
+            assert hi - lo == B, (lo, hi, B)
+            noise = np.ascontiguousarray(self.rng.standard_normal((max_steps, total, 3))[:, lo:hi])
+        else:
+            noise = self.rng.standard_normal((max_steps, B, 3))
         self.ctx.rollout_begin(x0, x0 if xglob0 is None else xglob0, xl, ul, noise)
 
     def run_lap_device(self, x0, xLin0, uLin0, xglob0=None, max_steps=400, ext=0, on_ext=None, keep_invalid=False):
@@ -76,6 +85,7 @@ class LmpcGeneration:
         self.lo, self.hi = parallel.shard(total_rollouts, self.rank, self.world)
         if self.hi <= self.lo:
             raise ValueError("every rank needs at least one rollout (total %d, world %d)" % (total_rollouts, self.world))
+        rollouts.noise_shard = (self.lo, self.hi, total_rollouts)
         self.parents = None            # [(x, u, x_glob, final12, stored_lap_index)] of the previous generation
         self.last_exchange = None      # (bytes per rank, seconds) of the last all-gather
         self.last_status = self.last_done = None

@@ -10,7 +10,8 @@ PredictiveModel.addTrajectory (main.py:113-119).  This module drives that loop f
     the CPU stand-in used to study the solver in the regime the reference converges to without a GPU,
 
 with the oracle's restatement of Simulator.dynModel as the plant (bit-exact against the reference, test_oracle_golden.py) and a
-seeded noise stream (three N(0,1) draws per step, in the reference's order).
+seeded noise stream (three N(0,1) draws per step, in the reference's order; by default the legacy RandomState stream the reference's own
+Simulator consumes after np.random.seed(seed), see noise_source).
 """
 import os
 import sys
@@ -135,11 +136,20 @@ class OracleFlow:
         return float(self.ctrl.Qfun[self.ctrl.it - 1][0])
 
 
-def run_laps(flow, g, laps, seed=5, max_steps=400, on_lap=None, dump_from=None):
+def noise_source(seed, kind="legacy"):
+    """N(0,1) draws of the plant noise, one per call.  "legacy": np.random.RandomState(seed).randn -- the stream the reference's own
+    Simulator.dynModel (SysModel.py:139-141: np.random.randn()) consumes after np.random.seed(seed), so that the executed reference
+    (tests/golden/make_flow_golden.py), the oracle flow and the GPU closed loop see IDENTICAL draws; "pcg": np.random.default_rng(seed)."""
+    if kind == "legacy":
+        return np.random.RandomState(seed).randn
+    return np.random.default_rng(seed).standard_normal
+
+
+def run_laps(flow, g, laps, seed=5, max_steps=400, on_lap=None, dump_from=None, noise="legacy"):
     """main.py:113-119.  Returns a list of per-lap dicts: steps, lap time (Qfun[0]), status histogram, iterations (mean, max), max vx, max |ey|."""
     from oracle import lmpc_oracle as orc
     pt = np.array(g["track"]); TL = float(g["trackLength"])
-    rng = np.random.default_rng(seed)
+    draw = noise_source(seed, noise)
     x0 = np.array([0.5, 0, 0, 0, 0, 0.0]); xS = [x0, x0]
     out = []
     for lap in range(laps):
@@ -156,7 +166,7 @@ def run_laps(flow, g, laps, seed=5, max_steps=400, on_lap=None, dump_from=None):
                 err = "%s: %s" % (type(e).__name__, e); break
             u_cl.append(u); sts.append(st); its.append(it)
             flow.add_point(x_cl[-1], u_cl[-1])
-            xt, gt = orc.dyn_model(pt, x_cl[-1], g_cl[-1], u_cl[-1], rng.standard_normal)
+            xt, gt = orc.dyn_model(pt, x_cl[-1], g_cl[-1], u_cl[-1], draw)
             x_cl.append(xt); g_cl.append(gt)
             if x_cl[-1][4] > TL:
                 break

@@ -29,16 +29,30 @@ def load_variant_golden(name):
     return g
 
 
+def load_30laps_golden(name="lmpc_30laps_n12"):
+    """Reference-executed fixtures on 30 laps of different lengths (tests/golden/make_wide_golden.py): "lmpc_30laps_n12" (numSS_it = trToUse = 4,
+    BASELINE configs[2]) or "lmpc_30laps_stress_n12" (numSS_it = trToUse = 30, numSS_Points = 360: SURVEY 8(d)'s stress variant, which shares the
+    laps of the first -- asserted equal when it was generated)."""
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    if "lapx0" not in g:
+        base = np.load(os.path.join(GOLDEN, "lmpc_30laps_n12.npz"))
+        for i in range(int(g["nLaps"])):
+            for k in ("lapx%d", "lapu%d", "Qfun%d"):
+                g[k % i] = base[k % i]
+    g.setdefault("trToUse", np.int64(4))
+    return g
+
+
 def load_ltv_golden():
     return np.load(os.path.join(GOLDEN, "ltvmpc_n12.npz"))
 
 
-def lmpc_config(g, N=12, max_batch=64, numSS_it=4, numSS_Points=None, **kw):
+def lmpc_config(g, N=12, max_batch=64, numSS_it=4, numSS_Points=None, trToUse=4, **kw):
     from oracle import lmpc_oracle as orc
     from racinglmpc_amd import _capi
     par = orc.QPParams.lmpc_default(N)
     cfg = _capi.config_from(N, par.Q, par.R, par.Qf, par.dR, par.Qslack, par.Fx, par.bx, par.Fu, par.bu, par.xRef,
-                            QterminalSlack=par.QterminalSlack, numSS_Points=12 * numSS_it if numSS_Points is None else numSS_Points, numSS_it=numSS_it, trToUse=4,
+                            QterminalSlack=par.QterminalSlack, numSS_Points=12 * numSS_it if numSS_Points is None else numSS_Points, numSS_it=numSS_it, trToUse=trToUse,
                             track=g["track"], trackLength=float(g["trackLength"]), max_batch=max_batch, **kw)
     return cfg, par
 
@@ -124,11 +138,11 @@ def replay_lap(g, lap, ctx, on_record, max_records=None):
     return n
 
 
-def run_golden_step_check(max_records=None):
+def run_golden_step_check(max_records=None, dev_every=0):
     """Replay the recorded reference laps through the HIP path (lmpc_step_batch, B = 1 per recorded step, addPoint
     in between) and compare with the certified optimum of the reference-assembled QP.  Used by smoke() and tests."""
     g = load_lmpc_golden()
-    errs, stats, iters, zerr = [], [], [], []
+    errs, stats, iters, zerr, ndev = [], [], [], [], []
     left = max_records
     for lap in (4, 5):
         if left is not None and left <= 0:
@@ -144,10 +158,24 @@ def run_golden_step_check(max_records=None):
             eu = np.abs(out["uPred"][0].ravel() - opt[78:102]).max()
             errs.append(max(ex, eu)); stats.append(int(out["status"][0])); iters.append(int(out["iters"][0]))
             zerr.append(np.abs(out["ssSel"][0] - g["rec_SSsel"][r].T).max())
+            if dev_every and len(errs) % dev_every == 0:
+                # the timed entry point as bench.py calls it: lmpc_step_batch_dev with the optional outputs (mu, residual triple, Q-function of the
+                # selection) NULL -- every output it does produce must be bit-identical to the host-buffer entry point's
+                inp = dict(x0=g["rec_x0"][r][None], xLin=g["rec_xLin"][r][None], uLin=g["rec_uLin"][r][None], uOld=g["rec_OldInput"][r][None],
+                           zt=g["rec_zt"][r][None], xPredPrev=g["rec_xPredPrev"][r][None], hasPred=np.array([g["rec_hasPred"][r]]), timeStep=np.array([g["rec_t"][r]]))
+                a, keep = ctx.step_dev_buffers(inp, diagnostics=False)
+                assert not a.mu and not a.resid and not a.qSel
+                ctx.step_batch_dev(1, a)
+                dev = ctx.step_dev_fetch(a, 1)
+                for k in ("xPred", "uPred", "slack", "lambd", "sTerm", "ztNext", "ztuNext", "ssSel", "A", "B", "C", "status", "iters"):
+                    assert np.array_equal(dev[k], out[k]), (r, k)
+                for q_ in keep:
+                    ctx.dev_free(q_)
+                ndev.append(r)
 
         n = replay_lap(g, lap, ctx, on_record, left)
         if left is not None:
             left -= n
         ctx.close()
     return dict(max_err_xu=float(np.max(errs)), max_err_sssel=float(np.max(zerr)), n=len(errs), status=np.array(stats),
-                iters_mean=float(np.mean(iters)), iters_max=int(np.max(iters)))
+                iters_mean=float(np.mean(iters)), iters_max=int(np.max(iters)), n_dev=len(ndev))

@@ -6,6 +6,7 @@ class exactly as tests/golden/make_golden.py does (same stand-ins for cvxopt.qp 
   lmpc_n40.npz        N = 40, numSS_it = 4, numSS_Points = 48: BASELINE.json configs[4]'s horizon (8 steps)
   mpc_n14.npz         N = 14: main.py's stage 2 (LTI MPC on Utilities.Regression's A, B) and stage 3 (LTV MPC), ten closed-loop steps each
   lmpc_30laps_n12.npz N = 12, 30 PID laps of different speeds in both stores (BASELINE.json configs[2]): sorted insert, the four fastest
+  lmpc_30laps_stress_n12.npz  the same 30 laps with numSS_it = trToUse = 30, numSS_Points = 360 (SURVEY 8(d)'s stress variant); `... make_wide_golden.py stress` makes only this one
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_wide_golden.py          (needs /root/reference)
 
@@ -90,16 +91,17 @@ def make(PC, ICP, PM, SM, TR, UT, N, numSS_it, fname, steps=12):
         len(recs), out["q"].shape[1], out["l"].shape[1], out["cert_opt"].max(), nact))
 
 
-def make_30laps(PC, ICP, PM, SM, TR, UT, fname="lmpc_30laps_n12.npz", steps=10):
+def make_30laps(PC, ICP, PM, SM, TR, UT, fname="lmpc_30laps_n12.npz", steps=10, numSS_it=4, trToUse=4, store_laps=True):
     """BASELINE.json configs[2] / SURVEY 8(d) "safe set from 30 laps": 30 single-lap PID trajectories (lap i at target speed 0.6 + 0.02 i,
     np.random.seed(i)) handed to PredictiveModel.addTrajectory (sorted insert, :35-46; the regression uses the first trToUse = 4 of the sorted
     store) and LMPC.addTrajectory (the selection uses argsort(LapTime)[:4], :395-402), then closed-loop steps started on lap 29."""
-    N, n, d, numSS_it, numSS_Points = 12, 6, 2, 4, 48
+    N, n, d = 12, 6, 2
+    numSS_Points = 12 * numSS_it                           # initControllerParameters.py:43-44
     map_ = TR.Map(0.4)
     x0 = np.array([0.5, 0, 0, 0, 0, 0])
     _it, _pts, Laps, TimeLMPC, QterminalSlack, lmpcParameters = ICP.initLMPCParams(map_, N)
     lmpcParameters.timeVarying = True
-    pm = PM.PredictiveModel(n, d, map_, 4)
+    pm = PM.PredictiveModel(n, d, map_, trToUse)
     laps = []
     for i in range(30):
         np.random.seed(i)
@@ -142,15 +144,26 @@ def make_30laps(PC, ICP, PM, SM, TR, UT, fname="lmpc_30laps_n12.npz", steps=10):
         lmpc.xLin = np.vstack((xo[1:, :], lmpc.zt)); lmpc.uLin = np.vstack((uo[1:, :], lmpc.zt_u)); lmpc.OldInput = uo[0, :].copy()
         xc, xg = simulator.dynModel(xc, xg, uo[0, :].copy())
     out = {k: mg.stack([r[k] for r in recs]) for k in recs[0].keys()}
-    out.update(track=map_.PointAndTangent.copy(), trackLength=map_.TrackLength, numSS_it=numSS_it, numSS_Points=numSS_Points, N=N, nLaps=30)
+    out.update(track=map_.PointAndTangent.copy(), trackLength=map_.TrackLength, numSS_it=numSS_it, numSS_Points=numSS_Points, N=N, nLaps=30, trToUse=trToUse)
+    base = None if store_laps else np.load(os.path.join(HERE, "lmpc_30laps_n12.npz"))      # (the stress fixture shares the 30 laps of lmpc_30laps_n12.npz: same seeds, asserted equal)
     for i, (xl, ul, gl) in enumerate(laps):
         assert np.array_equal(lmpc.SS[i], xl) and np.array_equal(lmpc.uSS[i], ul)          # (no in-place edit happened: xLin was replaced before the first solve)
-        out["lapx%d" % i] = xl; out["lapu%d" % i] = ul; out["Qfun%d" % i] = lmpc.Qfun[i].copy()
+        if store_laps:
+            out["lapx%d" % i] = xl; out["lapu%d" % i] = ul; out["Qfun%d" % i] = lmpc.Qfun[i].copy()
+        else:
+            assert np.array_equal(base["lapx%d" % i], xl) and np.array_equal(base["lapu%d" % i], ul) and np.array_equal(base["Qfun%d" % i], lmpc.Qfun[i])
     out["modelOrder"] = np.array([[j for j, (xl, _, _) in enumerate(laps) if xl is not None and xs.shape == xl.shape and np.array_equal(xs, xl)][0] for xs in pm.xStored])
     out["LapTime"] = np.array(lmpc.LapTime)
     np.savez_compressed(os.path.join(HERE, fname), **out)
     print(fname + ": %d steps, lap lengths %d..%d, model store order (first 6): %s, fastest four: %s, certificates <= %.1e" % (
         len(recs), min(lmpc.LapTime), max(lmpc.LapTime), list(out["modelOrder"][:6]), list(np.argsort(lmpc.LapTime)[:4]), out["cert_opt"].max()))
+
+
+def make_30laps_stress(*ref):
+    """SURVEY 8(d)'s scan-heavy stress variant on the executed reference: numSS_it = trToUse = 30 (every stored lap takes part in the regression,
+    PredictiveModel.py:31, 52-58, and in the safe set, PredictiveControllers.py:395-412), numSS_Points = 360 (nz = 492 variables, 366 terminal-block
+    columns), six closed-loop steps from lap 29.  The 30 laps are those of lmpc_30laps_n12.npz (same seeds; asserted equal, not stored twice)."""
+    make_30laps(*ref, fname="lmpc_30laps_stress_n12.npz", steps=6, numSS_it=30, trToUse=30, store_laps=False)
 
 
 def make_mpc_n14(PC, ICP, PM, SM, TR, UT, fname="mpc_n14.npz", steps=10):
@@ -207,11 +220,15 @@ def make_mpc_n14(PC, ICP, PM, SM, TR, UT, fname="mpc_n14.npz", steps=10):
 def main():
     mg.install_standins()
     ref = mg.load_reference()
+    if sys.argv[1:] == ["stress"]:                       # (only the stress fixture: the others are not touched)
+        make_30laps_stress(*ref)
+        return
     make_mpc_n14(*ref)
     make_30laps(*ref)
     make(*ref, 12, 6, "lmpc_wide_n12.npz")
     make(*ref, 14, 4, "lmpc_n14.npz")
     make(*ref, 40, 4, "lmpc_n40.npz", steps=8)
+    make_30laps_stress(*ref)
     for root, dirs, files in os.walk(mg.REF):
         assert "__pycache__" not in dirs, "reference tree was written to"
 

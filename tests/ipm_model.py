@@ -132,7 +132,7 @@ def kkt_solve(qp, f, th_lane, th_s, gx, gu, gs, h_lane, h_u, h_s, gl, re_dyn, re
     return dx, du, ds, dl
 
 
-def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True):
+def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True, polish=None, pex=None, so_w=1.0):
     """Returns dict(x,u,s,lam,sT, mu (ineq duals in reference row order), iters, gap, rd, re).
     exact_nu (round 3): the multipliers of the dynamics rows are not iterates of their own; every iteration takes them from the adjoint recursion
     nu_{k-1} = A_k' nu_k - w_k (w_k: gradient of the state rows' other terms), so the x rows of the dual residual vanish identically and the
@@ -160,14 +160,11 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
     info = {}
     sep = False; gap_prev = None          # separate primal/dual steps only after an iteration with poor progress
     qscale = max(1.0, float(np.max(np.abs(qp.Qsel)))) if qp.term else 1.0
-    for it in range(maxit):
-        if not carry_t or it == 0:
-            t_lane, t_u, t_s, t_l = slacks()       # (carry_t: the row slacks are iterates of their own, t += alpha dt, never a difference of O(1) numbers)
-        gap = (t_lane.ravel() @ m_lane.ravel() + t_u.ravel() @ m_u.ravel() + t_s.ravel() @ m_s.ravel() + t_l @ m_l) / mtot
-        if gap_prev is not None:
-            sep = gap > 0.1 * gap_prev
-        gap_prev = gap
-        # ---- residuals
+    pol_backup = None; pol_rej = 0; nfact = 0; act_pred = None; pol_again = False; pol_chain = 0
+
+    def residuals(x, u, s, lam, nu, eta_m, m_lane, m_u, m_s, m_l):
+        """True residuals of the KKT conditions at (x, u, s, lam | nu, eta_m, mu); with exact_nu the multipliers of the dynamics rows are
+        recomputed in place from the adjoint recursion (the x rows then vanish identically)."""
         sT = qp.SS @ lam - x[N] if qp.term else None
         rx = np.zeros((N + 1, 6))
         if exact_nu:
@@ -190,12 +187,102 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         re_sum = (lam.sum() - 1.0) if qp.term else 0.0
         rd = max(np.abs(rx[1:]).max(), np.abs(ru).max(), np.abs(rs).max(), np.abs(rl).max() if qp.term else 0)
         re = max(np.abs(re_dyn).max(), abs(re_sum))
+        return rx, ru, rs, rl, re_dyn, re_sum, rd, re
+
+    def costate_steps(dx, dl, dm_lane, dm_l, rx, rl):
+        """Steps of the equality multipliers that go with a Newton direction (dx, dl, dmu): dnu by the backward recursion over the x rows, deta as the
+        mean over the lambda rows."""
+        dnu = np.zeros((N, 6)); dsT = None
+        if qp.term:
+            dsT = qp.SS @ dl - dx[N]; g = rx[N] + Qf2 @ dx[N] - T * dsT
+        else:
+            g = rx[N] + Qf2 @ dx[N]
+        dnu[N - 1] = -g
+        for k in range(N - 1, 0, -1):
+            dnu[k - 1] = -(rx[k] + Q2 @ dx[k] + Fx.T @ dm_lane[k]) + A[k].T @ dnu[k]
+        deta = np.mean(-rl + dm_l - qp.SS.T @ (T * dsT)) if qp.term else 0.0
+        return dnu, deta
+    for it in range(maxit):
+        if not carry_t or it == 0:
+            t_lane, t_u, t_s, t_l = slacks()       # (carry_t: the row slacks are iterates of their own, t += alpha dt, never a difference of O(1) numbers)
+        gap = (t_lane.ravel() @ m_lane.ravel() + t_u.ravel() @ m_u.ravel() + t_s.ravel() @ m_s.ravel() + t_l @ m_l) / mtot
+        gp_before, sep_before = gap_prev, sep
+        if gap_prev is not None:
+            sep = gap > 0.1 * gap_prev
+        gap_prev = gap
+        # ---- residuals
+        rx, ru, rs, rl, re_dyn, re_sum, rd, re = residuals(x, u, s, lam, nu, eta_m, m_lane, m_u, m_s, m_l)
         if verbose:
             print("it %2d gap %.2e rd %.2e re %.2e" % (it, gap, rd, re))
-        info = dict(iters=it, gap=gap, rd=rd, re=re)
+        info.update(iters=it, gap=gap, rd=rd, re=re)
+        if pol_backup is not None:
+            # the previous iteration was an active-set (polish) step: accept it only if the true residuals meet the ordinary tolerances and
+            # the signs hold (slacks of the rows taken as inactive, multipliers of the rows taken as active); otherwise back to the iterate it started from
+            tsn = (t_lane, t_u, t_s, t_l); msn = (m_lane, m_u, m_s, m_l)
+            tmin = min([t.min() for t in tsn if t.size]); mmin = min([m.min() for m in msn if m.size])
+            ok = np.isfinite(gap) and abs(gap) < tol_gap and rd < tol_res * qscale and re < tol_res and tmin > -polish.get("tol_t", 1e-9) and mmin > -polish.get("tol_m", 1e-9) * qscale
+            info["polish"] = "ok" if ok else "rejected"
+            if verbose:
+                print("   polish %s: gap %.2e rd %.2e re %.2e tmin %.2e mmin %.2e" % (info["polish"], gap, rd, re, tmin, mmin))
+            if ok:
+                info["pol_ok"] = 1
+                break
+            if polish.get("pdas", 0) > pol_chain and np.isfinite(gap) and np.isfinite(rd):
+                # primal-dual active-set step: keep the point, re-classify the rows by mu - t > 0 (a violated inactive row has mu = 0, t < 0: becomes
+                # active; an active row with a negative multiplier has t = 0, mu < 0: becomes inactive) and solve again
+                pol_chain += 1; pol_again = True
+            else:
+                pol_again = False
+        if pol_backup is not None and not pol_again:
+            (x, u, s, lam, nu, eta_m, t_lane, t_u, t_s, t_l, m_lane, m_u, m_s, m_l, gap_prev, sep) = pol_backup
+            pol_backup = None; pol_rej += 1
+            continue
         if gap < tol_gap and rd < tol_res * qscale and re < tol_res:
             break
         ts = (t_lane, t_u, t_s, t_l); ms = (m_lane, m_u, m_s, m_l)
+        slow_ok = polish is None or "slow" not in polish or (gp_before is not None and gap > polish["slow"] * gp_before)      # only behind an iteration that contracted the gap by less than 1 / slow
+        if polish is not None and (pol_again or (slow_ok and pol_rej <= polish.get("retries", 0) and gap < polish["gap"] * (polish.get("retry_factor", 1e-2) ** pol_rej) and rd < polish.get("rd", np.inf) * qscale)):
+            # active-set finisher (the reference's own polish=True, PredictiveControllers.py:275): rows with t < mu are taken as active
+            # (weight th_pol, right-hand side t th_pol: the step drives their slack to zero), the others as inactive (weight 0, right-hand side mu:
+            # the step drives their multiplier to zero); ONE factorisation + solve, full step
+            thp = polish.get("th", 1e11)
+            act = [t < m for t, m in zip(ts, ms)]
+            if polish.get("lookahead") and act_pred is not None:
+                act = act_pred
+            ths_p = [np.where(a_, thp, 0.0) for a_ in act]
+            hp = [np.where(a_, t * thp, m) for a_, t, m in zip(act, ts, ms)]
+            f = kkt_factor(qp, ths_p[0], ths_p[1], ths_p[2], ths_p[3], polish.get("reg", reg_l))
+            dx, du, ds, dl = kkt_solve(qp, f, ths_p[0], ths_p[2], rx, ru, rs, hp[0], hp[1], hp[2], rl + hp[3], re_dyn, re_sum)
+            fl = dx[:N] @ Fx.T
+            dt = (-(fl - ds), -(du @ Fu.T), ds, (dl if qp.term else np.zeros(0)))
+            dm = [-h_ - th * d for h_, th, d in zip(hp, ths_p, dt)]
+            if not pol_again:
+                pol_backup = (x.copy(), u.copy(), s.copy(), lam.copy(), nu.copy(), eta_m, t_lane, t_u, t_s, t_l, m_lane, m_u, m_s, m_l, gp_before, sep_before); pol_chain = 0
+            pol_again = False
+            dnu = np.zeros((N, 6))
+            if qp.term:
+                dsT = qp.SS @ dl - dx[N]; g = rx[N] + Qf2 @ dx[N] - T * dsT
+            else:
+                g = rx[N] + Qf2 @ dx[N]
+            dnu[N - 1] = -g
+            for k in range(N - 1, 0, -1):
+                dnu[k - 1] = -(rx[k] + Q2 @ dx[k] + Fx.T @ dm[0][k]) + A[k].T @ dnu[k]
+            deta = np.mean(-rl + dm[3] - qp.SS.T @ (T * dsT)) if qp.term else 0.0
+            x = x + dx; u = u + du; s = s + ds
+            if qp.term:
+                lam = lam + dl
+            t_lane, t_u, t_s, t_l = [t + d for t, d in zip(ts, dt)]
+            m_lane, m_u, m_s, m_l = [m + d for m, d in zip(ms, dm)]
+            if not exact_nu:
+                nu = nu + dnu
+            eta_m += deta
+            info["pol_it"] = it; nfact += 1
+            if polish.get("debug"):
+                names = ("lane", "u", "s", "lam")
+                for nm, t0, m0, tn, mn, a_ in zip(names, ts, ms, (t_lane, t_u, t_s, t_l), (m_lane, m_u, m_s, m_l), act):
+                    for idx in np.argwhere((tn.ravel() < -1e-9) | (mn.ravel() < -1e-9)).ravel():
+                        print("   row %s[%d] act=%d  t %.3e mu %.3e -> t %.3e mu %.3e" % (nm, idx, a_.ravel()[idx], t0.ravel()[idx], m0.ravel()[idx], tn.ravel()[idx], mn.ravel()[idx]))
+            continue
         # Barrier weights theta = mu / t are capped at th_max in the Newton matrix: 1 / theta >= 1 / th_max is a dual regularisation of the row
         # (F dw + (1 / theta_c) dmu = -r_c / mu), so the right-hand side uses the same effective reciprocal rt = 1 / max(t, mu / th_max) as the
         # matrix and the fixed point does not move.  Uncapped, an active lane row (t ~ 1e-14, mu ~ 10) puts 1e15 into a stage Hessian whose
@@ -203,7 +290,7 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         cap = (lambda t, m: np.maximum(t, m / th_max)) if th_max is not None else (lambda t, m: t)
         rts = [1.0 / cap(t, m) if t.size else t for t, m in zip(ts, ms)]
         th_lane, th_u, th_s, th_l = ths = [m * rt for m, rt in zip(ms, rts)]
-        f = kkt_factor(qp, th_lane, th_u, th_s, th_l, reg_l)
+        f = kkt_factor(qp, th_lane, th_u, th_s, th_l, reg_l); nfact += 1
         # terminal slack eliminated: its Hessian T enters W7 through T^-1 (kept in factor)
         def solve(h_lane, h_u, h_s, h_l):
             return kkt_solve(qp, f, th_lane, th_s, rx, ru, rs, h_lane, h_u, h_s, rl + h_l, re_dyn, re_sum)
@@ -215,6 +302,24 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
             return -(fl - ds), -(du @ Fu.T), ds, (dl if qp.term else np.zeros(0))
         dt = ineq_steps(dxa, dua, dsa, dla)
         dma = [-h_ - th * d for h_, th, d in zip(hp, ths, dt)]
+        if pex is not None and gap < pex.get("gap", 1e-3):
+            # predictor-extrapolated termination: the full affine-scaling step lands on the tangent's estimate of the optimum (the stationarity rows
+            # are linear, so its dual residual is the solve's own error; its complementarity products are dt dmu, second order).  If that point
+            # meets every tolerance -- true residuals re-evaluated, slacks and multipliers not below -tol -- it is returned.
+            xc, uc, sc, lc = x + dxa, u + dua, s + dsa, (lam + dla if qp.term else lam)
+            tcs = [t + d for t, d in zip(ts, dt)]; mcs = [m + d for m, d in zip(ms, dma)]
+            dnu_a, deta_a = costate_steps(dxa, dla, dma[0], dma[3], rx, rl)
+            nuc = nu + dnu_a; etac = eta_m + deta_a
+            rdc, rec = residuals(xc, uc, sc, lc, nuc, etac, *mcs)[6:]
+            gapc = sum(np.abs(t * m).sum() for t, m in zip(tcs, mcs)) / mtot
+            tmin = min(t.min() for t in tcs if t.size); mmin = min(m.min() for m in mcs if m.size)
+            if verbose:
+                print("   pex: gap %.2e rd %.2e re %.2e tmin %.2e mmin %.2e" % (gapc, rdc, rec, tmin, mmin))
+            if gapc < tol_gap and rdc < tol_res * qscale and rec < tol_res and tmin > -pex.get("tol_t", 1e-9) and mmin > -pex.get("tol_m", 1e-9) * qscale:
+                x, u, s, lam, nu, eta_m = xc, uc, sc, lc, nuc, etac
+                m_lane, m_u, m_s, m_l = mcs
+                info.update(gap=gapc, rd=rdc, re=rec, pex=1)
+                break
         def maxstep(vs, dvs):
             al = np.inf
             for v, dv in zip(vs, dvs):
@@ -228,7 +333,7 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         gap_aff = sum(((t + aap * d).ravel() @ (m + aad * dm).ravel()) for t, d, m, dm in zip(ts, dt, ms, dma)) / mtot
         sig = (gap_aff / gap) ** 3
         tgt = max(sig * gap, 0.01 * tol_gap)          # keep the complementarity products off the rounding floor
-        rc = [t * m - tgt + d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]
+        rc = [t * m - tgt + so_w * d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]      # (so_w = 0: no second-order term -- affine + centring only, what a two-right-hand-side single sweep could deliver)
         hs = [r * rt for r, rt in zip(rc, rts)]
         dx, du, ds, dl = solve(*hs)
         dt = ineq_steps(dx, du, ds, dl)
@@ -253,6 +358,7 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         if qp.term:
             # row lambda_i: -dm_l + SS'(T dsT) + deta = -rl  -> average over rows for robustness
             deta = np.mean(-rl + dm[3] - qp.SS.T @ (T * dsT))
+        act_pred = [(t + d) < (m + d2) for t, d, m, d2 in zip(ts, dt, ms, dm)]      # full-step (Newton target) classification of the rows
         x += al * dx; u += al * du; s += al * ds
         if carry_t:
             t_lane, t_u, t_s, t_l = [t + al * d for t, d in zip(ts, dt)]
@@ -264,7 +370,7 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         eta_m += ald * deta
     out = dict(x=x, u=u, s=s, lam=lam, sT=(qp.SS @ lam - x[N]) if qp.term else None,
                mu=np.concatenate([m_lane.ravel(), m_u.ravel(), m_s.ravel(), m_l]), nu=nu, eta=eta_m)
-    out.update(info)
+    out.update(info); out["nfact"] = nfact
     return out
 
 

@@ -107,6 +107,52 @@ def test_batch4096_30_laps_certificate(built):
     ctx.close()
 
 
+@pytest.mark.parametrize("B", [64, 512, 1200])
+def test_30_laps_stress_variant_certificate(built, B):
+    """SURVEY 8(d)'s stress variant -- numSS_it = trToUse = 30, numSS_Points = 360 on 30 stored laps (the reference takes any numSS_it:
+    PredictiveControllers.py:293-311, 395-402; PredictiveModel.py:31) -- through the four-wave, the two-wave and the one-wave kernel: every problem
+    certified, the regression and the selection against the oracle on a sample.  (The reference-executed fixture of the same configuration:
+    test_gpu_parity.py::test_30_lap_stores_match_reference[lmpc_30laps_stress_n12].)"""
+    from racinglmpc_amd import _capi
+    from oracle import lmpc_oracle as orc
+    from tests.test_gpu_configs import pid_laps_batched
+    g = common.load_lmpc_golden()
+    N, L, S = 12, 30, 360
+    laps = pid_laps_batched(np.array(g["track"]), 30)
+    cfg, par = common.lmpc_config(g, N, max_batch=B, max_laps=40, max_lap_len=1024, numSS_it=L, trToUse=L)
+    ctx = _capi.Context(cfg)
+    for x, u in laps:
+        ctx.model_add_trajectory(x, u); ctx.ss_add_trajectory(x, u)
+    xq, uq = laps[29]
+    tb = (37 * np.arange(B)) % (xq.shape[0] - 40 - N - 2)
+    rng = np.random.default_rng(1234)
+    inp = dict(x0=xq[tb] + rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02]),
+               xLin=np.stack([xq[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uq[t + 1:t + N + 1] for t in tb]),
+               uOld=uq[tb].copy(), zt=xq[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    assert np.all(out["status"] == 0), np.unique(out["status"], return_counts=True)
+    _certify(par, out, inp, what="stress variant 30 laps / 360 points, B=%d (%d wave(s) per QP)" % (B, ctx.solver_waves(B)))
+    # oracle: sorted model store, all 30 laps in the regression; the 30 fastest (= all) laps in the safe set, in argsort(LapTime) order
+    TL = float(g["trackLength"]); track = np.array(g["track"])
+    model = orc.OracleModel(track, L)
+    for x, u in laps:
+        model.addTrajectory(x, u)
+    # (laps 13 and 14 both take 297 steps.  The reference orders the safe set by np.argsort(LapTime) (:395, 402), whose default sort is not stable --
+    #  and vectorised per CPU in current NumPy --, so the order of tied laps is not defined there; the library's sort is stable: lower lap index first.
+    #  The oracle is given the tie broken the same way.)
+    Qf = [orc.compute_cost(x, TL) for x, _ in laps]; LapTime = [x.shape[0] + 1e-6 * i for i, (x, _) in enumerate(laps)]
+    for b in range(0, B, max(B // 6, 1)):
+        A, Bm, C = orc.compute_ltv_dynamics(model.xStored, model.uStored, model.usedIt, track, inp["xLin"][b], inp["uLin"][b], N)
+        for got, ref in ((out["A"][b], A), (out["B"][b], Bm), (out["C"][b], C)):
+            assert (np.abs(got - np.array(ref)) / (1 + np.abs(np.array(ref)))).max() < common.TOL_ABC
+        zt = inp["zt"][b].copy()
+        if zt[4] - inp["x0"][b][4] > TL / 2:
+            zt[4] = np.max([zt[4] - TL, 0])
+        SSsel, Qsel, _, _ = orc.terminal_components([x for x, _ in laps], [u for _, u in laps], Qf, LapTime, zt, S, L, None, 30, int(inp["timeStep"][b]), N, TL)
+        assert np.array_equal(out["ssSel"][b], SSsel.T) and np.array_equal(out["qSel"][b], Qsel)
+    ctx.close()
+
+
 def test_inexact_and_perturbed_batches_certificate(built):
     """5x the bench's state noise (the regime that produces LMPC_ST_INEXACT): every unflagged solution carries a certificate
     <= 1e-7, the flagged ones the 1e-5 their status documents (their distance to the oracle optimum: test_inexact_status_is_usable)."""

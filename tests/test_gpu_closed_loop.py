@@ -1,8 +1,10 @@
 """-m gpu: the reference's actual experiment through the drop-in classes -- main.py:97-121, 40 LMPC laps at N = 14 (Laps = 40 + numSS_it,
 initControllerParameters.py:46), Simulator.sim's loop (SysModel.py:22-54) with the oracle's restatement of the plant and seeded noise.
 
-What the reference converges to (oracle restatement of its flow, tests/golden/reference_flow_laps_n14.json): 201..204 steps in the first LMPC
-lap, ~100 by lap 7, 66..73 from lap 27 on, vx up to 3.5 m/s, |ey| up to 0.45 (lane slacks active).  That regime is where the round-2 kernels
+What the reference converges to (tests/golden/reference_flow_laps_n14.json: the EXECUTED reference classes -- LMPC, PredictiveModel,
+Simulator.sim -- under np.random.seed(s), tests/golden/make_flow_golden.py; the GPU loop here consumes the same RandomState draws,
+tests/closed_loop.noise_source): 203..209 steps in the first LMPC lap, ~100 by lap 7, 68..75 from lap 27 on, vx up to 3.5 m/s, |ey| up to
+0.45 (lane slacks active).  That regime is where the round-2 kernels
 flagged LMPC_ST_INEXACT once or twice per lap (an active lane row's barrier weight mu / t ~ 1e15 cost the Riccati recursion its accuracy); the
 capped weights (LMPC_TH_INV, lmpc_kernels.hip.h) removed that: the tests assert NO status bit on any of the ~3 900 closed-loop QPs of a run.
 
@@ -10,7 +12,7 @@ Behavioural half of the a17 parity statement.  The reference's solver returns an
 closed loops are compared as closed loops:
   * against the oracle flow solved to the certified optimum (same noise): identical lap lengths while round-off has not been amplified
     (the first laps; the loop is chaotic at the scale of single steps from about lap 8 on);
-  * against the oracle's eps = 1e-3 flow: lap lengths scatter by +-5 steps from noise seed to noise seed in EITHER flow (201..212 vs 203..208 in lap 0
+  * against the executed reference's eps = 1e-3 flow: lap lengths scatter by +-5 steps from noise seed to noise seed in EITHER flow (201..212 vs 203..208 in lap 0
     over eight seeds), so seed-by-seed agreement to +-2 steps does not exist even between two seeds of the reference flow itself; the means over the
     eight seeds agree to 1.5 / 0.3 / 0.5 steps in laps 0 / 1 / 2, asserted to +-3.
 """

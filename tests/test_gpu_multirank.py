@@ -1,0 +1,138 @@
+"""-m gpu: the multi-rank LMPC generation loop (BASELINE configs[3]: rollouts sharded over the ranks, one exchange per lap) with world = 2 ON ONE
+MI355X.  RCCL refuses two ranks on one device, so the two processes -- each with its own lmpc context on device 0 -- exchange through the
+capability-chosen host path of rollout.LmpcGeneration (tests/gloo_comm.GlooComm: torch.distributed gloo); everything except the wire collective
+is the product code running on hardware: sharding, the device-resident laps, the owner gather of the lap extensions, the record packing, the
+deterministic top-K and the identical inserts into both stores (SysModel.py:22-54 x many cars; PredictiveControllers.py:418-445, 466-474).
+
+Checked: (a) both ranks end with bit-identical stores (Q-functions of every lap; a probe batch through the full step gives bit-identical
+regressions, selections and optima), (b) the laps chosen in every generation -- and the global rollouts they came from -- equal those of a ONE-rank
+run over the same 2 x shard (same per-rollout noise, same solve kernel), (c) lap extensions are taken from the rank that owns the continuing
+rollout, (d) a flagged rollout on rank 1 is skipped on both ranks."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys, numpy as np
+root, outdir, mode, total, gens, sabotage = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+sys.path.insert(0, root)
+from racinglmpc_amd import _capi, parallel, rollout
+from tests import common
+import bench
+if mode == "gloo":
+    from tests.gloo_comm import GlooComm
+    comm = GlooComm()
+else:
+    comm = parallel.LocalComm()
+rank, world = comm.rank, comm.world
+g = common.load_lmpc_golden()
+lo, hi = parallel.shard(total, rank, world)
+cfg, par = common.lmpc_config(g, 12, max_batch=max(hi - lo, 16), max_laps=8, max_lap_len=512)     # (small initial capacities: the stores grow under the loop)
+ctx = _capi.Context(cfg)
+for _ in range(4):
+    ctx.model_add_trajectory(g["xPID"], g["uPID"]); ctx.ss_add_trajectory(g["xPID"], g["uPID"])
+ro = rollout.BatchedRollouts(ctx, g["track"], seed=100, global_noise=True)
+K = 4
+gen = rollout.LmpcGeneration(ro, total, K=K, T_max=400, ext=40, comm=comm)
+x0 = np.tile(np.array([0.5, 0, 0, 0, 0, 0.0]), (total, 1)); x0[:, 5] = np.linspace(-0.1, 0.1, total); x0[:, 0] += np.linspace(0.0, 0.1, total)
+out = {}
+for it in range(gens):
+    if it == sabotage:                     # the rollouts that continue stored lap 3 start far off the track (every rank applies the same edit)
+        fin = gen.parents[3][3].copy(); fin[4] = 1.0e9
+        gen.parents[3] = gen.parents[3][:3] + (fin,) + gen.parents[3][4:]
+    rows_before = [ctx.ss_lap_rows(l) for l in range(ctx.ss_num_laps())]
+    try:
+        best = gen.run(x0, g["xPID"][1:14], g["uPID"][1:13])
+    except RuntimeError:
+        print("rank %d generation %d: done %s status %s" % (rank, it, gen.last_done, gen.last_status), file=sys.stderr, flush=True)
+        raise
+    shards = [parallel.shard(total, r, world) for r in range(world)]
+    out["gen%d_len" % it] = np.array([b[4] for b in best])
+    out["gen%d_global" % it] = np.array([shards[int(b[3])][0] + int(b[5][12]) for b in best])       # global rollout index of every chosen lap
+    out["gen%d_src" % it] = np.array([int(b[3]) for b in best])
+    for j, b in enumerate(best):
+        out["gen%d_x%d" % (it, j)] = b[0]; out["gen%d_u%d" % (it, j)] = b[1]
+    out["gen%d_skipped" % it] = np.array([k for k, _ in gen.skipped_extensions], dtype=np.int64)
+    out["gen%d_skipped_bits" % it] = np.array([b for _, b in gen.skipped_extensions], dtype=np.int64)
+    out["gen%d_ext_rows" % it] = np.array([ctx.ss_lap_rows(l) - rows_before[l] for l in range(len(rows_before))])
+    out["gen%d_flagged" % it] = lo + np.nonzero(gen.last_status & ~64)[0]            # global indices of this rank's flagged rollouts
+nl = ctx.ss_num_laps()
+out["n_laps"] = nl
+for l in range(nl):
+    out["qfun%d" % l] = ctx.ss_get_qfun(l)
+inp = bench.synth_batch(g, 16, 12, seed=7)
+probe = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+for k in ("A", "B", "C", "ssSel", "qSel", "xPred", "uPred", "lambd", "ztNext", "status"):
+    out["probe_" + k] = probe[k]
+out["lo"], out["hi"], out["waves"] = lo, hi, ctx.solver_waves(hi - lo)
+np.savez(os.path.join(outdir, "%s_rank%d.npz" % (mode, rank)), **out)
+comm.close()
+ctx.close()
+'''
+
+
+def _run(tmp_path, mode, total, gens, sabotage, port):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    # the same solve kernel whatever the shard size (the closed loop amplifies summation-order differences between the 4-, 2- and 1-wave kernels)
+    env = dict(os.environ, LMPC_MW_MAX_BATCH="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    args = [str(script), common.ROOT, str(tmp_path), mode, str(total), str(gens), str(sabotage)]
+    if mode == "gloo":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    else:
+        cmd = [sys.executable] + args
+    r = subprocess.run(cmd, env=env, timeout=1500, capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    return [dict(np.load(tmp_path / ("%s_rank%d.npz" % (mode, k)))) for k in range(2 if mode == "gloo" else 1)]
+
+
+def _same(a, b, keys=None, skip=("lo", "hi")):
+    for k in (keys or a.keys()):
+        if k in skip or k.endswith("_flagged"):
+            continue
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_two_ranks_on_one_gpu_match_each_other_and_one_rank(built, tmp_path):
+    total, gens = 1024, 3            # (512 per rank and 1024 on one rank: both beyond one regression work-group per CU, i.e. the same build of the regression kernel)
+    r0, r1 = _run(tmp_path, "gloo", total, gens, -1, 29631)
+    one, = _run(tmp_path, "local", total, gens, -1, 29633)
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 512, 512, 1024) and int(r0["waves"]) == 1 and int(one["waves"]) == 1
+    # (a) identical stores on both ranks: every Q-function, and a probe batch through regression + selection + solve
+    _same(r0, r1)
+    assert int(r0["n_laps"]) == 4 + 4 * gens
+    # (b) ... and equal to the one-rank run over the same 2 x shard: the chosen laps (bit for bit), the global rollouts they came from, the
+    #     rows by which the stored laps were extended, the stores afterwards
+    _same(r0, one, skip=("lo", "hi") + tuple("gen%d_src" % i for i in range(gens)))
+    for it in range(gens):
+        assert np.all(one["gen%d_src" % it] == 0)
+        assert np.array_equal(r0["gen%d_src" % it], (r0["gen%d_global" % it] >= 512).astype(int))
+        assert np.all(np.diff(r0["gen%d_len" % it]) >= 0)
+    assert any(r0["gen%d_src" % it].any() for it in range(gens)), "no chosen lap ever came from rank 1: the test would not see a broken exchange"
+    # generation g >= 1 extends the K laps stored by generation g - 1 (laps 4 g .. 4 g + 3) by `ext` rows each, nothing else
+    for it in range(1, gens):
+        e = r0["gen%d_ext_rows" % it]
+        assert list(e[4 * it:4 * it + 4]) == [40] * 4 and not e[:4 * it].any()
+    print("laps per generation:", [list(r0["gen%d_len" % it]) for it in range(gens)], "source ranks:", [list(r0["gen%d_src" % it]) for it in range(gens)])
+
+
+def test_owner_rank_supplies_extensions_and_flagged_rollout_is_skipped_everywhere(built, tmp_path):
+    """Six rollouts, K = 4: rank 0 owns global rollouts 0-2, rank 1 owns 3-5, so the rows that extend stored lap 3 exist on rank 1 only.
+    Generation 1: all four extensions applied on both ranks (row 3 can only have come from rank 1).  Generation 2: the rollout that continues
+    lap 3 is flagged (started off the track) -- lap 3 is not extended on EITHER rank, the other three are."""
+    total, gens = 6, 3
+    r0, r1 = _run(tmp_path, "gloo", total, gens, 2, 29635)
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 3, 3, 6)
+    _same(r0, r1)
+    assert list(r0["gen1_ext_rows"][4:8]) == [40] * 4 and r0["gen1_skipped"].size == 0        # (c) lap 7 = parent 3, extended from rank 1's rollout 3
+    assert list(r0["gen2_skipped"]) == [3] and (int(r0["gen2_skipped_bits"][0]) & ~64) != 0   # (d)
+    assert list(r0["gen2_ext_rows"][8:12]) == [40, 40, 40, 0]
+    one, = _run(tmp_path, "local", total, gens, 2, 29637)
+    _same(r0, one, skip=("lo", "hi") + tuple("gen%d_src" % i for i in range(gens)))

@@ -99,6 +99,13 @@ def test_full_step_matches_reference_path(g):
     assert res["max_err_xu"] < common.TOL_XU
 
 
+def test_full_step_device_entry_without_diagnostics(g):
+    """The same replay with every fifth recorded step also taken through lmpc_step_batch_dev the way bench.py's timed loop calls it
+    (diagnostics=False: mu, resid, qSel NULL): bit-identical outputs."""
+    res = common.run_golden_step_check(dev_every=6)
+    assert res["n_dev"] >= 70 and np.all(res["status"] == 0) and res["max_err_xu"] < common.TOL_XU
+
+
 @pytest.mark.parametrize("name", ["lmpc_wide_n12", "lmpc_n14", "lmpc_n40"])
 def test_other_configurations_match_reference(built, name):
     """Steps recorded from the EXECUTED reference in two more configurations (tests/golden/make_wide_golden.py): numSS_it = 6, numSS_Points = 72
@@ -151,15 +158,18 @@ def test_other_configurations_match_reference(built, name):
     ctx.close()
 
 
-def test_30_lap_stores_match_reference(built):
-    """BASELINE configs[2] pinned by the executed reference (lmpc_30laps_n12.npz): 30 laps of different lengths handed to both stores in the
+@pytest.mark.parametrize("name", ["lmpc_30laps_n12", "lmpc_30laps_stress_n12"])
+def test_30_lap_stores_match_reference(built, name):
+    """(lmpc_30laps_stress_n12: SURVEY 8(d)'s stress variant, numSS_it = trToUse = 30 and numSS_Points = 360 on the same laps -- a wave of the
+    regression kernel scans four laps in turn, the terminal block carries six columns per lane.)
+    BASELINE configs[2] pinned by the executed reference (lmpc_30laps_n12.npz): 30 laps of different lengths handed to both stores in the
     reference's order -- the library's sorted insert (regression over the first four) and its choice of the four fastest laps for the safe set
     must reproduce the reference's A, B, C (tolerance), selection (bit-exact), QP matrices (bit-exact) and the certified optimum."""
     from racinglmpc_amd import _capi
-    g = dict(np.load(common.GOLDEN + "/lmpc_30laps_n12.npz"))
+    g = common.load_30laps_golden(name)
     gl = common.load_lmpc_golden()
-    N = int(g["N"]); nl = int(g["nLaps"]); S = 48
-    cfg, par = common.lmpc_config(gl, N, max_batch=16, max_laps=40, max_lap_len=1024)
+    N = int(g["N"]); nl = int(g["nLaps"]); S = int(g["numSS_Points"])
+    cfg, par = common.lmpc_config(gl, N, max_batch=16, max_laps=40, max_lap_len=1024, numSS_it=int(g["numSS_it"]), trToUse=int(g["trToUse"]))
     ctx = _capi.Context(cfg)
     for i in range(nl):
         ctx.model_add_trajectory(g["lapx%d" % i], g["lapu%d" % i]); ctx.ss_add_trajectory(g["lapx%d" % i], g["lapu%d" % i])
@@ -320,7 +330,7 @@ def test_more_status_flags(g):
     assert out["status"][0] & _flag("ST_NOT_INTERIOR")
     ctx.close()
     # unsupported configuration fails loudly at creation, with a message
-    cfg, par = common.lmpc_config(g, 12, max_batch=4, numSS_it=4, numSS_Points=252)      # beyond LMPC_MAX_SS_POINTS
+    cfg, par = common.lmpc_config(g, 12, max_batch=4, numSS_it=4, numSS_Points=388)      # beyond LMPC_MAX_SS_POINTS (and more than 63 points per lap)
     with pytest.raises(_capi.LmpcError, match="argument check failed"):
         _capi.Context(cfg)
     # calls before any lap is stored

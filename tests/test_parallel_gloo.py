@@ -151,3 +151,27 @@ def test_rendezvous_rejects_a_stale_id_file(tmp_path, monkeypatch):
         parallel._rendezvous_id(0, 2, "127.0.0.1", 70000, lambda: bytes(128))
     monkeypatch.setenv("MASTER_PORT", "65500"); monkeypatch.delenv("LMPC_RDZV_PORT", raising=False)
     assert 0 < parallel.env_world()[4] < 65536
+
+
+def test_host_wait_ignores_a_dead_writers_event(tmp_path, monkeypatch):
+    """The host-side event the idle ranks sleep on (bench.py: rank 0 runs its extra configurations alone) carries its writer's pid: an event file
+    left behind by a killed launch with the same parent, port and nonce does not release the waiters, and a signaller that died is an error, not
+    an hour of sleep."""
+    import threading
+    import time
+    from racinglmpc_amd import parallel
+    port = 29687
+    monkeypatch.setattr(os, "getppid", os.getpid)
+    path = parallel._rdzv_file(port) + ".extras"
+    dead = subprocess.Popen([sys.executable, "-c", "pass"]); dead.wait()
+    with open(path, "wb") as f:
+        f.write(int(dead.pid).to_bytes(8, "little"))
+    with pytest.raises(TimeoutError):
+        parallel.host_wait("extras", port, timeout=0.5)
+    assert not os.path.exists(path)                                  # the stale event was removed
+    with pytest.raises(RuntimeError):
+        parallel.host_wait("extras", port, timeout=30.0, writer_pid=dead.pid)
+    threading.Timer(0.3, lambda: parallel.host_signal("extras", port)).start()
+    t0 = time.time()
+    assert parallel.host_wait("extras", port, timeout=30.0) == path and time.time() - t0 < 5.0
+    os.remove(path)

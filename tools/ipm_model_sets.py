@@ -42,7 +42,7 @@ def build():
         sets[name] = recs
         print(name, len(recs), flush=True)
     flow = closed_loop.OracleFlow(g, 14, solver="osqp")
-    closed_loop.run_laps(flow, g, 40, seed=5, dump_from=12)
+    closed_loop.run_laps(flow, g, 40, seed=5, dump_from=12, noise="pcg")     # (the stream build_tmp/ipm_sets.npz was made with)
     d = flow.dump
     p14 = orc.QPParams.lmpc_default(14)
     keep = []

@@ -41,7 +41,7 @@ for i in range(1, n):
     key = (int(ids[i - 1]), int(ids[i]))
     acc.setdefault(key, []).append(int(cyc[i] - cyc[i - 1]))
 tot = int(cyc[n - 1] - cyc[0])
-iters = int(np.sum(ids == 11))
+iters = int(np.sum(ids == 11)) or int(np.sum(ids == 12))        # Newton iterations: stamp 11 in the one-wave kernel, stamp 12 (start of phase 2) in the multi-wave kernels
 print("total cycles %d, IPM iterations %d (%.0f cycles / iteration)" % (tot, iters, tot / max(iters, 1)))
 for key, v in acc.items():
     print("%-40s n=%3d mean %8.0f  total %9d  (%.1f%%)" % (names.get(key, str(key)), len(v), np.mean(v), np.sum(v), 100.0 * np.sum(v) / tot))
