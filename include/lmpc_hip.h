@@ -110,6 +110,8 @@ int lmpc_ss_set_selected(lmpc_ctx *, const int *laps, int n);
         /* override of argsort(LapTime)[0:numSS_it] (:395,402); n = 0 restores the built-in stable sort */
 int lmpc_ss_num_laps(lmpc_ctx *, int *n);
 int lmpc_ss_get_qfun(lmpc_ctx *, int lap, double *qfun /*T*/, int *T);
+int lmpc_ss_get_laptime(lmpc_ctx *, int lap, int *T);
+        /* LMPC.LapTime[lap] (:420): rows of the lap when it was added (without addPoint extensions) -- what argsort(LapTime) sorts */
 
 /* ---- batched compute, host buffers --------------------------------------------------------- */
 int lmpc_regress_batch(lmpc_ctx *, int B, const double *xLin /*B x N x 6 (first N rows used)*/, int xLinRowStride /* (N+1)*6 or N*6 */,

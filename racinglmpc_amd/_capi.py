@@ -46,7 +46,7 @@ class StepDevArgs(C.Structure):
 EXPORTS = [
     "lmpc_config_default", "lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_version",
     "lmpc_model_add_trajectory", "lmpc_model_num_laps", "lmpc_model_replace_lap",
-    "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun",
+    "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun", "lmpc_ss_get_laptime",
     "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
     "lmpc_lti_regression", "lmpc_comm_unique_id", "lmpc_comm_init", "lmpc_comm_destroy", "lmpc_comm_info", "lmpc_comm_allgather_dev", "lmpc_comm_allgather",
@@ -72,6 +72,8 @@ def load():
         for name in EXPORTS:
             getattr(lib, name)          # raises AttributeError if a declared symbol is missing
         lib.lmpc_last_error.restype = C.c_char_p
+        # (declared argument types let the hot call take plain integers as addresses: no c_void_p object per array)
+        lib.lmpc_step_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 24
         _lib = lib
     return _lib
 
@@ -140,6 +142,7 @@ class Context:
         self.N = cfg.N
         self.S = cfg.numSS_points if cfg.numSS_it > 0 else 0
         self.M = 8 * self.N + self.S
+        self._step_plan = {}
         self._h = C.c_void_p()
         rc = self.lib.lmpc_create(C.byref(cfg), C.byref(self._h))
         if rc == E_VARIANT:             # (N, numSS_points) outside the built-in set: compile its shared object once (hipcc, ~20 s), then retry
@@ -231,16 +234,27 @@ class Context:
         xpp = None if xPredPrev is None else _f64(xPredPrev)
         hp = None if hasPred is None else _i32(hasPred)
         ts = None if timeStep is None else _i32(timeStep)
-        out = dict(xPred=np.zeros((B, N + 1, 6)), uPred=np.zeros((B, N, 2)), slack=np.zeros((B, 2 * N)), lambd=np.zeros((B, S)),
-                   sTerm=np.zeros((B, 6)), ztNext=np.zeros((B, 6)), ztuNext=np.zeros((B, 2)), ssSel=np.zeros((B, S, 6)),
-                   qSel=np.zeros((B, S)), mu=np.zeros((B, self.M)),
-                   A=np.zeros((B, N, 6, 6)), B=np.zeros((B, N, 6, 2)), C=np.zeros((B, N, 6)),
-                   status=np.zeros(B, np.int32), iters=np.zeros(B, np.int32), resid=np.zeros((B, 3)))
-        _chk(self.lib.lmpc_step_batch(self._h, C.c_int(B), _d(x0), _d(xLin), _d(uLin), _d(uOld), _d(ztc), _d(xpp), _d(hp), _d(ts),
-                                      _d(out["xPred"]), _d(out["uPred"]), _d(out["slack"]), _d(out["lambd"]), _d(out["sTerm"]),
-                                      _d(out["ztNext"]), _d(out["ztuNext"]), _d(out["ssSel"]), _d(out["qSel"]), _d(out["mu"]),
-                                      _d(out["A"]), _d(out["B"]), _d(out["C"]),
-                                      _d(out["status"]), _d(out["iters"]), _d(out["resid"])))
+        # the sixteen outputs are ranges of ONE fresh float64 buffer and one int32 buffer (a drop-in LMPC.solve spends more time in sixteen
+        # allocations and twenty-six address look-ups than the library spends outside its two kernels): addresses are base + offset
+        plan = self._step_plan.get(B)
+        if plan is None:
+            shapes = (("xPred", (B, N + 1, 6)), ("uPred", (B, N, 2)), ("slack", (B, 2 * N)), ("lambd", (B, S)), ("sTerm", (B, 6)), ("ztNext", (B, 6)),
+                      ("ztuNext", (B, 2)), ("ssSel", (B, S, 6)), ("qSel", (B, S)), ("mu", (B, self.M)), ("A", (B, N, 6, 6)), ("B", (B, N, 6, 2)),
+                      ("C", (B, N, 6)), ("resid", (B, 3)))
+            offs, o = [], 0
+            for k, shp in shapes:
+                n = int(np.prod(shp)); offs.append((k, shp, o, n)); o += n
+            plan = self._step_plan[B] = (offs, o)
+        offs, total = plan
+        buf = np.zeros(total); ibuf = np.zeros(2 * B, np.int32)
+        base = buf.ctypes.data; ibase = ibuf.ctypes.data
+        out = {k: buf[o:o + n].reshape(shp) for k, shp, o, n in offs}
+        out["status"] = ibuf[:B]; out["iters"] = ibuf[B:]
+        adr = {k: base + 8 * o for k, shp, o, n in offs}
+        pa = lambda a: None if a is None else a.ctypes.data
+        _chk(self.lib.lmpc_step_batch(self._h, B, pa(x0), pa(xLin), pa(uLin), pa(uOld), pa(ztc), pa(xpp), pa(hp), pa(ts),
+                                      adr["xPred"], adr["uPred"], adr["slack"], adr["lambd"], adr["sTerm"], adr["ztNext"], adr["ztuNext"], adr["ssSel"], adr["qSel"], adr["mu"],
+                                      adr["A"], adr["B"], adr["C"], ibase, ibase + 4 * B, adr["resid"]))
         return out
 
     def qp_dims(self):
@@ -373,6 +387,12 @@ class Context:
         n = C.c_int()
         _chk(self.lib.lmpc_ss_num_laps(self._h, C.byref(n)))
         return n.value
+
+    def ss_lap_time(self, lap):
+        """LMPC.LapTime[lap]: rows of the stored lap when it was added (addPoint extensions not counted)."""
+        T = C.c_int()
+        _chk(self.lib.lmpc_ss_get_laptime(self._h, C.c_int(int(lap)), C.byref(T)))
+        return T.value
 
     def ss_lap_rows(self, lap):
         T = C.c_int()

@@ -18,18 +18,27 @@ def _current():
     return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
 
 
-def build_flavour(suffix, defines, verbose=False):
+ASAN_FLAGS = ["-g", "-fno-omit-frame-pointer", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan"]      # host code under AddressSanitizer, device code as it is
+ASAN_RUNTIME = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"                     # LD_PRELOAD for python (tools/asan_run.sh)
+
+
+def build_flavour(suffix, defines, verbose=False, extra=()):
     """Developer builds next to the product library (e.g. the -DLMPC_TIMING flavour of tools/phase_timing.py): liblmpc_hip_<suffix>.so."""
     out = os.path.join(_HERE, "liblmpc_hip_%s.so" % suffix)
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-unused-value", "-fPIC", "-shared"] + \
-          ["-D" + d for d in defines] + ["-o", out, SRC, "-L/opt/rocm/lib", "-lrccl"]
+          list(extra) + ["-D" + d for d in defines] + ["-o", out, SRC, "-L/opt/rocm/lib", "-lrccl"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
     return out
+
+
+def build_asan():
+    """The memory-safety flavour: liblmpc_hip_asan.so -- host side under AddressSanitizer, guard zones behind every device buffer (-DLMPC_GUARD)."""
+    return build_flavour("asan", ["LMPC_GUARD"], extra=ASAN_FLAGS)
 
 
 def build(force=False, verbose=False):

@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -16,6 +17,44 @@ static thread_local std::string g_err;
 static int set_err(int code, const char *what, const char *detail) { g_err = std::string(what) + ": " + (detail ? detail : ""); return code; }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(LMPC_E_HIP, #call, hipGetErrorString(e_)); } while (0)
 #define ARGCHK(cond) do { if (!(cond)) return set_err(LMPC_E_ARG, "argument check failed", #cond); } while (0)
+
+// ---- device allocations of a context.  Builds with -DLMPC_GUARD (the "asan" developer flavour, racinglmpc_amd.build: host code under AddressSanitizer) put a
+// 256-byte guard zone filled with 0xA5 behind every allocation -- and between the work-buffer ranges of the two slabs -- and check it when the buffer is
+// freed (lmpc_destroy, store growth, end of a rollout session): a kernel that wrote past a buffer's end is reported on stderr and counted
+// (lmpc_debug_guard_failures).  Ordinary builds: plain hipMalloc / hipFree.
+#define LMPC_GUARD_BYTES 256
+static int g_guard_failures = 0;
+#ifdef LMPC_GUARD
+#include <map>
+#include <mutex>
+static std::map<void *, size_t> g_guarded; static std::mutex g_guard_mu;
+static int check_guard_zone(const void *zone, const char *what) {
+    unsigned char h[LMPC_GUARD_BYTES];
+    if (hipMemcpy(h, zone, LMPC_GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    for (int i = 0; i < LMPC_GUARD_BYTES; i++) if (h[i] != 0xA5) {
+        fprintf(stderr, "liblmpc_hip GUARD: %s: byte %d behind the buffer was overwritten (0x%02x)\n", what, i, h[i]); g_guard_failures++; return 1; }
+    return 0;
+}
+static hipError_t g_malloc_raw(void **p, size_t bytes) {
+    const size_t padded = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(p, padded + LMPC_GUARD_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipMemset((char *)*p + padded, 0xA5, LMPC_GUARD_BYTES);
+    std::lock_guard<std::mutex> lk(g_guard_mu); g_guarded[*p] = padded;
+    return e;
+}
+static hipError_t g_free(void *p) {
+    if (!p) return hipSuccess;
+    size_t padded = 0; bool known = false;
+    { std::lock_guard<std::mutex> lk(g_guard_mu); auto it = g_guarded.find(p); if (it != g_guarded.end()) { padded = it->second; known = true; g_guarded.erase(it); } }
+    if (known) { (void)hipDeviceSynchronize(); check_guard_zone((char *)p + padded, "device buffer"); }
+    return hipFree(p);
+}
+#else
+static hipError_t g_malloc_raw(void **p, size_t bytes) { return hipMalloc(p, bytes); }
+static hipError_t g_free(void *p) { return p ? hipFree(p) : hipSuccess; }
+#endif
+template <class T> static hipError_t g_malloc(T **p, size_t bytes) { return g_malloc_raw((void **)p, bytes); }
 
 struct evpair { hipEvent_t a, b; int kind; };
 
@@ -51,6 +90,8 @@ struct lmpc_ctx {
     size_t ab_pack_cap;                      // problems ab_pack holds
     int *w_selStart;                         // lmpc_select_batch: window starts, max_batch x numSS_it
     void *scr_dev; size_t scr_bytes;         // pooled scratch of the small host-buffer entry points (plant step, global position)
+    std::vector<char *> gaps;                // guard builds: the 256-byte zones between the work-buffer ranges of the slabs
+    double tr_s[4]; long long tr_n;          // developer trace of lmpc_step_batch's one-QP path (lmpc_debug_step_trace): seconds spent staging / launching / waiting / unstaging
     struct lmpc_rollout_session *ro;
     void *comm; int comm_rank, comm_world;   // RCCL communicator of this rank (lmpc_comm.hip.h); null = single process
     double *ext_rows; size_t ext_rows_bytes;   // staging buffer of lmpc_ss_extend_lap
@@ -187,17 +228,17 @@ static int create_body(lmpc_ctx *c) {
         const char *e = getenv("LMPC_CD"); c->cd_mode = e ? atoi(e) : 0;
     }
     HIPCHK(hipStreamCreate(&c->stream));
-    if (c->var.lds_1w_abg > 0 && !getenv("LMPC_NO_ABG")) { HIPCHK(hipMalloc(&c->ab_pack, sizeof(double) * 48 * (size_t)cfg->N * (size_t)cfg->max_batch)); c->ab_pack_cap = (size_t)cfg->max_batch; }
+    if (c->var.lds_1w_abg > 0 && !getenv("LMPC_NO_ABG")) { HIPCHK(g_malloc(&c->ab_pack, sizeof(double) * 48 * (size_t)cfg->N * (size_t)cfg->max_batch)); c->ab_pack_cap = (size_t)cfg->max_batch; }
     HIPCHK(hipHostMalloc(&c->h_retry, sizeof(int) * LMPC_RETRY_RING, hipHostMallocMapped));
     memset(c->h_retry, 0, sizeof(int) * LMPC_RETRY_RING);
     HIPCHK(hipHostGetDevicePointer((void **)&c->d_retry, c->h_retry, 0));
     const size_t store_elems = (size_t)cfg->max_laps * LMPC_COLS * cfg->max_lap_len;
-    HIPCHK(hipMalloc(&c->mstore, store_elems * sizeof(double)));
-    HIPCHK(hipMalloc(&c->sstore, store_elems * sizeof(double)));
+    HIPCHK(g_malloc(&c->mstore, store_elems * sizeof(double)));
+    HIPCHK(g_malloc(&c->sstore, store_elems * sizeof(double)));
     HIPCHK(hipMemset(c->mstore, 0, store_elems * sizeof(double)));
     c->mq_chunks = (cfg->max_lap_len + K1_CHUNK - 1) / K1_CHUNK;
-    HIPCHK(hipMalloc(&c->mquant, (size_t)cfg->max_laps * 3 * cfg->max_lap_len * sizeof(unsigned)));
-    HIPCHK(hipMalloc(&c->mqpar, (size_t)cfg->max_laps * c->mq_chunks * 6 * sizeof(double)));
+    HIPCHK(g_malloc(&c->mquant, (size_t)cfg->max_laps * 3 * cfg->max_lap_len * sizeof(unsigned)));
+    HIPCHK(g_malloc(&c->mqpar, (size_t)cfg->max_laps * c->mq_chunks * 6 * sizeof(double)));
     HIPCHK(hipMemset(c->mquant, 0, (size_t)cfg->max_laps * 3 * cfg->max_lap_len * sizeof(unsigned)));
     HIPCHK(hipMemset(c->mqpar, 0, (size_t)cfg->max_laps * c->mq_chunks * 6 * sizeof(double)));
     HIPCHK(hipMemset(c->sstore, 0, store_elems * sizeof(double)));
@@ -205,8 +246,13 @@ static int create_body(lmpc_ctx *c) {
     // two passes over the same list: sizes first, then pointers into the slabs (every range 256-byte aligned)
     for (int pass = 0; pass < 2; pass++) {
         size_t oi = 0, oo = 0;
+#ifdef LMPC_GUARD      // (guard builds: a 256-byte zone behind every work-buffer range, see check_slab_gaps)
+#define SLAB_GAP(slab, off) do { if (pass) c->gaps.push_back(c->slab + off); off += LMPC_GUARD_BYTES; } while (0)
+#else
+#define SLAB_GAP(slab, off) do { } while (0)
+#endif
 #define SLAB(ptr, n, slab, off) do { const size_t bytes_ = (std::max<size_t>((n), 1) * sizeof(*c->ptr) + 255) & ~(size_t)255; \
-                                     if (pass) c->ptr = (decltype(c->ptr))(c->slab + off); off += bytes_; } while (0)
+                                     if (pass) c->ptr = (decltype(c->ptr))(c->slab + off); off += bytes_; SLAB_GAP(slab, off); } while (0)
         SLAB(w_x0, B * 6, slab_in, oi); SLAB(w_xLin, B * (N + 1) * 6, slab_in, oi); SLAB(w_uLin, B * N * 2, slab_in, oi); SLAB(w_uOld, B * 2, slab_in, oi);
         SLAB(w_zt, B * 6, slab_in, oi); SLAB(w_xPP, B * (N + 1) * 6, slab_in, oi); SLAB(w_hasPred, B, slab_in, oi); SLAB(w_tstep, B, slab_in, oi);
         SLAB(w_xPred, B * (N + 1) * 6, slab_out, oo); SLAB(w_uPred, B * N * 2, slab_out, oo); SLAB(w_slack, B * N * 2, slab_out, oo); SLAB(w_lam, B * S, slab_out, oo);
@@ -216,9 +262,11 @@ static int create_body(lmpc_ctx *c) {
         SLAB(w_succ, B * S * 6, slab_out, oo); SLAB(w_succU, B * S * 2, slab_out, oo); SLAB(w_ztUsed, B * 6, slab_out, oo); SLAB(w_rstatus, B * N, slab_out, oo);
         SLAB(w_selStart, B * (size_t)std::max(cfg->numSS_it, 1), slab_out, oo);
 #undef SLAB
+#undef SLAB_GAP
+        if (pass) { for (char *g_ : c->gaps) HIPCHK(hipMemset(g_, 0xA5, LMPC_GUARD_BYTES)); }
         if (!pass) {
             c->slab_in_bytes = oi; c->slab_out_bytes = oo;
-            HIPCHK(hipMalloc(&c->slab_in, oi)); HIPCHK(hipMalloc(&c->slab_out, oo));
+            HIPCHK(g_malloc(&c->slab_in, oi)); HIPCHK(g_malloc(&c->slab_out, oo));
             HIPCHK(hipMemset(c->slab_in, 0, oi)); HIPCHK(hipMemset(c->slab_out, 0, oo));
             if (oo <= LMPC_SLAB_COPY_MAX) {
                 HIPCHK(hipHostMalloc(&c->h_in, oi, hipHostMallocMapped)); HIPCHK(hipHostMalloc(&c->h_out, oo, hipHostMallocMapped)); memset(c->h_in, 0, oi); memset(c->h_out, 0, oo);
@@ -255,19 +303,29 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
 }
 
 static void rollout_free(lmpc_ctx *c);
+static void check_slab_gaps(lmpc_ctx *c) {
+#ifdef LMPC_GUARD
+    (void)hipDeviceSynchronize();
+    for (char *g_ : c->gaps) check_guard_zone(g_, "work-buffer range of a slab");
+#else
+    (void)c;
+#endif
+}
+int lmpc_debug_guard_failures(void) { return g_guard_failures; }      /* guard builds (-DLMPC_GUARD): overruns found so far; 0 in ordinary builds */
 int lmpc_destroy(lmpc_ctx *c) {
     if (!c) return LMPC_OK;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rollout_free(c);
     if (c->comm) { (void)ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
-    if (c->ext_rows) (void)hipFree(c->ext_rows);
-    if (c->scr_dev) (void)hipFree(c->scr_dev);
-    if (c->comm_scr) (void)hipFree(c->comm_scr);
+    if (c->ext_rows) (void)g_free(c->ext_rows);
+    if (c->scr_dev) (void)g_free(c->scr_dev);
+    if (c->comm_scr) (void)g_free(c->comm_scr);
     if (c->comm_scr_h) (void)hipHostFree(c->comm_scr_h);
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     void *ptrs[] = {c->mstore, c->sstore, c->mquant, c->mqpar, c->slab_in, c->slab_out, c->ab_pack};      // (the w_* work buffers are ranges of the two slabs)
-    for (void *q : ptrs) if (q) (void)hipFree(q);
+    check_slab_gaps(c);
+    for (void *q : ptrs) if (q) (void)g_free(q);
     if (c->h_retry) (void)hipHostFree(c->h_retry);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_out) (void)hipHostFree(c->h_out);
@@ -300,10 +358,10 @@ static int grow_stores(lmpc_ctx *c, int need_laps, int need_len) {
     const int old_chunks = c->mq_chunks, new_chunks = (new_len + K1_CHUNK - 1) / K1_CHUNK;
     const size_t elems = (size_t)new_laps * LMPC_COLS * new_len;
     double *nm = nullptr, *ns = nullptr, *np_ = nullptr; unsigned *nq = nullptr;
-    auto fail = [&](int rc) { if (nm) (void)hipFree(nm); if (ns) (void)hipFree(ns); if (nq) (void)hipFree(nq); if (np_) (void)hipFree(np_); return rc; };
+    auto fail = [&](int rc) { if (nm) (void)g_free(nm); if (ns) (void)g_free(ns); if (nq) (void)g_free(nq); if (np_) (void)g_free(np_); return rc; };
 #define GROWCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(set_err(LMPC_E_HIP, #call, hipGetErrorString(e_))); } while (0)
-    GROWCHK(hipMalloc(&nm, elems * sizeof(double))); GROWCHK(hipMalloc(&ns, elems * sizeof(double)));
-    GROWCHK(hipMalloc(&nq, (size_t)new_laps * 3 * new_len * sizeof(unsigned))); GROWCHK(hipMalloc(&np_, (size_t)new_laps * new_chunks * 6 * sizeof(double)));
+    GROWCHK(g_malloc(&nm, elems * sizeof(double))); GROWCHK(g_malloc(&ns, elems * sizeof(double)));
+    GROWCHK(g_malloc(&nq, (size_t)new_laps * 3 * new_len * sizeof(unsigned))); GROWCHK(g_malloc(&np_, (size_t)new_laps * new_chunks * 6 * sizeof(double)));
     GROWCHK(hipMemset(nm, 0, elems * sizeof(double))); GROWCHK(hipMemset(ns, 0, elems * sizeof(double)));
     GROWCHK(hipMemset(nq, 0, (size_t)new_laps * 3 * new_len * sizeof(unsigned))); GROWCHK(hipMemset(np_, 0, (size_t)new_laps * new_chunks * 6 * sizeof(double)));
     const size_t nml = c->m_len.size(), nsl = c->s_len.size();
@@ -314,7 +372,7 @@ static int grow_stores(lmpc_ctx *c, int need_laps, int need_len) {
     }
     if (nsl) GROWCHK(hipMemcpy2D(ns, (size_t)new_len * 8, c->sstore, (size_t)old_len * 8, (size_t)old_len * 8, nsl * LMPC_COLS, hipMemcpyDeviceToDevice));
 #undef GROWCHK
-    (void)hipFree(c->mstore); (void)hipFree(c->sstore); (void)hipFree(c->mquant); (void)hipFree(c->mqpar);
+    (void)g_free(c->mstore); (void)g_free(c->sstore); (void)g_free(c->mquant); (void)g_free(c->mqpar);
     c->mstore = nm; c->sstore = ns; c->mquant = nq; c->mqpar = np_; c->mq_chunks = new_chunks;
     c->cfg.max_laps = new_laps; c->cfg.max_lap_len = new_len;
     const lmpc_dev_params keep = c->dp;
@@ -456,6 +514,8 @@ int lmpc_ss_get_qfun(lmpc_ctx *c, int lap, double *qfun, int *T) {
     return LMPC_OK;
 }
 
+int lmpc_ss_get_laptime(lmpc_ctx *c, int lap, int *T) { ARGCHK(c && T && lap >= 0 && lap < (int)c->s_laptime.size()); *T = c->s_laptime[lap]; return LMPC_OK; }
+
 // refresh the per-launch part of the device parameter block
 static int refresh_params(lmpc_ctx *c, bool need_model, bool need_ss) {
     lmpc_dev_params &p = c->dp;
@@ -549,8 +609,8 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io_in, bool imm
         if ((size_t)B > c->ab_pack_cap) {                   // rollout sessions may run more problems than max_batch: the scratch follows
             int rc = resolve_retries(c); if (rc) return rc;
             HIPCHK(hipStreamSynchronize(c->stream));
-            (void)hipFree(c->ab_pack); c->ab_pack = nullptr; c->ab_pack_cap = 0;
-            HIPCHK(hipMalloc(&c->ab_pack, sizeof(double) * 48 * (size_t)c->cfg.N * (size_t)B)); c->ab_pack_cap = (size_t)B;
+            (void)g_free(c->ab_pack); c->ab_pack = nullptr; c->ab_pack_cap = 0;
+            HIPCHK(g_malloc(&c->ab_pack, sizeof(double) * 48 * (size_t)c->cfg.N * (size_t)B)); c->ab_pack_cap = (size_t)B;
         }
         io.abPack = c->ab_pack;
     }
@@ -693,6 +753,7 @@ int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, co
     if (term) ARGCHK(zt != nullptr);
     HIPCHK(hipSetDevice(c->cfg.device));
     const bool one_copy = c->h_in && B == c->cfg.max_batch;          // small contexts (the drop-in classes: max_batch = 1): one copy each way
+    const auto tr0 = std::chrono::steady_clock::now();
     if (one_copy) {
 #define STAGE(wptr, src, n) memcpy(c->h_in + ((char *)c->wptr - c->slab_in), src, sizeof(*c->wptr) * (size_t)(n))
         STAGE(w_x0, x0, (size_t)B * 6); STAGE(w_xLin, xLin, (size_t)B * (N + 1) * 6); STAGE(w_uLin, uLin, (size_t)B * N * 2); STAGE(w_uOld, uOld, (size_t)B * 2);
@@ -732,8 +793,11 @@ int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, co
 #undef MAP_IN
 #undef MAP_OUT
     }
+    const auto tr1 = std::chrono::steady_clock::now();
     int rc = lmpc_step_batch_dev(c, B, &a); if (rc) return rc;
+    const auto tr2 = std::chrono::steady_clock::now();
     rc = resolve_retries(c); if (rc) return rc;          // drains the stream; a flagged problem gets its retry pass before anything is copied out
+    const auto tr3 = std::chrono::steady_clock::now();
     if (one_copy) {
         if (!zero_copy) {
             // everything up to (not including) the selection-only buffers w_succ ..: one copy into the pinned mirror, then plain memcpys
@@ -750,6 +814,9 @@ int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, co
 #undef UNSTAGE
         const int *it_ = (const int *)(c->h_out + ((char *)c->w_iters - c->slab_out));
         for (int b = 0; b < B; b++) c->stats.ipm_iters += it_[b];
+        const auto tr4 = std::chrono::steady_clock::now();
+        c->tr_s[0] += std::chrono::duration<double>(tr1 - tr0).count(); c->tr_s[1] += std::chrono::duration<double>(tr2 - tr1).count();
+        c->tr_s[2] += std::chrono::duration<double>(tr3 - tr2).count(); c->tr_s[3] += std::chrono::duration<double>(tr4 - tr3).count(); c->tr_n++;
         return LMPC_OK;
     }
     D2H(xPred, c->w_xPred, (size_t)B * (N + 1) * 6); D2H(uPred, c->w_uPred, (size_t)B * N * 2); D2H(slack, c->w_slack, (size_t)B * N * 2);
@@ -800,6 +867,10 @@ int lmpc_dev_upload(lmpc_ctx *c, void *dptr, const void *host, long long bytes) 
 int lmpc_dev_download(lmpc_ctx *c, void *host, const void *dptr, long long bytes) { ARGCHK(c && dptr && host); HIPCHK(hipSetDevice(c->cfg.device)); { int rc = resolve_retries(c); if (rc) return rc; } HIPCHK(hipMemcpyAsync(host, dptr, (size_t)bytes, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
 int lmpc_dev_sync(lmpc_ctx *c) { ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); { int rc = resolve_retries(c); if (rc) return rc; } HIPCHK(hipStreamSynchronize(c->stream)); return LMPC_OK; }
 
+// developer trace: host-side seconds of the one-QP path of lmpc_step_batch since the context was made -- out[0..3] = staging the inputs, launching the
+// two kernels, waiting for the stream, reading the outputs back; out[4] = calls (tools/dropin_time.py)
+int lmpc_debug_step_trace(lmpc_ctx *c, double *out5) { ARGCHK(c && out5); for (int i = 0; i < 4; i++) out5[i] = c->tr_s[i]; out5[4] = (double)c->tr_n; return LMPC_OK; }
+
 // timing build only: one solve of problem 0 of a host batch with cycle stamps (tools/phase_timing.py)
 int lmpc_debug_timing(lmpc_ctx *c, const double *A, const double *Bm, const double *C, const double *x0, const double *uOld,
                       const double *ssSel, const double *qSel, long long *tbuf_host, int nt) {
@@ -842,9 +913,9 @@ int lmpc_debug_k1_timing(lmpc_ctx *c, int B, const double *xLin, const double *u
 static int pooled_scratch(lmpc_ctx *c, size_t bytes, void **out) {
     if (bytes > c->scr_bytes) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->scr_dev) { (void)hipFree(c->scr_dev); c->scr_dev = nullptr; c->scr_bytes = 0; }
+        if (c->scr_dev) { (void)g_free(c->scr_dev); c->scr_dev = nullptr; c->scr_bytes = 0; }
         const size_t want = std::max<size_t>((bytes + 4095) & ~(size_t)4095, (size_t)64 * 1024);
-        HIPCHK(hipMalloc(&c->scr_dev, want)); c->scr_bytes = want;
+        HIPCHK(g_malloc(&c->scr_dev, want)); c->scr_bytes = want;
     }
     *out = c->scr_dev;
     return LMPC_OK;
@@ -889,7 +960,7 @@ struct lmpc_rollout_session {
 
 static void rollout_free(lmpc_ctx *c) {
     if (!c->ro) return;
-    for (void *q : c->ro->keep) (void)hipFree(q);
+    for (void *q : c->ro->keep) (void)g_free(q);
     if (c->ro->pstream) { (void)hipStreamDestroy(c->ro->pstream); (void)hipEventDestroy(c->ro->e_solved); (void)hipEventDestroy(c->ro->e_plant); }
     delete c->ro; c->ro = nullptr;
 }
@@ -904,7 +975,7 @@ int lmpc_rollout_begin(lmpc_ctx *c, int B, int T_max, const double *x0, const do
     HIPCHK(hipStreamCreate(&r->pstream)); HIPCHK(hipEventCreateWithFlags(&r->e_solved, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&r->e_plant, hipEventDisableTiming));
     const size_t N = c->cfg.N, S = c->cfg.numSS_points, Bz = B;
     bool ok = true;
-    auto dalloc = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) { ok = false; return nullptr; } r->keep.push_back(q); return q; };
+    auto dalloc = [&](size_t bytes) -> void * { void *q = nullptr; if (g_malloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) { ok = false; return nullptr; } r->keep.push_back(q); return q; };
 #define DA(type, name, n) r->name = (type *)dalloc(sizeof(type) * (size_t)(n));
     DA(double, d_x, Bz * 6) DA(double, d_xg, Bz * 6) DA(double, d_xLin, Bz * (N + 1) * 6) DA(double, d_uLin, Bz * N * 2) DA(double, d_uOld, Bz * 2)
     DA(double, d_zt, Bz * 6) DA(double, d_xPP, Bz * (N + 1) * 6) DA(int, d_hasPred, Bz) DA(int, d_tstep, Bz) DA(int, d_done, Bz) DA(int, d_nDone, 1) DA(int, d_stAcc, Bz)
@@ -1009,11 +1080,10 @@ int lmpc_ss_extend_lap(lmpc_ctx *c, int lap, const double *x, const double *u, i
         r[4] += c->cfg.trackLength; r[6] = u[(size_t)i * 2]; r[7] = u[(size_t)i * 2 + 1]; r[8] = q;
     }
     if (rows.size() * sizeof(double) > c->ext_rows_bytes) {       // staging buffer of the batched addPoint: grown once, kept
-        if (c->ext_rows) (void)hipFree(c->ext_rows);
-    if (c->scr_dev) (void)hipFree(c->scr_dev);
+        if (c->ext_rows) (void)g_free(c->ext_rows);
         c->ext_rows = nullptr; c->ext_rows_bytes = 0;
         const size_t want = std::max<size_t>(rows.size() * sizeof(double), (size_t)64 * LMPC_COLS * sizeof(double));
-        HIPCHK(hipMalloc(&c->ext_rows, want)); c->ext_rows_bytes = want;
+        HIPCHK(g_malloc(&c->ext_rows, want)); c->ext_rows_bytes = want;
     }
     double *d_rows = c->ext_rows;
     hipError_t e = hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);

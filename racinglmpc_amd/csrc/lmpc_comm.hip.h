@@ -37,10 +37,10 @@ static int comm_scratch(lmpc_ctx *c, size_t bytes) {
     size_t want = std::max<size_t>(bytes, (size_t)64 * 1024);
     want = (want + 4095) & ~(size_t)4095;
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->comm_scr) { (void)hipFree(c->comm_scr); c->comm_scr = nullptr; }
+    if (c->comm_scr) { (void)g_free(c->comm_scr); c->comm_scr = nullptr; }
     if (c->comm_scr_h) { (void)hipHostFree(c->comm_scr_h); c->comm_scr_h = nullptr; }
     c->comm_scr_bytes = 0;
-    HIPCHK(hipMalloc(&c->comm_scr, want)); HIPCHK(hipHostMalloc(&c->comm_scr_h, want));
+    HIPCHK(g_malloc(&c->comm_scr, want)); HIPCHK(hipHostMalloc(&c->comm_scr_h, want));
     c->comm_scr_bytes = want;
     return LMPC_OK;
 }

@@ -762,12 +762,15 @@ __device__ __forceinline__ ricc_consts ricc_setup(int lane, const double *Q2, co
 // (Publishing the stage through an LDS word that the followers poll, so that this wave never waits, was measured too: no difference.)
 // SPLIT (one-wave kernel): rows 0..5 of Phi_k go to 6 x 8 tiles in `Phi` (scratch, read back once into the sweep registers), rows 6, 7
 // (= -K_k, needed by every Newton solve) straight to their permanent place PhiK (2 x 8 per stage).
-template <int N, bool term, bool STEP = false, bool SPLIT = false>
+// dump: this lane's slot of >= 64 doubles of LDS nobody reads during the recursion -- the lanes that have nothing to store (60 of 64 for M_uu^-1) store
+// there, so that no stage carries an exec-mask region with its branch on the critical wave (see sweep_dst).
+template <int N, bool term, bool STEP = false, bool SPLIT = false, bool HASPI = true>
 __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *AB, const double *kap, const double *th, const double *Qf2,
-                                           const double *PiT, double *Phi, double *PiAll, double *Mi, double *PhiK = nullptr) {
+                                           const double *PiT, double *Phi, double *PiAll, double *Mi, double *PhiK, double *dump) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int qr = c.qr;
     int bad = 0;
+    double *const miDst = lane < 4 ? Mi + lane : dump; const int miStride = lane < 4 ? 4 : 0;           // M_uu^-1 of stage k: lanes 0..3 -> Mi[k * 4 + lane]
     double Piq = c.w_xx ? Qf2[c.qR * 6 + c.qC] + (term ? PiT[c.qR * 6 + c.qC] : 0.0) : 0.0;   // Pi_N = [[2Qf + Pi_term, 0], [0, 0]]
     // Stage operands are fetched one stage ahead.  The twelve LDS reads of stage k - 1 are ISSUED at the top of stage k (a compiler fence
     // pins them there) and their arithmetic -- the six-term sum that builds the stage Hessian W -- runs at the bottom, behind the chain of
@@ -832,8 +835,12 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
 #ifndef RICC_VAR_NOSTORE              // (tools/microbench_ricc.hip: what the LDS stores cost -- 90 cycles per stage)
         if constexpr (SPLIT) { double *d_ = c.qR < 6 ? Phi + k * 48 + c.qR * 8 + c.qC : PhiK + k * 16 + (c.qR - 6) * 8 + c.qC; *d_ = Phq; }
         else Phi[k * 64 + c.qR * 8 + c.qC] = Phq;
-        if (PiAll) PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
+        if constexpr (HASPI) PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
+#ifdef LMPC_EXP_NORICCDUMP
         if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 3 ? i11 : i01);
+#else
+        miDst[k * miStride] = lane == 0 ? i00 : (lane == 3 ? i11 : i01);
+#endif
 #else
         if (k == 0) { Phi[c.qR * 8 + c.qC] = Phq; if (lane < 4) Mi[lane] = i00 + i01 + i11; }
 #endif
@@ -935,6 +942,46 @@ __device__ __forceinline__ double sum_over_g(double v) {
     return v;
 }
 
+
+// Branch-free stores of the register sweeps.  A sweep stage ends with ONE row of 8 lanes holding the stage's 8 results (the lanes with lc == 0 in a
+// "sum over c" stage, those with lg == 0 in a "sum over g" stage).  Written as `if (writer) { if (idx < 6) dx[..] = v; else du[..] = v; }` that is two
+// nested exec-mask regions with their branches and spilled-mask reloads per stage, ON the dependent chain of the sweep (~60 of ~200 cycles per stage).
+// Instead every lane stores unconditionally: the writers to their element, the others to a per-lane slot of `dump` -- LDS that is dead during the
+// sweep (the array the sweep's own per-stage operands were just read from).  destination(k) = p + k * s, for even / odd stages.
+typedef __attribute__((address_space(3))) double lds_f64;    // explicit LDS pointers: 32-bit, ds_write whatever the optimiser can or cannot infer
+struct sweep_dst { double *wE, *wO; int dE, dO; };          // destination of the NEXT even / odd stage and its (signed) advance per use, in doubles
+// (the pointers are advanced stage by stage and pinned with an empty asm: computed as base + k * stride the compiler forms all N addresses ahead of the
+//  unrolled loop -- 2 N live registers, spills at N = 40)
+#ifdef LMPC_EXP_NOPIN
+#define SWEEP_PIN(a, b) do { } while (0)
+#else
+#define SWEEP_PIN(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#endif
+template <int N> __device__ __forceinline__ double *sweep_dump(double *region8N, int lane) {
+    constexpr int DN = 8 * N >= WAVE ? WAVE : 16;               // (N >= 2: at least 16 doubles; a few lanes may share a slot, which is harmless)
+    return region8N + (lane & (DN - 1));
+}
+// forward sweep xi_{k+1} = Phi_k xi_k + phi_k, k = 0 .. N-1: even stages sum over c (writers lc == 0, element lg), odd stages over g (writers lg == 0,
+// element lc); element < 6 -> dx[(k + 1) * 6 + element], else du[k * 2 + element - 6]
+template <int N> __device__ __forceinline__ sweep_dst fwd_sweep_dst(double *dx, double *du, double *dump8N, int lane, int lg, int lc) {
+    double *d = sweep_dump<N>(dump8N, lane);
+    const int sE = lc == 0 ? (lg < 6 ? 6 : 2) : 0, sO = lg == 0 ? (lc < 6 ? 6 : 2) : 0;
+    sweep_dst w;
+    w.wE = lc == 0 ? (lg < 6 ? dx + 6 + lg : du + (lg - 6)) : d; w.dE = 2 * sE;                  // stage 0, then 2, 4, ...
+    w.wO = (lg == 0 ? (lc < 6 ? dx + 6 + lc : du + (lc - 6)) : d) + sO; w.dO = 2 * sO;          // stage 1, then 3, 5, ...
+    return w;
+}
+// backward sweep p_k = Phi_k' p_{k+1} + gamma_k, k = N-1 .. 0: odd stages sum over c (writers lc == 0, pst[k * 8 + lg]), even stages over g (writers
+// lg == 0, pst[k * 8 + lc])
+template <int N> __device__ __forceinline__ sweep_dst bwd_sweep_dst(double *pst, double *dump8N, int lane, int lg, int lc) {
+    double *d = sweep_dump<N>(dump8N, lane);
+    constexpr int kO = ((N - 1) & 1) ? N - 1 : N - 2, kE = ((N - 1) & 1) ? N - 2 : N - 1;       // first odd / even stage of the sweep
+    const int sO = lc == 0 ? 8 : 0, sE = lg == 0 ? 8 : 0;
+    sweep_dst w;
+    w.wO = (lc == 0 ? pst + lg : d) + kO * sO; w.dO = -2 * sO;
+    w.wE = (lg == 0 ? pst + lc : d) + kE * sE; w.dE = -2 * sE;
+    return w;
+}
 
 // r[j] = sum_c SS[j][c] v[c] - sub[j] for j < 6, using lanes (j, part) = (lane>>3, lane&7): S/8 terms each + group reduction
 template <int S> __device__ __forceinline__ void ss_times(const double *SS, const double *v, const double *sub, double *out, int lane) {
@@ -1329,11 +1376,14 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
 #pragma unroll
             for (int k = 0; k < N; k++) gm[k] = (k & 1) ? gam[k * 8 + lg] : gam[k * 8 + lc];
             double pv = ((N - 1) & 1) ? lane_gather(pN, 32 * lc) : pN;
+            const sweep_dst wd = bwd_sweep_dst<N>(pst, gam, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;       // (gamma is in the gm registers: its LDS takes the non-writers' stores)
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int k = N - 1; k >= 0; k--) {
                 double pr = ph[k] * pv;
-                if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; if (lc == 0) pst[k * 8 + lg] = pv; }
-                else { pr = sum_over_g(pr); pv = pr + gm[k]; if (lg == 0) pst[k * 8 + lc] = pv; }
+                if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; *wO = pv; wO += wd.dO; }
+                else { pr = sum_over_g(pr); pv = pr + gm[k]; *wE = pv; wE += wd.dE; }
+                SWEEP_PIN(wE, wO);
             }
         }
         __syncthreads();
@@ -1360,14 +1410,15 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
 #pragma unroll
             for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
             double xi = 0.0;
+            const sweep_dst wd = fwd_sweep_dst<N>(dx, du, phi, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;    // (phi is in the fm registers)
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int k = 0; k < N; k++) {
                 double pr = ph[k] * xi;
-                int idx;
-                if (k & 1) { pr = sum_over_g(pr); idx = lc; } else { pr = sum_over_c(pr); idx = lg; }
+                if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
                 xi = pr + fm[k];
-                const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
-                if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
+                if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
+                SWEEP_PIN(wE, wO);
             }
             xiN = xi;
         }
@@ -1617,7 +1668,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             // (the opaque copy of `lane` keeps the compiler from hoisting them): carried, they were spilled to scratch at the loop entry
             int l2 = lane; asm volatile("" : "+v"(l2));
             const ricc_consts rc = ricc_setup(l2, Q2, Fx, R2, dR2, Fu);
-            numeric_bad |= ricc_factor<N, term, false, true>(rc, AB, kap, th, Qf2, PiT, Phi, (double *)nullptr, Mi, PhiK);
+            numeric_bad |= ricc_factor<N, term, false, true, false>(rc, AB, kap, th, Qf2, PiT, Phi, (double *)nullptr, Mi, PhiK,
+                                                                    rx + (lane & (6 * (N + 1) >= WAVE ? WAVE - 1 : 7)));    // (w, the adjoint recursion's input, is dead by now: dump)
         }
         // a breakdown of the factorisation once the iterate is optimal to working accuracy (gap at its floor, residuals small: the
         // barrier weights span > 1e26 there) is reported as INEXACT, not as a failure: the iterate whose residuals were just measured is returned

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                  *R2 = par + PAR_R2, *dR2 = par + PAR_DR2, *T2p = par + PAR_T2, *xRef = par + PAR_XREF;
     __shared__ double red[12 * 4];                           // cross-wave reduction slots
     __shared__ double phi_sh[8 * N];
+    __shared__ double dump_sh[WAVE];                         // wave 0's lanes that have nothing to store in a stage of the recursion store here (no exec-mask region on the chain)
     __shared__ int st_sh, bad_sh;
     __shared__ double gs0[WAVE];                             // wave 0's per-lane share of sum t mu (it does not take part in the residual reductions)
     __shared__ int sel_start[LMPC_MAX_USED_LAPS];
@@ -243,12 +244,14 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
 #pragma unroll
                 for (int k = 0; k < N; k++) gm[k] = (k & 1) ? gam[k * 8 + lg] : gam[k * 8 + lc];
                 double pv = ((N - 1) & 1) ? lane_gather(pN, 32 * lc) : pN;
+                const sweep_dst wd = bwd_sweep_dst<N>(pst, gam, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;   // (branch-free stores, see sweep_dst: gamma is in registers, its LDS is the dump)
                 LDS_GROUP();
 #pragma unroll
                 for (int k = N - 1; k >= 0; k--) {
                     double pr = ph[k] * pv;
-                    if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; if (lc == 0) pst[k * 8 + lg] = pv; }
-                    else { pr = sum_over_g(pr); pv = pr + gm[k]; if (lg == 0) pst[k * 8 + lc] = pv; }
+                    if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; *wO = pv; wO += wd.dO; }
+                    else { pr = sum_over_g(pr); pv = pr + gm[k]; *wE = pv; wE += wd.dE; }
+                SWEEP_PIN(wE, wO);
                 }
             }
             WSYNC();
@@ -271,16 +274,16 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 double fm[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
+                const sweep_dst wd = fwd_sweep_dst<N>(dx, du, phi, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;   // (phi is in registers)
                 LDS_GROUP();
                 double xi = 0.0;
 #pragma unroll
                 for (int k = 0; k < N; k++) {
                     double pr = ph[k] * xi;
-                    int idx;
-                    if (k & 1) { pr = sum_over_g(pr); idx = lc; } else { pr = sum_over_c(pr); idx = lg; }
+                    if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
                     xi = pr + fm[k];
-                    const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
-                    if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
+                    if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
+                SWEEP_PIN(wE, wO);
                 }
                 xiN = xi;
             }
@@ -510,8 +513,8 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 // with four waves -- 512 registers per wave -- carrying them measured the same as rebuilding them)
                 int l2 = lane; asm volatile("" : "+v"(l2));
                 const ricc_consts rc2 = ricc_setup(l2, Q2, Fx, R2, dR2, Fu);
-                numeric_bad |= ricc_factor<N, term, true>(rc2, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
-            } else numeric_bad |= ricc_factor<N, term, true>(rc, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
+                numeric_bad |= ricc_factor<N, term, true>(rc2, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi, (double *)nullptr, dump_sh + lane);
+            } else numeric_bad |= ricc_factor<N, term, true>(rc, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi, (double *)nullptr, dump_sh + lane);
             if (numeric_bad && lane == 0) bad_sh = 1;
 #pragma unroll
             for (int k = 0; k < N; k++) ph[k] = (k & 1) ? Phi[k * 64 + lc * 8 + lg] : Phi[k * 64 + lg * 8 + lc];
@@ -589,16 +592,16 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             double fm[N];
 #pragma unroll
             for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
+            const sweep_dst wd = fwd_sweep_dst<N>(dx, du, phi, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;
             LDS_GROUP();
             double xi = 0.0;
 #pragma unroll
             for (int k = 0; k < N; k++) {
                 double pr = ph[k] * xi;
-                int idx;
-                if (k & 1) { pr = sum_over_g(pr); idx = lc; } else { pr = sum_over_c(pr); idx = lg; }
+                if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
                 xi = pr + fm[k];
-                const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
-                if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
+                if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
+                SWEEP_PIN(wE, wO);
             }
             xiN = xi;
         }

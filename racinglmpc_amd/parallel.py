@@ -253,9 +253,10 @@ def comm_from_env(ctx, force_rccl=False):
 
 
 # ---------------------------------------------------------------------------------------------- lap records
-def pack_laps(laps, K, T_max):
+def pack_laps(laps, K, T_max, ids=None):
     """laps: list of (x (T,6), u (T,2), x_glob (T,6)[, extra (<=12,)]).  Keeps the K shortest (ties: lower local index),
-    pads to T_max rows + 1 row for `extra` (the state right after the finish line) and the local index.
+    pads to T_max rows + 1 row for `extra` (the state right after the finish line) and the local index (ids[i] if given -- the rollout's index
+    in the rank's shard, which is what the device-side packing writes -- else the position in `laps`).
     Returns (records float64 [K, T_max + 1, 14], lengths int64 [K]); unused slots have length -1.
     Same layout as the device-side packing of lmpc_rollout_exchange (lmpc_comm.hip.h)."""
     order = sorted(range(len(laps)), key=lambda i: (laps[i][0].shape[0], i))[:K]
@@ -269,7 +270,7 @@ def pack_laps(laps, K, T_max):
         if len(laps[i]) > 3:
             e = np.asarray(laps[i][3], float).reshape(-1)
             rec[j, T_max, :e.shape[0]] = e
-        rec[j, T_max, 12] = i
+        rec[j, T_max, 12] = i if ids is None else ids[i]
     return rec, ln
 
 

@@ -90,6 +90,7 @@ class LmpcGeneration:
         self.last_exchange = None      # (bytes per rank, seconds) of the last all-gather
         self.last_status = self.last_done = None
         self.skipped_extensions = []   # [(k, status bits)]: stored laps NOT extended in the last generation because the continuing rollout was flagged
+        self.open_laps = set()         # stored laps that end at the finish line for good (their extension was skipped): kept out of the safe-set selection
 
     def run(self, x0_all=None, xLin0=None, uLin0=None):
         import time
@@ -109,7 +110,9 @@ class LmpcGeneration:
             ext = self.ext
         ro.begin(x0, xl, ul, xg0, self.T_max)
         undo = []                      # (stored lap, rows before this generation's extension): a generation completes or leaves the safe set as it found it
+        open_before = set(self.open_laps)
         try:
+            self._apply_selection()    # (the laps added by the previous generation take part from the first step on)
             if ext > 0:
                 # the rollout with GLOBAL index k (k < K) continues stored lap k: its first ext points extend that lap on every rank.
                 # Each row is taken from the rank whose shard holds rollout k, together with that rollout's accumulated status bits: a row of a
@@ -135,6 +138,12 @@ class LmpcGeneration:
                     lap = self.parents[k][4]
                     undo.append((lap, ctx.ss_lap_rows(lap)))
                     ctx.ss_extend_lap(lap, rows[k, :nmin, 0:6], rows[k, :nmin, 6:8])
+                # A stored lap whose extension was skipped ends AT the finish line: a car approaching the line would find its 13-row window running
+                # past the lap's end (LMPC_ST_WINDOW -- the reference's IndexError, :497) on every step there.  Such a lap stays in the store (and in the
+                # regression data) but is left out of the safe-set selection from now on: the numSS_it fastest laps among the others are used --
+                # decided from the gathered rows, hence identically on every rank.
+                self.open_laps |= {self.parents[k][4] for k, _ in self.skipped_extensions} | {self.parents[k][4] for k in range(K) if nmin > 0 and not owned[k]}
+                self._apply_selection()
             ctx.rollout_run(self.T_max)
             _, _, _, self.last_done, self.last_status, _, _ = ctx.rollout_fetch(0, 0)     # per-rollout finish step / accumulated status bits
             t0 = time.perf_counter()
@@ -154,6 +163,7 @@ class LmpcGeneration:
         except Exception:
             for lap, rows_before in undo:
                 ctx.ss_truncate_lap(lap, rows_before)
+            self.open_laps = open_before
             raise
         self.parents = []
         for x, u, xg, src, T, extra in best:
@@ -162,13 +172,26 @@ class LmpcGeneration:
             self.parents.append((x, u, xg, extra[:12], ctx.ss_num_laps() - 1))
         return best
 
+    def _apply_selection(self):
+        """Safe-set selection of this generation: the library's own choice -- the numSS_it fastest stored laps, argsort(LapTime) (:395, 402) -- unless
+        some stored lap never got its extension past the finish line (`open_laps`): then the numSS_it fastest of the OTHER laps, handed over explicitly."""
+        ctx = self.ro.ctx
+        if not self.open_laps:
+            return
+        L = ctx.cfg.numSS_it
+        usable = [l for l in range(ctx.ss_num_laps()) if l not in self.open_laps]
+        if len(usable) < L:
+            raise RuntimeError("fewer than numSS_it = %d stored laps have their extension past the finish line" % L)
+        usable.sort(key=lambda l: (ctx.ss_lap_time(l), l))                  # stable argsort(LapTime)
+        ctx.ss_set_selected(usable[:L])
+
     def _host_exchange(self):
         """Same exchange with host-packed records over a caller-supplied communicator (CPU tests)."""
         ctx = self.ro.ctx
         X, U, G, done, st, fx, fg = ctx.rollout_fetch(0, ctx._ro_t)
-        laps = [(X[:done[b], b], U[:done[b], b], G[:done[b], b], np.concatenate([fx[b], fg[b]])) for b in range(X.shape[1])
-                if done[b] >= 0 and (st[b] & ~_capi.ST_INEXACT) == 0]
-        rec, ln = parallel.pack_laps(laps, self.K, self.T_max)
+        valid = [b for b in range(X.shape[1]) if done[b] >= 0 and (st[b] & ~_capi.ST_INEXACT) == 0]
+        laps = [(X[:done[b], b], U[:done[b], b], G[:done[b], b], np.concatenate([fx[b], fg[b]])) for b in valid]
+        rec, ln = parallel.pack_laps(laps, self.K, self.T_max, ids=valid)        # (the record carries the rollout's index in the shard, as the device-packed records do)
         return self.comm.allgather(rec), self.comm.allgather(ln), len(laps)
 
 

@@ -89,7 +89,8 @@ def _run(tmp_path, mode, total, gens, sabotage, port):
     else:
         cmd = [sys.executable] + args
     r = subprocess.run(cmd, env=env, timeout=1500, capture_output=True)
-    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    err = r.stderr.decode()
+    assert r.returncode == 0, "\n".join([l for l in err.splitlines() if "generation" in l][:8]) + "\n" + err[-2500:]
     return [dict(np.load(tmp_path / ("%s_rank%d.npz" % (mode, k)))) for k in range(2 if mode == "gloo" else 1)]
 
 
@@ -134,5 +135,8 @@ def test_owner_rank_supplies_extensions_and_flagged_rollout_is_skipped_everywher
     assert list(r0["gen1_ext_rows"][4:8]) == [40] * 4 and r0["gen1_skipped"].size == 0        # (c) lap 7 = parent 3, extended from rank 1's rollout 3
     assert list(r0["gen2_skipped"]) == [3] and (int(r0["gen2_skipped_bits"][0]) & ~64) != 0   # (d)
     assert list(r0["gen2_ext_rows"][8:12]) == [40, 40, 40, 0]
+    # (lap 11 now ends at the finish line for good: it is kept out of the safe-set selection on both ranks, so the other cars complete the lap --
+    #  with it selected, every window near the line would run past its end: LMPC_ST_WINDOW, the reference's IndexError)
+    assert list(r0["gen2_flagged"]) == [] and list(r1["gen2_flagged"]) == [3]
     one, = _run(tmp_path, "local", total, gens, 2, 29637)
     _same(r0, one, skip=("lo", "hi") + tuple("gen%d_src" % i for i in range(gens)))

@@ -30,7 +30,19 @@ for t in range(300):
     lmpc.addPoint(xq[t], lmpc.uPred[0])
 ts = np.array(ts[20:]) * 1e3
 print("drop-in LMPC.solve wall time per call: median %.3f ms, p90 %.3f ms (N = %d)" % (np.median(ts), np.percentile(ts, 90), N))
+import ctypes as C
+tr = (C.c_double * 5)()
+lmpc._ctx.lib.lmpc_debug_step_trace(lmpc._ctx._h, tr)
+n = max(tr[4], 1.0)
+print("inside lmpc_step_batch, per call: stage inputs %.1f us, launch K1 + K3 %.1f us, wait for the stream %.1f us, read outputs %.1f us  (%d calls)" % (
+    tr[0] / n * 1e6, tr[1] / n * 1e6, tr[2] / n * 1e6, tr[3] / n * 1e6, int(tr[4])))
+st = lmpc._ctx.stats()
+lmpc._ctx.set_profiling(1)
+for t in range(300, 340): lmpc.solve(xq[t])
+st = lmpc._ctx.stats()
+print("kernel time per call (HIP events): regression %.1f us, solve %.1f us" % (st.ms_regress / max(st.n_regress_timed, 1) * 1e3, st.ms_solve / max(st.n_solve_timed, 1) * 1e3))
+lmpc._ctx.set_profiling(0)
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
-for t in range(300, 400): lmpc.solve(xq[t])
+for t in range(340, 440): lmpc.solve(xq[t])
 pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(12)

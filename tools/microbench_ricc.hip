@@ -5,7 +5,7 @@
 #include "../racinglmpc_amd/csrc/lmpc_kernels.hip.h"
 #include <cstdio>
 template <int N> __global__ __launch_bounds__(64, 1) void mb(double *out, long long *cyc, int reps) {
-    __shared__ double AB[48 * N], kap[2 * N], th[8 * N + 48], Qf2[36], PiT[36], Phi[64 * N], PiAll[64 * N], Mi[4 * N], Q2[36], Fx[12], R2[4], dR2[2], Fu[8];
+    __shared__ double AB[48 * N], kap[2 * N], th[8 * N + 48], Qf2[36], PiT[36], Phi[64 * N], PiAll[64 * N], Mi[4 * N], Q2[36], Fx[12], R2[4], dR2[2], Fu[8], dump[64];
     const int lane = threadIdx.x;
     for (int i = lane; i < 48 * N; i += 64) { const int r = (i % 48) / 8, c = i % 8; AB[i] = (r == c ? 1.0 : 0.0) + 0.01 * ((i * 7) % 13 - 6) * (c < 6 ? 0.1 : 1.0); }
     for (int i = lane; i < 2 * N; i += 64) kap[i] = 0.5 + 0.01 * i;
@@ -19,7 +19,7 @@ template <int N> __global__ __launch_bounds__(64, 1) void mb(double *out, long l
     const ricc_consts rc = ricc_setup(lane, Q2, Fx, R2, dR2, Fu);
     int bad = 0;
     long long t0 = __builtin_readcyclecounter();
-    for (int r = 0; r < reps; r++) bad |= ricc_factor<N, true>(rc, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi);
+    for (int r = 0; r < reps; r++) bad |= ricc_factor<N, true>(rc, AB, kap, th, Qf2, PiT, Phi, PiAll, Mi, (double *)nullptr, dump + lane);
     long long t1 = __builtin_readcyclecounter();
     __syncthreads();
     out[lane] = Phi[lane] + Mi[lane & 3] + bad;
