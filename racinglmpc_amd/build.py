@@ -41,6 +41,11 @@ def build_asan():
     return build_flavour("asan", ["LMPC_GUARD"], extra=ASAN_FLAGS)
 
 
+def build_guard():
+    """Guard zones only (no AddressSanitizer): liblmpc_hip_guard.so -- the same device-buffer overrun check at full speed, with libstdc++ assertions on."""
+    return build_flavour("guard", ["LMPC_GUARD", "_GLIBCXX_ASSERTIONS"])
+
+
 def build(force=False, verbose=False):
     if not force and _current():
         return OUT

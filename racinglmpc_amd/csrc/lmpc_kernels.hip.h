@@ -20,6 +20,12 @@
 #define LMPC_VARIANT_ABI 6              // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change
 #define LMPC_COLS 9                 // lap-store columns: x0..x5, u0, u1, Qfun
 
+// Branch-free LDS stores in the register sweeps and the Riccati recursion (sweep_dst below): on for horizons up to 24.
+// (horizons up to 24.  At N = 40 the one-wave kernel sits at 256 VGPRs + ~190 AGPRs and its code generation is brittle: with the branch-free stores
+//  the solve kernel measured 13 % SLOWER there (1.10 -> 1.24 ms at batch 1024; neither the pinned pointers nor the recursion's dump stores alone
+//  explain it) -- long horizons keep the predicated stores, text unchanged.)
+template <int N> constexpr bool SWEEP_BF = N <= 24;
+
 struct lmpc_dev_params {
     int N, S, L, ppl;               // horizon, safe-set columns, laps per solve, points per lap (S/L)
     int trToUse, maxNumPoint;
@@ -770,7 +776,7 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
     const int lane = threadIdx.x & (WAVE - 1);
     const int qr = c.qr;
     int bad = 0;
-    double *const miDst = lane < 4 ? Mi + lane : dump; const int miStride = lane < 4 ? 4 : 0;           // M_uu^-1 of stage k: lanes 0..3 -> Mi[k * 4 + lane]
+    double *const miDst = (lane < 4 || !SWEEP_BF<N>) ? Mi + lane : dump; const int miStride = lane < 4 ? 4 : 0;           // M_uu^-1 of stage k: lanes 0..3 -> Mi[k * 4 + lane]
     double Piq = c.w_xx ? Qf2[c.qR * 6 + c.qC] + (term ? PiT[c.qR * 6 + c.qC] : 0.0) : 0.0;   // Pi_N = [[2Qf + Pi_term, 0], [0, 0]]
     // Stage operands are fetched one stage ahead.  The twelve LDS reads of stage k - 1 are ISSUED at the top of stage k (a compiler fence
     // pins them there) and their arithmetic -- the six-term sum that builds the stage Hessian W -- runs at the bottom, behind the chain of
@@ -835,18 +841,38 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
 #ifndef RICC_VAR_NOSTORE              // (tools/microbench_ricc.hip: what the LDS stores cost -- 90 cycles per stage)
         if constexpr (SPLIT) { double *d_ = c.qR < 6 ? Phi + k * 48 + c.qR * 8 + c.qC : PhiK + k * 16 + (c.qR - 6) * 8 + c.qC; *d_ = Phq; }
         else Phi[k * 64 + c.qR * 8 + c.qC] = Phq;
-        if constexpr (HASPI) PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
-#ifdef LMPC_EXP_NORICCDUMP
-        if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 3 ? i11 : i01);
-#else
-        miDst[k * miStride] = lane == 0 ? i00 : (lane == 3 ? i11 : i01);
-#endif
+        if constexpr (HASPI && SWEEP_BF<N>) PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
+        else if (PiAll) PiAll[k * 64 + c.qR * 8 + c.qC] = Piq;
+        if constexpr (SWEEP_BF<N>) miDst[k * miStride] = lane == 0 ? i00 : (lane == 3 ? i11 : i01);
+        else { if (lane < 4) Mi[k * 4 + lane] = lane == 0 ? i00 : (lane == 3 ? i11 : i01); }
 #else
         if (k == 0) { Phi[c.qR * 8 + c.qC] = Phq; if (lane < 4) Mi[lane] = i00 + i01 + i11; }
 #endif
         if constexpr (STEP) { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     }
     return bad;
+}
+
+// Gram matrix of the terminal factor: W = M M' (8 x 8 row-major in Wl, row / column 7 zero; M = 8 rows x 64 CH columns, column-major in Mt, 8 per column)
+// on the matrix cores with v_mfma_f64_4x4x4 -- one instruction multiplies four independent 4 x 4 blocks, here the four quadrants (I, J) of W for four
+// columns of M: lane 16 k + 4 b + i supplies A = M[4 (b >> 1) + i][4 s + k] and B = M[4 (b & 1) + i][4 s + k] (operand layout: ricc_factor above), the
+// quadrant entry W[4 (b >> 1) + r][4 (b & 1) + c] comes back in lane 16 r + 4 b + c.  16 CH instructions in four accumulation chains, ~16 issue cycles
+// each.  (Rounds 1-3 used 16 CH v_mfma_f64_16x16x4 -- a 16 x 16 tile for an 8 x 8 result; on CDNA4 FP64 matrix work runs at the vector rate, so the
+// big shape only costs: the Gram matrix was ~1.1 k of the terminal factor's ~5 k cycles.)
+template <int CH> __device__ __forceinline__ void gram8_mfma(const double *Mt, double *Wl, int lane) {
+    const int k = lane >> 4, b = (lane >> 2) & 3, i = lane & 3;
+    const double *pa = Mt + k * 8 + 4 * (b >> 1) + i, *pb = Mt + k * 8 + 4 * (b & 1) + i;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll
+    for (int s_ = 0; s_ < 16 * CH; s_ += 4) {
+        const double a0 = pa[32 * s_], b0 = pb[32 * s_], a1 = pa[32 * (s_ + 1)], b1 = pb[32 * (s_ + 1)];
+        const double a2 = pa[32 * (s_ + 2)], b2 = pb[32 * (s_ + 2)], a3 = pa[32 * (s_ + 3)], b3 = pb[32 * (s_ + 3)];
+        acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2, b2, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f64_4x4x4f64(a3, b3, acc3, 0, 0, 0);
+    }
+    Wl[(4 * (b >> 1) + (lane >> 4)) * 8 + 4 * (b & 1) + (lane & 3)] = (acc0 + acc1) + (acc2 + acc3);
 }
 
 template <int N, int S> struct solve_lds {
@@ -952,11 +978,7 @@ typedef __attribute__((address_space(3))) double lds_f64;    // explicit LDS poi
 struct sweep_dst { double *wE, *wO; int dE, dO; };          // destination of the NEXT even / odd stage and its (signed) advance per use, in doubles
 // (the pointers are advanced stage by stage and pinned with an empty asm: computed as base + k * stride the compiler forms all N addresses ahead of the
 //  unrolled loop -- 2 N live registers, spills at N = 40)
-#ifdef LMPC_EXP_NOPIN
-#define SWEEP_PIN(a, b) do { } while (0)
-#else
 #define SWEEP_PIN(a, b) asm volatile("" : "+v"(a), "+v"(b))
-#endif
 template <int N> __device__ __forceinline__ double *sweep_dump(double *region8N, int lane) {
     constexpr int DN = 8 * N >= WAVE ? WAVE : 16;               // (N >= 2: at least 16 doubles; a few lanes may share a slot, which is harmless)
     return region8N + (lane & (DN - 1));
@@ -1376,14 +1398,23 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
 #pragma unroll
             for (int k = 0; k < N; k++) gm[k] = (k & 1) ? gam[k * 8 + lg] : gam[k * 8 + lc];
             double pv = ((N - 1) & 1) ? lane_gather(pN, 32 * lc) : pN;
-            const sweep_dst wd = bwd_sweep_dst<N>(pst, gam, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;       // (gamma is in the gm registers: its LDS takes the non-writers' stores)
-            asm volatile("" ::: "memory");
+            if constexpr (SWEEP_BF<N>) {
+                const sweep_dst wd = bwd_sweep_dst<N>(pst, gam, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;       // (gamma is in the gm registers: its LDS takes the non-writers' stores)
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int k = N - 1; k >= 0; k--) {
-                double pr = ph[k] * pv;
-                if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; *wO = pv; wO += wd.dO; }
-                else { pr = sum_over_g(pr); pv = pr + gm[k]; *wE = pv; wE += wd.dE; }
-                SWEEP_PIN(wE, wO);
+                for (int k = N - 1; k >= 0; k--) {
+                    double pr = ph[k] * pv;
+                    if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; *wO = pv; wO += wd.dO; }
+                    else { pr = sum_over_g(pr); pv = pr + gm[k]; *wE = pv; wE += wd.dE; }
+                    SWEEP_PIN(wE, wO);
+                }
+            } else {
+#pragma unroll
+                for (int k = N - 1; k >= 0; k--) {
+                    double pr = ph[k] * pv;
+                    if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; if (lc == 0) pst[k * 8 + lg] = pv; }
+                    else { pr = sum_over_g(pr); pv = pr + gm[k]; if (lg == 0) pst[k * 8 + lc] = pv; }
+                }
             }
         }
         __syncthreads();
@@ -1410,15 +1441,27 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
 #pragma unroll
             for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
             double xi = 0.0;
-            const sweep_dst wd = fwd_sweep_dst<N>(dx, du, phi, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;    // (phi is in the fm registers)
-            asm volatile("" ::: "memory");
+            if constexpr (SWEEP_BF<N>) {
+                const sweep_dst wd = fwd_sweep_dst<N>(dx, du, phi, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;    // (phi is in the fm registers)
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int k = 0; k < N; k++) {
-                double pr = ph[k] * xi;
-                if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
-                xi = pr + fm[k];
-                if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
-                SWEEP_PIN(wE, wO);
+                for (int k = 0; k < N; k++) {
+                    double pr = ph[k] * xi;
+                    if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
+                    xi = pr + fm[k];
+                    if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
+                    SWEEP_PIN(wE, wO);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    double pr = ph[k] * xi;
+                    int idx;
+                    if (k & 1) { pr = sum_over_g(pr); idx = lc; } else { pr = sum_over_c(pr); idx = lg; }
+                    xi = pr + fm[k];
+                    const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
+                    if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
+                }
             }
             xiN = xi;
         }
@@ -1471,6 +1514,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
     };
     int it = 0, converged = 0, sep = 0;                   // sep: separate primal/dual step lengths after a poor-progress iteration
     double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0;
+
     const double qscale = wave_uniform(fmax(1.0, qmax));                // dual residual tolerance is relative to the cost scale
 #pragma unroll 1
     for (it = 0; it <= p.max_iter; it++) {
@@ -1594,9 +1638,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
                 }
             }
             double Rr[7][7], rinv[7];
-            // Gram matrix W = M M' (7 x 7, K = 64 CH columns) on the matrix cores: v_mfma_f64_16x16x4 over 16 CH K-chunks.
-            // operand layout: lane = 16 k + i holds M[i][4 s + k] for both A and B (W is M times its own transpose);
-            // accumulator: lane l, register r holds W[4 r + l / 16][l % 16].
+            // Gram matrix W = M M' (7 x 7, K = 64 CH columns) on the matrix cores (gram8_mfma)
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
 #pragma unroll
@@ -1604,7 +1646,12 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
                 Mt[(lane + WAVE * ch) * 8 + 7] = 0.0;
             }
             __syncthreads();
-            {
+            // (one-wave kernel: the 4x4x4 form where it has been validated -- horizons up to 24 with at most two terminal-block columns per lane.  At N = 40
+            //  and with six columns per lane (numSS_points = 360) -- both kernels that run one wave per SIMD on the full register file -- every problem
+            //  ran into the iteration limit with it, although the two Gram matrices agree to rounding both in a stand-alone check (tools/gram_check.hip)
+            //  and computed side by side inside this kernel: unexplained, so those configurations keep the shape they were validated with.)
+            if constexpr (SWEEP_BF<N> && CH <= 2) gram8_mfma<CH>(Mt, Wl, lane);
+            else {
                 typedef double v4d __attribute__((ext_vector_type(4)));
                 v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;   // four independent accumulation chains (the dependent latency of this shape is ~100 cycles)
                 const int kk = lane >> 4, ii = lane & 15;

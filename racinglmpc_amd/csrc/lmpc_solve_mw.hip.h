@@ -144,13 +144,19 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     // terminal slack likewise (s_T <- s_T + alpha ds_T).  One pass over the rows per iteration, together with the step, instead of three.
     // rt is the EFFECTIVE reciprocal 1 / max(t, 1e-11 mu) (barrier weight capped at 1e11, see LMPC_TH_INV): matrix (theta = mu rt) and right-hand
     // sides (predictor h = t mu rt, corrector h = (t mu + dt dmu - sigma gap) rt) use the same one, so the capped row is a regularised row.
+    // Row ownership (round 4): slot s = tid + NT j owns inequality row  s < S ? 8 N + s : s - S -- the lambda rows, whose barrier weights are the
+    // terminal block's, belong to the FIRST S threads: to wave 0 when S <= 64.  The wave that factorises the terminal block then knows the new
+    // weights the moment it has updated its own rows, and starts the next iteration's terminal factor (Gram matrix part) inside the step phase
+    // instead of behind the barrier that ends it (TEARLY; four waves per QP, one terminal-block column per lane).
+    constexpr bool TEARLY = term && NW == 4 && LL::CH == 1 && S <= WAVE;
+    auto slot_row = [&](int j) -> int { const int s_ = tid + NT * j; return s_ >= M ? -1 : (s_ < S ? 8 * N + s_ : s_ - S); };
     double t_r[RPL], rt_r[RPL], tp_r[RPL], dt_r[RPL];
     double gsum_c = 0.0;                                   // this thread's share of sum t mu (the complementarity gap)
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
-        const int r = tid + NT * j;
+        const int r = slot_row(j);
         t_r[j] = 1.0; rt_r[j] = 1.0; tp_r[j] = 0.0; dt_r[j] = 0.0;
-        if (r < M) {
+        if (r >= 0) {
             const double tt = rowb(r) - rowF(r, x, u, s, lam), mm = mu0 / tt; t_r[j] = tt; m[r] = mm;
             const double rt = barrier_rt(tt, mm), thv = mm * rt;
             rt_r[j] = rt; th[r] = thv; h[r] = tt * thv; gsum_c = fma(tt, mm, gsum_c);      // h: the predictor's right-hand side, see the step
@@ -182,7 +188,95 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     constexpr int NT3 = NT - WAVE;
     const int t3 = tid - WAVE;
 #define FOR_HELP(i, n, off) for (int i = (t3 >= ((off) % NT3) ? t3 - ((off) % NT3) : t3 - ((off) % NT3) + NT3); i < (n); i += NT3)
+    // a loop that belongs to ONE wave (w, or the last wave of a smaller work-group), 64 items per trip.  A wave executes every loop BODY one of its
+    // lanes takes part in, so a wave that straddles three loops pays the latency chains of all three: phase 1's helper loops are handed out wave by wave
+    // (before: wave 2 ran the tail of the stationarity rows, the u / s rows AND half the lambda rows -- 4.7 k cycles against 3.3 k and 2.9 k)
+#define FOR_WAVE(i, n, w) for (int i = (wave == ((w) < NW ? (w) : NW - 1)) ? lane : (n); i < (n); i += WAVE)
+    // ... and a loop of up to 128 items in ONE trip: items 0 .. 63 on wave w, the rest on the low lanes of wave w2 (two trips of one wave cost two
+    // latency chains; with two waves per QP both names mean wave 1 and the loop takes its trips there)
+#define WCL(w) ((w) < NW ? (w) : NW - 1)
+#define FOR_WAVE2(i, n, w, w2) for (int i = WCL(w) == WCL(w2) ? (wave == WCL(w) ? lane : (n)) : (wave == (w) ? lane : (wave == (w2) ? WAVE + lane : (n))), \
+                                        i##_st = WCL(w) == WCL(w2) ? WAVE : 2 * WAVE; i < (n); i += i##_st)
     int tcnt = 0;
+    // Terminal factor of the CURRENT barrier weights of the lambda rows, by wave 0, in two parts.
+    //   part A: columns of M = [E D^-1/2 | T^-1/2] (registers + LDS copy)
+    //   part B: Gram matrix W = M M' on the matrix cores, Cholesky R'R = W, R^-1, Pi_term
+    // Part B sits in phase 1 of the Newton iteration.  Part A does too in the generic kernel; with TEARLY wave 0 runs it at the end of the PREVIOUS
+    // iteration's step phase, right after it has updated its own (lambda) rows, while the other waves are still busy with the costates and the
+    // primal update (nothing else reads rsq / Mt / Wl / mcol between the corrector solve and the next factorisation).
+    auto term_partA = [&]() {
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) {
+            const int col = lane + WAVE * ch;
+#pragma unroll
+            for (int j = 0; j < 7; j++) mcol[ch][j] = 0.0;
+            if (col < S) {
+                const double rs_ = frsqrt(th[8 * N + col] + p.reg); rsq[col] = rs_;
+#pragma unroll
+                for (int j = 0; j < 6; j++) mcol[ch][j] = SS[j * S + col] * rs_;
+                mcol[ch][6] = rs_;
+            } else {
+                rsq[col] = 1.0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) if (col - S == j) mcol[ch][j] = tsq_lane[ch];
+            }
+#pragma unroll
+            for (int j = 0; j < 7; j++) Mt[col * 8 + j] = mcol[ch][j];
+            Mt[col * 8 + 7] = 0.0;
+        }
+    };
+    auto term_partB = [&](int &numeric_bad) {
+        double Rr[7][7], rinv[7];
+        WSYNC();
+        gram8_mfma<CH>(Mt, Wl, lane);             // Gram matrix W = M M' on the matrix cores
+        WSYNC();
+#pragma unroll
+        for (int i = 0; i < 7; i++)
+#pragma unroll
+            for (int j = i; j < 7; j++) Rr[i][j] = Wl[i * 8 + j];
+        LDS_GROUP();
+#pragma unroll
+        for (int i = 0; i < 7; i++) {                                                 // Cholesky, row by row
+            double d_ = Rr[i][i];
+#pragma unroll
+            for (int k = 0; k < i; k++) d_ = fma(-Rr[k][i], Rr[k][i], d_);
+            if (!(d_ > 0.0)) { numeric_bad = 1; d_ = 1.0; }
+            rinv[i] = frsqrt(d_); const double rii = d_ * rinv[i]; Rr[i][i] = rii;
+#pragma unroll
+            for (int j = i + 1; j < 7; j++) {
+                double v = Rr[i][j];
+#pragma unroll
+                for (int k = 0; k < i; k++) v = fma(-Rr[k][i], Rr[k][j], v);
+                Rr[i][j] = v * rinv[i];
+            }
+        }
+        {   // Ri = R^-1 (upper): lane j < 7 back-substitutes column j (R is uniform across the lanes), 28 dependent operations instead of 140.
+            // Terms beyond the diagonal multiply exact zeros, so every entry is bit-identical to the column-by-column form.
+            double col[7];
+#pragma unroll
+            for (int i = 6; i >= 0; i--) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = i + 1; k < 7; k++) v = fma(-Rr[i][k], col[k], v);
+                col[i] = lane == i ? rinv[i] : (lane > i ? v * rinv[i] : 0.0);
+            }
+            if (lane < 7) {
+#pragma unroll
+                for (int i = 0; i < 7; i++) Ri[i * 7 + lane] = col[i];
+            }
+        }
+        WSYNC();
+        if (lane < 36) {                                 // Pi_term = (Ri Ri')[0:6,0:6]  (Ri is zero below the diagonal: all seven terms, same sum)
+            const int i = lane / 6, j = lane % 6; double v = 0.0;
+            double ra[7], rb[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) { ra[k] = Ri[i * 7 + k]; rb[k] = Ri[j * 7 + k]; }
+            LDS_GROUP();
+#pragma unroll
+            for (int k = 0; k < 7; k++) v = (k >= i && k >= j) ? fma(ra[k], rb[k], v) : v;
+            PiT[lane] = v;
+        }
+                };
     // Corrector solve (right-hand side h in LDS; the factors of this iterate are in place).  Three barriers:
     //   C1  wave 0: terminal costate p_N;  helper waves: gamma_k for every stage, each entry rebuilding the two slack eliminations and the
     //       reduced input gradient of its stage from h (no intermediate arrays, hence no barrier between them and gamma)
@@ -244,14 +338,24 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
 #pragma unroll
                 for (int k = 0; k < N; k++) gm[k] = (k & 1) ? gam[k * 8 + lg] : gam[k * 8 + lc];
                 double pv = ((N - 1) & 1) ? lane_gather(pN, 32 * lc) : pN;
-                const sweep_dst wd = bwd_sweep_dst<N>(pst, gam, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;   // (branch-free stores, see sweep_dst: gamma is in registers, its LDS is the dump)
-                LDS_GROUP();
+                if constexpr (SWEEP_BF<N>) {
+                    const sweep_dst wd = bwd_sweep_dst<N>(pst, gam, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;   // (branch-free stores, see sweep_dst: gamma is in registers, its LDS is the dump)
+                    LDS_GROUP();
 #pragma unroll
-                for (int k = N - 1; k >= 0; k--) {
-                    double pr = ph[k] * pv;
-                    if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; *wO = pv; wO += wd.dO; }
-                    else { pr = sum_over_g(pr); pv = pr + gm[k]; *wE = pv; wE += wd.dE; }
-                SWEEP_PIN(wE, wO);
+                    for (int k = N - 1; k >= 0; k--) {
+                        double pr = ph[k] * pv;
+                        if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; *wO = pv; wO += wd.dO; }
+                        else { pr = sum_over_g(pr); pv = pr + gm[k]; *wE = pv; wE += wd.dE; }
+                        SWEEP_PIN(wE, wO);
+                    }
+                } else {
+                    LDS_GROUP();
+#pragma unroll
+                    for (int k = N - 1; k >= 0; k--) {
+                        double pr = ph[k] * pv;
+                        if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; if (lc == 0) pst[k * 8 + lg] = pv; }
+                        else { pr = sum_over_g(pr); pv = pr + gm[k]; if (lg == 0) pst[k * 8 + lc] = pv; }
+                    }
                 }
             }
             WSYNC();
@@ -274,16 +378,29 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 double fm[N];
 #pragma unroll
                 for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
-                const sweep_dst wd = fwd_sweep_dst<N>(dx, du, phi, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;   // (phi is in registers)
-                LDS_GROUP();
                 double xi = 0.0;
+                if constexpr (SWEEP_BF<N>) {
+                    const sweep_dst wd = fwd_sweep_dst<N>(dx, du, phi, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;   // (phi is in registers)
+                    LDS_GROUP();
 #pragma unroll
-                for (int k = 0; k < N; k++) {
-                    double pr = ph[k] * xi;
-                    if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
-                    xi = pr + fm[k];
-                    if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
-                SWEEP_PIN(wE, wO);
+                    for (int k = 0; k < N; k++) {
+                        double pr = ph[k] * xi;
+                        if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
+                        xi = pr + fm[k];
+                        if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
+                        SWEEP_PIN(wE, wO);
+                    }
+                } else {
+                    LDS_GROUP();
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        double pr = ph[k] * xi;
+                        int idx;
+                        if (k & 1) { pr = sum_over_g(pr); idx = lc; } else { pr = sum_over_c(pr); idx = lg; }
+                        xi = pr + fm[k];
+                        const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
+                        if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
+                    }
                 }
                 xiN = xi;
             }
@@ -340,96 +457,14 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         int numeric_bad = 0;
         if (w0) {
             if constexpr (term) {
-#pragma unroll
-                for (int ch = 0; ch < CH; ch++) {
-                    const int col = lane + WAVE * ch;
-#pragma unroll
-                    for (int j = 0; j < 7; j++) mcol[ch][j] = 0.0;
-                    if (col < S) {
-                        const double rs_ = frsqrt(th[8 * N + col] + p.reg); rsq[col] = rs_;
-#pragma unroll
-                        for (int j = 0; j < 6; j++) mcol[ch][j] = SS[j * S + col] * rs_;
-                        mcol[ch][6] = rs_;
-                    } else {
-                        rsq[col] = 1.0;
-#pragma unroll
-                        for (int j = 0; j < 6; j++) if (col - S == j) mcol[ch][j] = tsq_lane[ch];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 7; j++) Mt[col * 8 + j] = mcol[ch][j];
-                    Mt[col * 8 + 7] = 0.0;
-                }
-                double Rr[7][7], rinv[7];
-                WSYNC();
-                {   // Gram matrix W = M M' on the matrix cores (see lmpc_solve_kernel)
-                    typedef double v4d __attribute__((ext_vector_type(4)));
-                    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;   // four independent accumulation chains (the dependent latency of this shape is ~100 cycles)
-                    const int kk = lane >> 4, ii = lane & 15;
-                    const bool live = ii < 8;
-#pragma unroll
-                    for (int s_ = 0; s_ < 16 * CH; s_ += 4) {
-                        double a0 = Mt[(4 * s_ + kk) * 8 + (ii & 7)], a1 = Mt[(4 * (s_ + 1) + kk) * 8 + (ii & 7)], a2 = Mt[(4 * (s_ + 2) + kk) * 8 + (ii & 7)], a3 = Mt[(4 * (s_ + 3) + kk) * 8 + (ii & 7)];
-                        a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0; a2 = live ? a2 : 0.0; a3 = live ? a3 : 0.0;
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc2, 0, 0, 0);
-                        acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc3, 0, 0, 0);
-                    }
-                    if (ii < 8) { Wl[kk * 8 + ii] = (acc0[0] + acc1[0]) + (acc2[0] + acc3[0]); Wl[(4 + kk) * 8 + ii] = (acc0[1] + acc1[1]) + (acc2[1] + acc3[1]); }
-                }
-                WSYNC();
-#pragma unroll
-                for (int i = 0; i < 7; i++)
-#pragma unroll
-                    for (int j = i; j < 7; j++) Rr[i][j] = Wl[i * 8 + j];
-                LDS_GROUP();
-#pragma unroll
-                for (int i = 0; i < 7; i++) {                                                 // Cholesky, row by row
-                    double d_ = Rr[i][i];
-#pragma unroll
-                    for (int k = 0; k < i; k++) d_ = fma(-Rr[k][i], Rr[k][i], d_);
-                    if (!(d_ > 0.0)) { numeric_bad = 1; d_ = 1.0; }
-                    rinv[i] = frsqrt(d_); const double rii = d_ * rinv[i]; Rr[i][i] = rii;
-#pragma unroll
-                    for (int j = i + 1; j < 7; j++) {
-                        double v = Rr[i][j];
-#pragma unroll
-                        for (int k = 0; k < i; k++) v = fma(-Rr[k][i], Rr[k][j], v);
-                        Rr[i][j] = v * rinv[i];
-                    }
-                }
-                {   // Ri = R^-1 (upper): lane j < 7 back-substitutes column j (R is uniform across the lanes), 28 dependent operations instead of 140.
-                    // Terms beyond the diagonal multiply exact zeros, so every entry is bit-identical to the column-by-column form.
-                    double col[7];
-#pragma unroll
-                    for (int i = 6; i >= 0; i--) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int k = i + 1; k < 7; k++) v = fma(-Rr[i][k], col[k], v);
-                        col[i] = lane == i ? rinv[i] : (lane > i ? v * rinv[i] : 0.0);
-                    }
-                    if (lane < 7) {
-#pragma unroll
-                        for (int i = 0; i < 7; i++) Ri[i * 7 + lane] = col[i];
-                    }
-                }
-                WSYNC();
-                if (lane < 36) {                                 // Pi_term = (Ri Ri')[0:6,0:6]  (Ri is zero below the diagonal: all seven terms, same sum)
-                    const int i = lane / 6, j = lane % 6; double v = 0.0;
-                    double ra[7], rb[7];
-#pragma unroll
-                    for (int k = 0; k < 7; k++) { ra[k] = Ri[i * 7 + k]; rb[k] = Ri[j * 7 + k]; }
-                    LDS_GROUP();
-#pragma unroll
-                    for (int k = 0; k < 7; k++) v = (k >= i && k >= j) ? fma(ra[k], rb[k], v) : v;
-                    PiT[lane] = v;
-                }
+                if (!TEARLY || it == 0) term_partA();
+                term_partB(numeric_bad);
             }
             WSYNC();
             TSMW(110);
         } else {
             double rmax = 0.0, remax = 0.0, lsum = 0.0;
-            FOR_HELP(i, 6 * (N + 1), 0) {                     // stationarity rows of x_k
+            FOR_WAVE2(i, 6 * (N + 1), 1, 3) {                 // stationarity rows of x_k (wave 1, the last few on wave 3)
                 const int k = i / 6, c = i % 6; double v = 0.0;
                 if (k >= 1) {
                     const double *Qk = k < N ? Q2 : Qf2;
@@ -446,7 +481,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 rx[i] = v;
                 if (i < 6) dx[i] = 0.0;
             }
-            FOR_HELP(i, 2 * N, 6 * (N + 1)) {                 // rows of u_k and s_k; slack elimination and the predictor's (h = mu) reduced gradients
+            FOR_WAVE(i, 2 * N, 2) {                           // rows of u_k and s_k; slack elimination and the predictor's (h = mu) reduced gradients (wave 2)
                 const int k = i >> 1, c = i & 1;
                 const double up = k > 0 ? u[(k - 1) * 2 + c] : (c == 0 ? uOld0 : uOld1);
                 double v = R2[c * 2] * u[k * 2] + R2[c * 2 + 1] * u[k * 2 + 1] + dR2[c] * (u[i] - up);
@@ -468,14 +503,14 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 ee[i] = e_; eta[i] = hl + th[i] * e_ * d_;
             }
             if constexpr (term) {
-                FOR_HELP(c, S, 6 * (N + 1) + 2 * N) {
+                FOR_WAVE(c, S, 2) {                           // rows of lambda (wave 2)
                     double v = Qsel[c] - m[8 * N + c] + eta_m;
 #pragma unroll
                     for (int j = 0; j < 6; j++) v = fma(SS[j * S + c], T2p[j] * sT[j], v);
                     rl[c] = v; rmax = fmax(rmax, fabs(v)); lsum += lam[c];
                 }
             }
-            FOR_HELP(i, 6 * N, 6 * (N + 1) + 2 * N + S) {     // dynamics residual (monitoring only)
+            FOR_WAVE2(i, 6 * N, 3, 1) {                       // dynamics residual (monitoring only; wave 3, the last few on wave 1)
                 const int k = i / 6, c = i % 6;
                 double v = x[(k + 1) * 6 + c] - C[i] - AB[k * 48 + c * 8 + 6] * u[k * 2] - AB[k * 48 + c * 8 + 7] * u[k * 2 + 1];
 #pragma unroll
@@ -592,16 +627,29 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             double fm[N];
 #pragma unroll
             for (int k = 0; k < N; k++) fm[k] = (k & 1) ? phi[k * 8 + lc] : phi[k * 8 + lg];
-            const sweep_dst wd = fwd_sweep_dst<N>(dx, du, phi, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;
-            LDS_GROUP();
             double xi = 0.0;
+            if constexpr (SWEEP_BF<N>) {
+                const sweep_dst wd = fwd_sweep_dst<N>(dx, du, phi, lane, lg, lc); lds_f64 *wE = (lds_f64 *)wd.wE, *wO = (lds_f64 *)wd.wO;
+                LDS_GROUP();
 #pragma unroll
-            for (int k = 0; k < N; k++) {
-                double pr = ph[k] * xi;
-                if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
-                xi = pr + fm[k];
-                if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
-                SWEEP_PIN(wE, wO);
+                for (int k = 0; k < N; k++) {
+                    double pr = ph[k] * xi;
+                    if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
+                    xi = pr + fm[k];
+                    if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
+                    SWEEP_PIN(wE, wO);
+                }
+            } else {
+                LDS_GROUP();
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    double pr = ph[k] * xi;
+                    int idx;
+                    if (k & 1) { pr = sum_over_g(pr); idx = lc; } else { pr = sum_over_c(pr); idx = lg; }
+                    xi = pr + fm[k];
+                    const bool wr = (k & 1) ? (lg == 0) : (lc == 0);
+                    if (wr) { if (idx < 6) dx[(k + 1) * 6 + idx] = xi; else du[k * 2 + (idx - 6)] = xi; }
+                }
             }
             xiN = xi;
         }
@@ -647,8 +695,8 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         double apmax = 1.0, admax = 1.0, dma_r[RPL];
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-            const int r = tid + NT * j; dma_r[j] = 0.0;
-            if (r < M) {
+            const int r = slot_row(j); dma_r[j] = 0.0;
+            if (r >= 0) {
                 const double dta = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dma = -h[r] - th[r] * dta;
                 dt_r[j] = dta; dma_r[j] = dma;
@@ -663,8 +711,8 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         double gaff = 0.0;
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-            const int r = tid + NT * j;
-            if (r < M) { gaff = fma(t_r[j] + apmax * dt_r[j], m[r] + admax * dma_r[j], gaff); tp_r[j] = dt_r[j] * dma_r[j]; }
+            const int r = slot_row(j);
+            if (r >= 0) { gaff = fma(t_r[j] + apmax * dt_r[j], m[r] + admax * dma_r[j], gaff); tp_r[j] = dt_r[j] * dma_r[j]; }
         }
         red_put(6, wsum(gaff));
         __syncthreads();
@@ -674,15 +722,15 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         TSMW(15);
         // ---- corrector ---------------------------------------------------------------------------------------
 #pragma unroll
-        for (int j = 0; j < RPL; j++) { const int r = tid + NT * j; if (r < M) h[r] = (fma(t_r[j], m[r], tp_r[j]) - tgt) * rt_r[j]; }
+        for (int j = 0; j < RPL; j++) { const int r = slot_row(j); if (r >= 0) h[r] = (fma(t_r[j], m[r], tp_r[j]) - tgt) * rt_r[j]; }
         __syncthreads();
         kkt_solve(re_sum);
         TSMW(16);
         double apx = INFINITY, adx = INFINITY, dsum = 0.0;   // dsum: this thread's lambda rows' share of the step of the multiplier of sum(lambda) = 1
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-            const int r = tid + NT * j;
-            if (r < M) {
+            const int r = slot_row(j);
+            if (r >= 0) {
                 const double dtt = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dmm = -h[r] - th[r] * dtt;
                 dm[r] = dmm; dt_r[j] = dtt;
@@ -701,7 +749,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         TSMW(17);
         // ---- step.  The multipliers of the equality rows (costates nu_k = -(Pi_k xi_k + p_k)_x for all stages at once) are formed and
         //      applied in the same pass as the primal step and the inequality rows: nothing here reads what another thread writes. ----------
-        for (int i = tid; i < 6 * N; i += NT) {
+        FOR_WAVE2(i, 6 * N, 3, 1) {                          // (wave 3 and a few lanes of wave 1: wave 0 has the next terminal factor to start, see below)
             const int k = i / 6 + 1, c = i % 6;
             double g;
             if (k == N) {
@@ -727,14 +775,14 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             for (int j = 0; j < 6; j++) deta -= T2p[j] * w7[j] * ss_rowsum[j];
             deta /= (double)S;
         }
-        FOR_OFF(i, 6 * (N + 1), O1) x[i] = fma(al, dx[i], x[i]);
-        FOR_OFF(i, 2 * N, O2) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
-        if constexpr (term) { FOR_OFF(c, S, (O2 + 2 * N) % NT) lam[c] = fma(al, dl[c], lam[c]); }
+        FOR_WAVE2(i, 6 * (N + 1), 1, 2) x[i] = fma(al, dx[i], x[i]);
+        FOR_WAVE(i, 2 * N, 2) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
+        if constexpr (term) { FOR_WAVE(c, S, 2) lam[c] = fma(al, dl[c], lam[c]); }
         gsum_c = 0.0;
 #pragma unroll
         for (int j = 0; j < RPL; j++) {                         // inequality rows: slack, multiplier, barrier weight, gap share
-            const int r = tid + NT * j;
-            if (r < M) {
+            const int r = slot_row(j);
+            if (r >= 0) {
                 const double tt = fma(al, dt_r[j], t_r[j]), mm = fma(ald, dm[r], m[r]);
                 const double rt = barrier_rt(tt, mm), thv = mm * rt;
                 t_r[j] = tt; m[r] = mm; rt_r[j] = rt; th[r] = thv; gsum_c = fma(tt, mm, gsum_c);
@@ -743,6 +791,11 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         }
         if (w0) gs0[lane] = gsum_c;
         if constexpr (term) { if (tid < 6) sT[tid] = fma(al, w7[tid], sT[tid]); }
+        if constexpr (TEARLY) {
+            // the next iteration's terminal factor, part A: wave 0 owns the lambda rows, so the weights it has just written are all it needs
+            // (its own LDS writes are visible to it after the wait); the Gram matrix is in Wl when the barrier below falls
+            if (w0) { WSYNC(); TSMW(180); term_partA(); }
+        }
         __syncthreads();
         if constexpr (term) eta_m = fma(ald, deta, eta_m);
         TSMW(18);
@@ -799,4 +852,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     }
 #undef FOR_OFF
 #undef FOR_HELP
+#undef FOR_WAVE
+#undef FOR_WAVE2
+#undef WCL
 }
