@@ -560,12 +560,20 @@ static void k1_grid(lmpc_ctx *c, int B, int *qg, int *nblk) {
     }
     *qg = q; *nblk = B * np;
 }
+// The regression kernel in the build that fits the launch: the occupancy build when the grid exceeds one work-group per CU, and the
+// 8-rows-per-lane scan when every lap in use lies inside its first quantisation chunk half (<= 512 rows; k1_scan_lap).
+static void launch_k1(lmpc_ctx *c, int nblk, int B, int qg, const double *xLin, int xstride, const double *uLin, double *dA, double *dB, double *dC, int *dst) {
+    bool small = true;
+    for (int i = 0; i < c->cfg.trToUse; i++) small = small && c->dp.mlen[i] - 1 <= 8 * WAVE;
+    const bool occ = nblk > c->n_cu;
+    auto k = occ ? (small ? lmpc_regress_kernel<true, 8> : lmpc_regress_kernel<true, K1_RPL>) : (small ? lmpc_regress_kernel<false, 8> : lmpc_regress_kernel<false, K1_RPL>);
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, xLin, xstride, uLin, dA, dB, dC, dst);
+}
 static int launch_regress(lmpc_ctx *c, int B, const double *d_xLin, int xstride, const double *d_uLin, double *dA, double *dB, double *dC, int *dst) {
     int rc = refresh_params(c, true, false); if (rc) return rc;
     ev_begin(c, 0);
     int qg, nblk; k1_grid(c, B, &qg, &nblk);
-    if (nblk > c->n_cu) hipLaunchKernelGGL(lmpc_regress_kernel<true>, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, d_xLin, xstride, d_uLin, dA, dB, dC, dst);
-    else hipLaunchKernelGGL(lmpc_regress_kernel<false>, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, d_xLin, xstride, d_uLin, dA, dB, dC, dst);
+    launch_k1(c, nblk, B, qg, d_xLin, xstride, d_uLin, dA, dB, dC, dst);
     ev_end(c);
     HIPCHK(hipGetLastError());
     c->stats.n_regress++;
@@ -897,10 +905,10 @@ int lmpc_debug_k1_timing(lmpc_ctx *c, int B, const double *xLin, const double *u
     const int N = c->cfg.N;
     HIPCHK(hipSetDevice(c->cfg.device));
     H2D(c->w_xLin, xLin, (size_t)B * (N + 1) * 6); H2D(c->w_uLin, uLin, (size_t)B * N * 2);
-    long long *dt; HIPCHK(hipMalloc(&dt, sizeof(long long) * 8)); HIPCHK(hipMemsetAsync(dt, 0, sizeof(long long) * 8, c->stream));
+    long long *dt; HIPCHK(hipMalloc(&dt, sizeof(long long) * 24)); HIPCHK(hipMemsetAsync(dt, 0, sizeof(long long) * 24, c->stream));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_k1_tbuf), &dt, sizeof(dt)));
     for (int rep = 0; rep < 2; rep++) { int rc = launch_regress(c, B, c->w_xLin, (N + 1) * 6, c->w_uLin, c->w_A, c->w_B, c->w_C, c->w_rstatus); if (rc) return rc; }
-    HIPCHK(hipMemcpyAsync(tbuf_host, dt, sizeof(long long) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(tbuf_host, dt, sizeof(long long) * 24, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     long long *nul = nullptr; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_k1_tbuf), &nul, sizeof(nul))); hipFree(dt);
     return LMPC_OK;
@@ -1015,10 +1023,7 @@ int lmpc_rollout_run(lmpc_ctx *c, int max_steps, int *steps_total, int *n_done) 
         rc = refresh_params(c, true, true); if (rc) return rc;
         ev_begin(c, 0);
         { int qg, nblk; k1_grid(c, B, &qg, &nblk);
-          if (nblk > c->n_cu) hipLaunchKernelGGL(lmpc_regress_kernel<true>, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, (const double *)r->d_xLin, (int)(N + 1) * 6, (const double *)r->d_uLin,
-                                                 r->d_A, r->d_B, r->d_C, r->d_rst);
-          else hipLaunchKernelGGL(lmpc_regress_kernel<false>, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, (const double *)r->d_xLin, (int)(N + 1) * 6, (const double *)r->d_uLin,
-                                  r->d_A, r->d_B, r->d_C, r->d_rst); }
+          launch_k1(c, nblk, B, qg, (const double *)r->d_xLin, (int)(N + 1) * 6, (const double *)r->d_uLin, r->d_A, r->d_B, r->d_C, r->d_rst); }
         ev_end(c); c->stats.n_regress++;
         lmpc_solve_io io; memset(&io, 0, sizeof(io));
         io.mode = 3; io.A = r->d_A; io.Bm = r->d_B; io.C = r->d_C; io.x0 = r->d_x; io.uOld = r->d_uOld; io.zt = r->d_zt; io.xPredPrev = r->d_xPP; io.hasPred = r->d_hasPred;

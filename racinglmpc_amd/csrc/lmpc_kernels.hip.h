@@ -260,16 +260,25 @@ __global__ void lmpc_global_position_kernel(lmpc_dev_params p, int n, const doub
 #define K1_PTS (K1_QG * 32)        // staged points per pass (32 per query when trToUse * MaxNumPoint <= 32; fewer queries per pass beyond: 32 laps x 8 points = 256 fit one query)
 #define K1_SEL K1_PTS              // entries of the running selection: queries x laps x MaxNumPoint of one pass
 
-template <int CTRL> __device__ __forceinline__ unsigned dpp_minu(unsigned v) {
-    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-    return o < v ? o : v;
-}
-__device__ __forceinline__ unsigned wminu(unsigned v) {                       // wave-wide unsigned minimum, all lanes
-    v = dpp_minu<DPP_QP_X1>(v); v = dpp_minu<DPP_QP_X2>(v); v = dpp_minu<DPP_HALF_MIRROR>(v); v = dpp_minu<DPP_MIRROR>(v);
-    auto r0 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    v = r0[0] < r0[1] ? r0[0] : r0[1];
-    auto r1 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return r1[0] < r1[1] ? r1[0] : r1[1];
+// smallest T such that at least K of the 64 lane values m (< 2^19) are <= T: the K-th smallest, built bit by bit; one v_cmp per round, the
+// count and the candidate live on the scalar unit (a K-round chain of wave minima cost 12 vector instructions per round)
+__device__ __forceinline__ unsigned kth_lane_value(unsigned m, int K) {
+    unsigned A = 0u;
+    if (__popcll(__ballot(m <= 0xfffu)) < K) {             // (rare: the K nearest rows of a 1024-row chunk lie within 1 / 16 of one feature's range of the query)
+#pragma unroll
+        for (int b = 18; b >= 12; b--) {
+            const unsigned t = A + ((1u << b) - 1u);
+            const int cnt = __popcll(__ballot(m <= t));
+            A = cnt < K ? A + (1u << b) : A;
+        }
+    }
+#pragma unroll
+    for (int b = 11; b >= 0; b--) {
+        const unsigned t = A + ((1u << b) - 1u);
+        const int cnt = __popcll(__ballot(m <= t));
+        A = cnt < K ? A + (1u << b) : A;
+    }
+    return A;
 }
 // inclusive prefix sum over the 64 lanes (gfx9 DPP: four shifts inside a row of 16, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
 __device__ __forceinline__ int wave_incl_scan_i32(int x) {
@@ -291,8 +300,10 @@ template <int ROT> __device__ __forceinline__ void k1_row_rank(double d, int i, 
         k1_row_rank<ROT + 1>(d, i, rank);
     }
 }
-__device__ __forceinline__ unsigned sad_u16(unsigned a, unsigned b, unsigned c) {   // |a.lo16 - b.lo16| + |a.hi16 - b.hi16| + c
-    unsigned r; asm("v_sad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+__device__ __forceinline__ unsigned sad_u16(unsigned a, unsigned b, unsigned c) {   // |a.lo16 - b.lo16| + |a.hi16 - b.hi16| + c   (v_sad_u16)
+    // (the compiler's own builtin: as inline asm every dependent pair of the 48 per query and lap was followed by a conservative s_nop, and the
+    //  three-instruction chains of the 16 rows could not be interleaved)
+    return __builtin_amdgcn_sad_u16(a, b, c);
 }
 __device__ __forceinline__ float wminf(float v) {                           // wave-wide float minimum, all lanes
 #pragma unroll
@@ -312,8 +323,11 @@ __host__ __device__ inline int k1_queries_per_block(int qg, int trToUse, int max
 // (developer build) cycle stamps of work-group 0 of the regression kernel: g_k1_tbuf[id] = cycle counter at stamp id (lmpc_debug_k1_timing)
 static __device__ long long *g_k1_tbuf;
 #define K1STAMP(id) do { if (g_k1_tbuf && blockIdx.x == 0 && threadIdx.x == 0) g_k1_tbuf[id] = (long long)__builtin_readcyclecounter(); } while (0)
+// stamps inside the scan of wave 0 (ids 8 ..): outstanding loads are waited for first, so that a stamp separates the work before it from the work after it
+#define K1WSTAMP(id) do { if (g_k1_tbuf && blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); g_k1_tbuf[id] = (long long)__builtin_readcyclecounter(); } } while (0)
 #else
 #define K1STAMP(id) do { } while (0)
+#define K1WSTAMP(id) do { } while (0)
 #endif
 
 // LDS work space of the regression: static arrays in the stand-alone kernel (8 waves per problem), a slice of the solve kernel's
@@ -324,7 +338,6 @@ struct k1_smem {
     double *seld; int *seli; int *nsel; int Ls, Sp; // [QG][Ls][Sp], [QG][Ls][Sp], [QG][Ls]: running selection per query and lap (Ls = laps in use, Sp = MaxNumPoint)
     double (*pts)[10];               // [QF PP]     vx vy wz delta a K y_vx y_vy y_wz 1   (PredictiveModel.py:141-168)
     double (*gram)[45];              // [QF]        Q_vx(15) b_vx(5) Q_lat(15) b_vy(5) b_wz(5)
-    double (*theta)[15];             // [QF]        three solutions of five coefficients
     double (*outv)[54];              // [QF]        A_i (36) | B_i (12) | C_i (6)
     int *st_s;                       // [QG]
 };
@@ -332,13 +345,15 @@ struct k1_smem {
 // computeIndices (PredictiveModel.py:180-197) of ONE wave for lap c: the lap's prefilter image is loaded once per 1024-row chunk and scanned
 // for the wave's queries qi = sgi + s nsub, s < nqw; the running selection per (query, lap) stays in sm.seld / seli / nsel.  cs0: first
 // row of this wave in sm.cseg / ccnt.  PAIR: two queries per trip (independent reduction chains interleave; 32 registers more).
-template <bool PAIR>
+// RPL: rows per lane per trip.  16 = the host's quantisation chunk (K1_CHUNK rows, own range each); 8 only when every lap in use has at
+// most 512 rows, i.e. lies in its first chunk (launch_k1): half the prefilter work and 32 registers less per wave.
+template <bool PAIR, int RPL>
 __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_smem &sm, int c, int cs0, int sgi, int nsub, int nq, int lane, int MAXP) {
     const double h = p.h;
     const double *base = p.mstore + (size_t)p.mslot[c] * LMPC_COLS * p.lap_stride;
     const int ls = p.lap_stride;
     const int nrows = p.mlen[c] - 1;
-    for (int t0 = 0; t0 < nrows; t0 += K1_CHUNK) {
+    for (int t0 = 0; t0 < nrows; t0 += RPL * WAVE) {
         // Prefilter image of this lane's rows: the scaled features in 16-bit fixed point, packed (vx, vy | wz, delta | a, flag),
         // quantised by the host when the lap was stored (lmpc_capi.hip: quantise_lap), per 1024-row chunk over the chunk's own
         // [min, max] with ONE scale for the five features (the L1 norm weighs them equally).  Three v_sad_u16 per row give the
@@ -346,42 +361,52 @@ __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_s
         // of a feature's |differences| by the same amount, so the order of the rows is untouched.  Rows beyond the lap carry
         // 0xffff in the unused half-word (the query has 0 there): farther than a full range from everything.
         const double *qp = p.mqpar + ((size_t)p.mslot[c] * p.mq_chunks + t0 / K1_CHUNK) * 6;
-        const double qlo[5] = {qp[0], qp[1], qp[2], qp[3], qp[4]}, qsc = qp[5];
+        const double qsc = qp[5];
         const unsigned *qb = p.mquant + (size_t)p.mslot[c] * 3 * ls;
-        unsigned qv[3][K1_RPL];
+        unsigned qv[3][RPL];
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int j = 0; j < K1_RPL; j++) { const int t = t0 + lane + WAVE * j; qv[k][j] = qb[(size_t)k * ls + (t < nrows ? t : 0)]; }
+            for (int j = 0; j < RPL; j++) { const int t = t0 + lane + WAVE * j; qv[k][j] = qb[(size_t)k * ls + (t < nrows ? t : 0)]; }
 #pragma unroll
-        for (int j = 0; j < K1_RPL; j++) if (t0 + lane + WAVE * j >= nrows) qv[2][j] |= 0xffff0000u;
+        for (int j = 0; j < RPL; j++) if (t0 + lane + WAVE * j >= nrows) qv[2][j] |= 0xffff0000u;
+        K1WSTAMP(8);
         // ---- step A: integer prefilter, one query at a time; survivors (row indices) go to the query's 16-slot LDS segment ----
         const int nqw = nq > sgi ? (nq - sgi + nsub - 1) / nsub : 0;                  // queries of this wave: qi = sgi + s nsub
+        // The queries in this chunk's fixed point, all at once: lane 8 s + k holds feature k of the wave's query s (s < 8 in tq0, 8 <= s < 16
+        // in tq1); the loop below fetches its five values with v_readlane (they land in SGPRs, which v_sad_u16 takes directly).  Done per
+        // query inside the loop this was 25 FP64 instructions of the ~350 per (query, lap).
+        unsigned tq0, tq1;
+        {
+            const int k = lane & 7, k5 = k < 5 ? k : 0, sa = lane >> 3, sb = sa + 8;
+            const int qa_ = sgi + (sa < nqw ? sa : 0) * nsub, qb_ = sgi + (sb < nqw ? sb : 0) * nsub;
+            const double scl = k5 == 0 ? p.scaling[0] : k5 == 1 ? p.scaling[1] : k5 == 2 ? p.scaling[2] : k5 == 3 ? p.scaling[3] : p.scaling[4];
+            const double lo = qp[k5];
+            tq0 = (unsigned)fmin(fmax((sm.qf[qa_][k5] * scl - lo) * qsc, 0.0), 65535.0);
+            tq1 = (unsigned)fmin(fmax((sm.qf[qb_][k5] * scl - lo) * qsc, 0.0), 65535.0);
+        }
         for (int s = 0; s < nqw; s += PAIR ? 2 : 1) {
             const bool two = PAIR && s + 1 < nqw;
-            const int qa = sgi + s * nsub, qb2 = two ? qa + nsub : qa;
+            const int sb2 = two ? s + 1 : s;
             unsigned ta5[5], tb5[5];
+            const unsigned tqa = s < 8 ? tq0 : tq1, tqb = sb2 < 8 ? tq0 : tq1;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                ta5[k] = (unsigned)fmin(fmax((sm.qf[qa][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 65535.0);
-                tb5[k] = (unsigned)fmin(fmax((sm.qf[qb2][k] * p.scaling[k] - qlo[k]) * qsc, 0.0), 65535.0);
+                ta5[k] = (unsigned)__builtin_amdgcn_readlane((int)tqa, (s & 7) * 8 + k);
+                tb5[k] = PAIR ? (unsigned)__builtin_amdgcn_readlane((int)tqb, (sb2 & 7) * 8 + k) : 0u;
             }
             const unsigned ya[3] = {ta5[0] | (ta5[1] << 16), ta5[2] | (ta5[3] << 16), ta5[4]};
             const unsigned yb[3] = {tb5[0] | (tb5[1] << 16), tb5[2] | (tb5[3] << 16), tb5[4]};
-            unsigned ea[K1_RPL], eb[K1_RPL], ma = 0xffffffffu, mb = 0xffffffffu;
+            unsigned ea[RPL], eb[RPL], ma = 0xffffffffu, mb = 0xffffffffu;
 #pragma unroll
-            for (int j = 0; j < K1_RPL; j++) {
+            for (int j = 0; j < RPL; j++) {
                 unsigned a_ = 0, b_ = 0;
 #pragma unroll
                 for (int k = 0; k < 3; k++) { a_ = sad_u16(qv[k][j], ya[k], a_); if (PAIR) b_ = sad_u16(qv[k][j], yb[k], b_); }
                 ea[j] = a_; eb[j] = b_; ma = a_ < ma ? a_ : ma; mb = b_ < mb ? b_ : mb;
             }
-            // MAXP-th smallest distinct lane minimum: at least MAXP rows lie at or below it (one-instruction DPP integer minima)
-            unsigned ba = 0u, bb = 0u;
-            for (int r = 0; r < MAXP; r++) {
-                ba = wminu((r == 0 || ma > ba) ? ma : 0xffffffffu);
-                if (PAIR) bb = wminu((r == 0 || mb > bb) ? mb : 0xffffffffu);
-            }
+            // MAXP-th smallest lane minimum (three v_sad_u16 of 16-bit fields: < 2^19): at least MAXP rows lie at or below it
+            const unsigned ba = kth_lane_value(ma, MAXP), bb = PAIR ? kth_lane_value(mb, MAXP) : 0u;
             // Two-sided bound.  Per feature |floor(a) - floor(b)| differs from |a - b| by < 1, so over the five features the
             // integer distance e of a row and its exact scaled distance d satisfy |e - d| < 5.  (i) At least MAXP rows have
             // e <= T (T = ba / bb), hence d < T + 5: the MAXP-th smallest exact distance is < T + 5.  (ii) A row of the exact
@@ -394,7 +419,7 @@ __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_s
             // instructions per (query, lap).  The order inside the segment changes; the exact re-rank below does not depend on it.)
             unsigned mska = 0u, mskb = 0u;
 #pragma unroll
-            for (int j = 0; j < K1_RPL; j++) { mska |= (ea[j] <= ta ? 1u : 0u) << j; if (PAIR) mskb |= (eb[j] <= tb ? 1u : 0u) << j; }
+            for (int j = 0; j < RPL; j++) { mska |= (ea[j] <= ta ? 1u : 0u) << j; if (PAIR) mskb |= (eb[j] <= tb ? 1u : 0u) << j; }
             const int ca_ = __popc(mska), cb_ = PAIR ? __popc(mskb) : 0;
             const int ia = wave_incl_scan_i32(ca_), ib = PAIR ? wave_incl_scan_i32(cb_) : 0;
             const int na = __builtin_amdgcn_readlane(ia, 63), nb = PAIR ? __builtin_amdgcn_readlane(ib, 63) : 0;
@@ -402,7 +427,9 @@ __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_s
             while (mska) { const int j = __builtin_ctz(mska); mska &= mska - 1u; if (pa < 16) sm.cseg[cs0 + s][pa] = t0 + lane + WAVE * j; pa++; }
             if (two) { while (mskb) { const int j = __builtin_ctz(mskb); mskb &= mskb - 1u; if (pb < 16) sm.cseg[cs0 + s + 1][pb] = t0 + lane + WAVE * j; pb++; } }
             if (lane == 0) { sm.ccnt[cs0 + s] = na; if (two) sm.ccnt[cs0 + s + 1] = nb; }
+            if (s == 0) K1WSTAMP(9);
         }
+        K1WSTAMP(10);
         // ---- step B: exact FP64 distances of the survivors, four queries at a time (one per row of 16 lanes), ranked inside the
         //      row by 15 DPP rotations; the running selection of earlier chunks rides along as extra entries ----
         for (int s0 = 0; s0 < nqw; s0 += 4) {
@@ -427,6 +454,7 @@ __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_s
                     dv = real ? nrm : INFINITY;
                 } else if (r < cnt + ns) { dv = sd[r - cnt]; iv = si[r - cnt]; }
             }
+            if (s0 == 0) K1WSTAMP(11);
             const bool in_h = dv < h;
             const double kd = in_h ? dv : INFINITY;                                   // rows outside h never outrank anything
             int rank = 0;
@@ -437,6 +465,7 @@ __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_s
                 if (in_h && rank < MAXP) { sd[rank] = dv; si[rank] = iv; }
                 if (r == 0) sm.nsel[qi * sm.Ls + c] = nin < MAXP ? nin : MAXP;
             }
+            if (s0 == 0) K1WSTAMP(12);
             // prefilter overflow (massive ties): MAXP rounds of exact arg-min extraction over the chunk + running selection
             unsigned long long mo = __ballot(live && ovf && r == 0);
             while (mo) {
@@ -450,7 +479,7 @@ __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_s
                 for (int rr = 0; rr < MAXP; rr++) {
                     double bd = INFINITY; int bi = 0x7fffffff;
                     if (k1_less(pd, pi, od, oi)) { bd = od; bi = oi; }
-                    for (int j = 0; j < K1_RPL; j++) {
+                    for (int j = 0; j < RPL; j++) {
                         const int tj = t0 + lane + WAVE * j;
                         if (tj < nrows) {
                             double nrm = fabs((base[0 * ls + tj] - x0) * p.scaling[0]);
@@ -470,6 +499,7 @@ __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_s
                 if (lane == 0) sm.nsel[qj * sm.Ls + c] = got;
             }
         }
+        K1WSTAMP(13);
     }
 }
 
@@ -479,6 +509,36 @@ __device__ __forceinline__ void k1_scan_lap(const lmpc_dev_params &p, const k1_s
 __device__ __forceinline__ void k1_fit(const lmpc_dev_params &p, const k1_smem &sm, int q0, int nf, int tid, int nt, const double *xq_pass, int MAXP) {
     const int L = p.trToUse, PP = L * MAXP;
     const double h = p.h;
+    // ---- assemble A_i, B_i, C_i (:70-135), one thread per query.  The kinematic rows (epsi, s, ey) depend on the query state only: they are
+    //      written by the last wave, which has no points to stage, while the others do (cos, sin and the divisions are a ~3400-cycle
+    //      chain; the one-wave fused step has no spare wave and runs them in turn).  Every entry of outv is written exactly once:
+    //      rows 3-5 of A_i and C_i and the zero rows of B_i here, rows 0-2 by the threads that solve for them below ----
+    const int at0 = nt > WAVE ? nt - WAVE : 0;
+    if (tid >= at0 && tid < at0 + nf) {
+        const int ql = tid - at0, qi = q0 + ql;
+        const double *xq = xq_pass + (size_t)qi * 6;
+        double *Ai = sm.outv[ql], *Ci = sm.outv[ql] + 48;
+        for (int j = 0; j < 6; j++) sm.outv[ql][36 + 6 + j] = 0.0;
+        const double vx = xq[0], vy = xq[1], wz = xq[2], epsi = xq[3], s = xq[4], ey = xq[5], dt = p.dt;
+        int bad = 0;
+        const double cur = track_curvature(p, s, &bad);
+        if (bad) atomicOr(&sm.st_s[qi], LMPC_ST_NO_SEGMENT);
+        const double den = 1 - cur * ey, ce = cos(epsi), se = sin(epsi);
+        const double xv[6] = {vx, vy, wz, epsi, s, ey};
+        double row[6], dot;
+        row[0] = -dt * ce / den * cur; row[1] = dt * se / den * cur; row[2] = dt;
+        row[3] = 1 - dt * (-vx * se - vy * ce) / den * cur; row[4] = 0;
+        row[5] = dt * (vx * ce - vy * se) / (den * den) * cur * (-cur);
+        dot = 0; for (int j = 0; j < 6; j++) { Ai[18 + j] = row[j]; dot += row[j] * xv[j]; }
+        Ci[3] = epsi + dt * (wz - (vx * ce - vy * se) / (1 - cur * ey) * cur) - dot;
+        row[0] = dt * (ce / den); row[1] = -dt * (se / den); row[2] = 0; row[3] = dt * (-vx * se - vy * ce) / den; row[4] = 1;
+        row[5] = -dt * (vx * ce - vy * se) / (den * den) * (-cur);
+        dot = 0; for (int j = 0; j < 6; j++) { Ai[24 + j] = row[j]; dot += row[j] * xv[j]; }
+        Ci[4] = s + dt * ((vx * ce - vy * se) / (1 - cur * ey)) - dot;
+        row[0] = dt * se; row[1] = dt * ce; row[2] = 0; row[3] = dt * (vx * ce - vy * se); row[4] = 0; row[5] = 1;
+        dot = 0; for (int j = 0; j < 6; j++) { Ai[30 + j] = row[j]; dot += row[j] * xv[j]; }
+        Ci[5] = ey + dt * (vx * se + vy * ce) - dot;
+    }
     // ---- stage the selected points: slot = lap * MAXP + rank; empty slots carry weight K = 0 (they add exact zeros) ----
     for (int e = tid; e < nf * PP; e += nt) {
         const int ql = e / PP, qi = q0 + ql, sl = e % PP, c = sl / MAXP, r = sl % MAXP;
@@ -542,78 +602,53 @@ __device__ __forceinline__ void k1_fit(const lmpc_dev_params &p, const k1_smem &
             double dj = Lm[j][j];
             for (int k = 0; k < j; k++) dj -= Lm[j][k] * Lm[j][k];
             if (!(dj > 0.0)) { bad = 1; dj = 1.0; }
-            dj = sqrt(dj); Lm[j][j] = dj;
+            // the diagonal is kept as 1 / L_jj (hardware estimate + two Newton steps, ~1 ulp): the 20 IEEE divisions and 5 square roots of the
+            // textbook form were a dependent chain of ~2000 cycles on three lanes per query while the rest of the work-group waits
+            const double inv = frsqrt(dj); Lm[j][j] = inv;
             for (int r = j + 1; r < 5; r++) {
                 double v = Lm[r][j];
                 for (int k = 0; k < j; k++) v -= Lm[r][k] * Lm[j][k];
-                Lm[r][j] = v / dj;
+                Lm[r][j] = v * inv;
             }
         }
         double y[5];
-        for (int r = 0; r < 5; r++) { double v = -bv[r]; for (int k = 0; k < r; k++) v -= Lm[r][k] * y[k]; y[r] = v / Lm[r][r]; }
-        for (int r = 4; r >= 0; r--) { double v = y[r]; for (int k = r + 1; k < 5; k++) v -= Lm[k][r] * y[k]; y[r] = v / Lm[r][r]; }
-        for (int r = 0; r < 5; r++) sm.theta[ql][sy * 5 + r] = bad ? 0.0 : y[r];
+        for (int r = 0; r < 5; r++) { double v = -bv[r]; for (int k = 0; k < r; k++) v -= Lm[r][k] * y[k]; y[r] = v * Lm[r][r]; }
+        for (int r = 4; r >= 0; r--) { double v = y[r]; for (int k = r + 1; k < 5; k++) v -= Lm[k][r] * y[k]; y[r] = v * Lm[r][r]; }
+        // theta -> row sy of A_i, B_i, C_i (:70-135: vx is driven by a, vy and wz by delta)
+        double *Ai = sm.outv[ql], *Bi = sm.outv[ql] + 36, *Ci = sm.outv[ql] + 48;
+        for (int r = 0; r < 5; r++) y[r] = bad ? 0.0 : y[r];
+        Ai[sy * 6 + 0] = y[0]; Ai[sy * 6 + 1] = y[1]; Ai[sy * 6 + 2] = y[2]; Ai[sy * 6 + 3] = 0.0; Ai[sy * 6 + 4] = 0.0; Ai[sy * 6 + 5] = 0.0; Ci[sy] = y[4];
+        Bi[sy * 2 + (sy == 0 ? 1 : 0)] = y[3]; Bi[sy * 2 + (sy == 0 ? 0 : 1)] = 0.0;
         int npts = 0;
         for (int c = 0; c < L; c++) npts += sm.nsel[qi * sm.Ls + c];
         if (bad || npts < 5) atomicOr(&sm.st_s[qi], LMPC_ST_REG_SINGULAR);
     }
-    for (int e = tid; e < nf * 54; e += nt) sm.outv[e / 54][e % 54] = 0.0;
     __syncthreads();
     K1STAMP(5);
-
-    // ---- assemble A_i, B_i, C_i (:70-135), one thread per query ------------------------------------------------------
-    if (tid < nf) {
-        const int ql = tid, qi = q0 + ql;
-        const double *xq = xq_pass + (size_t)qi * 6;
-        const double *th_ = sm.theta[ql];
-        double *Ai = sm.outv[ql], *Bi = sm.outv[ql] + 36, *Ci = sm.outv[ql] + 48;
-        for (int r = 0; r < 3; r++) { Ai[r * 6 + 0] = th_[r * 5 + 0]; Ai[r * 6 + 1] = th_[r * 5 + 1]; Ai[r * 6 + 2] = th_[r * 5 + 2]; Ci[r] = th_[r * 5 + 4]; }
-        Bi[0 * 2 + 1] = th_[0 * 5 + 3]; Bi[1 * 2 + 0] = th_[1 * 5 + 3]; Bi[2 * 2 + 0] = th_[2 * 5 + 3];
-        const double vx = xq[0], vy = xq[1], wz = xq[2], epsi = xq[3], s = xq[4], ey = xq[5], dt = p.dt;
-        int bad = 0;
-        const double cur = track_curvature(p, s, &bad);
-        if (bad) atomicOr(&sm.st_s[qi], LMPC_ST_NO_SEGMENT);
-        const double den = 1 - cur * ey, ce = cos(epsi), se = sin(epsi);
-        const double xv[6] = {vx, vy, wz, epsi, s, ey};
-        double row[6], dot;
-        row[0] = -dt * ce / den * cur; row[1] = dt * se / den * cur; row[2] = dt;
-        row[3] = 1 - dt * (-vx * se - vy * ce) / den * cur; row[4] = 0;
-        row[5] = dt * (vx * ce - vy * se) / (den * den) * cur * (-cur);
-        dot = 0; for (int j = 0; j < 6; j++) { Ai[18 + j] = row[j]; dot += row[j] * xv[j]; }
-        Ci[3] = epsi + dt * (wz - (vx * ce - vy * se) / (1 - cur * ey) * cur) - dot;
-        row[0] = dt * (ce / den); row[1] = -dt * (se / den); row[2] = 0; row[3] = dt * (-vx * se - vy * ce) / den; row[4] = 1;
-        row[5] = -dt * (vx * ce - vy * se) / (den * den) * (-cur);
-        dot = 0; for (int j = 0; j < 6; j++) { Ai[24 + j] = row[j]; dot += row[j] * xv[j]; }
-        Ci[4] = s + dt * ((vx * ce - vy * se) / (1 - cur * ey)) - dot;
-        row[0] = dt * se; row[1] = dt * ce; row[2] = 0; row[3] = dt * (vx * ce - vy * se); row[4] = 0; row[5] = 1;
-        dot = 0; for (int j = 0; j < 6; j++) { Ai[30 + j] = row[j]; dot += row[j] * xv[j]; }
-        Ci[5] = ey + dt * (vx * se + vy * ce) - dot;
-    }
-    __syncthreads();
     K1STAMP(6);
 }
 
 // OCC: compile for four waves per SIMD (two work-groups per CU; <= 128 VGPRs) -- pays when the grid exceeds one work-group
 // per CU (1.47x at batch 4096); the other variant has the shorter latency when each CU runs a single group.
-template <bool OCC>
-__global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_dev_params p, int B, int qg, const double *__restrict__ xLin, int xstride,
+template <bool OCC, int RPL>
+__global__ __launch_bounds__(K1_NT, OCC ? (RPL <= 8 ? 6 : 4) : 2) void lmpc_regress_kernel(lmpc_dev_params p, int B, int qg, const double *__restrict__ xLin, int xstride,
                                                              const double *__restrict__ uLin, double *__restrict__ Aout,
                                                              double *__restrict__ Bout, double *__restrict__ Cout, int *__restrict__ status) {
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);             // wave-uniform by construction: lap pointers, row counts and loop bounds stay in SGPRs
     __shared__ double qf[K1_QG][5];
-    __shared__ int cseg[K1_NW * K1_QG][16]; __shared__ int ccnt[K1_NW * K1_QG];
+    __shared__ __attribute__((aligned(16))) int cseg[K1_NW * K1_QG][16]; __shared__ int ccnt[K1_NW * K1_QG];
     // running selection per (query, lap): queries x laps x MaxNumPoint <= K1_PTS entries whatever the split (k1_queries_per_block keeps
     // queries x laps x MaxNumPoint <= K1_PTS, or one query per block when a single query's laps x MaxNumPoint exceed it: K1_PTS_MAX)
     __shared__ double seld[K1_SEL]; __shared__ int seli[K1_SEL];
     __shared__ int nsel[K1_SEL];
     __shared__ double pts[K1_PTS][10];
     __shared__ double gram[K1_QG][45];
-    __shared__ double theta[K1_QG][15];
-    __shared__ double outv[K1_QG][54];
+    static_assert(sizeof(cseg) >= sizeof(double) * K1_QG * 54, "outv lives in cseg");
+    double (*outv)[54] = (double (*)[54])cseg;          // A_i | B_i | C_i of the fit: the scan's survivor lists are dead by then (three work-groups per CU fit 160 KB of LDS this way)
     __shared__ int st_s[K1_QG];
     k1_smem sm; sm.qf = qf; sm.cseg = cseg; sm.ccnt = ccnt; sm.seld = seld; sm.seli = seli; sm.nsel = nsel; sm.Ls = p.trToUse; sm.Sp = p.maxNumPoint > 8 ? 8 : p.maxNumPoint;
-    sm.pts = pts; sm.gram = gram; sm.theta = theta; sm.outv = outv; sm.st_s = st_s;
+    sm.pts = pts; sm.gram = gram; sm.outv = outv; sm.st_s = st_s;
 
     const int N = p.N, L = p.trToUse;
     const int MAXP = p.maxNumPoint > 8 ? 8 : p.maxNumPoint;
@@ -638,7 +673,7 @@ __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_d
     //  fill the chain's latency, and the second query's 16 distances cost registers it does not have -- spilled registers are scratch
     //  WRITES: 134 MB per launch at batch 4096 before this)
     for (int c = myc; c < L && sgi < nsub; c += K1_NW)                    // (c += K1_NW: more laps than waves -- trToUse up to 32 -- a wave then scans several laps in turn)
-        k1_scan_lap<!OCC>(p, sm, c, wave * K1_QG, sgi, nsub, nq, lane, MAXP);
+        k1_scan_lap<!OCC, RPL>(p, sm, c, wave * K1_QG, sgi, nsub, nq, lane, MAXP);
     __syncthreads();
     K1STAMP(2);
     k1_fit(p, sm, 0, nq, tid, K1_NT, xLin + (size_t)b * xstride + (size_t)i0 * 6, MAXP);
@@ -658,7 +693,7 @@ __global__ __launch_bounds__(K1_NT, OCC ? 4 : 2) void lmpc_regress_kernel(lmpc_d
 __host__ __device__ constexpr inline int k1_fused_doubles(int N, int L, int maxNumPoint) {
     const int QG = N < K1_QG ? N : K1_QG, MAXP = maxNumPoint > 8 ? 8 : maxNumPoint, PP = L * MAXP;
     const int ints = QG * 16 + QG + QG * L * 8 + QG * L + QG;                                  // cseg, ccnt, seli, nsel, st_s
-    return QG * 5 + QG * L * 8 + (ints + 1) / 2 + K1F_QF * (PP * 10 + 45 + 15 + 54);
+    return QG * 5 + QG * L * 8 + (ints + 1) / 2 + K1F_QF * (PP * 10 + 45 + 54);
 }
 // PredictiveModel.regressionAndLinearization for the N horizon points of problem b by the calling wave (block of one wave): results go to
 // AB / C in LDS in the solve kernel's layout (and to global memory if the pointers are given); returns the OR of the points' status bits.
@@ -673,7 +708,6 @@ __device__ __forceinline__ int k1_wave_problem(const lmpc_dev_params &p, int b, 
     sm.seld = w; w += QG * L * 8;
     sm.pts = (double (*)[10])w; w += K1F_QF * PP * 10;
     sm.gram = (double (*)[45])w; w += K1F_QF * 45;
-    sm.theta = (double (*)[15])w; w += K1F_QF * 15;
     sm.outv = (double (*)[54])w; w += K1F_QF * 54;
     int *wi = (int *)w;
     sm.cseg = (int (*)[16])wi; wi += QG * 16;
@@ -691,7 +725,7 @@ __device__ __forceinline__ int k1_wave_problem(const lmpc_dev_params &p, int b, 
         for (int e = lane; e < nq * L; e += WAVE) sm.nsel[e] = 0;
         if (lane < nq) sm.st_s[lane] = 0;
         __syncthreads();
-        for (int c = 0; c < L; c++) k1_scan_lap<true>(p, sm, c, 0, 0, 1, nq, lane, MAXP);
+        for (int c = 0; c < L; c++) k1_scan_lap<true, K1_RPL>(p, sm, c, 0, 0, 1, nq, lane, MAXP);
         __syncthreads();
         for (int q0 = 0; q0 < nq; q0 += K1F_QF) {
             const int nf = nq - q0 < K1F_QF ? nq - q0 : K1F_QF;

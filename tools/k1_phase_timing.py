@@ -17,7 +17,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 g = bench.load_seed()
 ctx = bench.make_ctx(g, 12, B, 0)
 inp = bench.synth_batch(g, B, 12)
-tb = np.zeros(8, np.int64)
+tb = np.zeros(24, np.int64)
 f = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data_as(C.c_void_p)
 rc = ctx.lib.lmpc_debug_k1_timing(ctx._h, C.c_int(B), f(inp["xLin"]), f(inp["uLin"]), tb.ctypes.data_as(C.c_void_p))
 assert rc == 0, ctx.lib.lmpc_last_error()
@@ -26,3 +26,8 @@ names = ["load queries", "scan (computeIndices: prefilter + exact re-rank)", "st
 print("regression kernel, batch %d, work-group 0: %d cycles" % (B, tb[7] - tb[0]))
 for i, n in enumerate(names):
     print("  %-55s %7d" % (n, tb[i + 1] - tb[i]))
+if tb[8]:
+    print("  inside the scan of wave 0 (one lap, its share of the queries; loads drained at every stamp):")
+    for a, b_, n in ((1, 8, "load the lap's prefilter image"), (8, 9, "step A, first trip (one query; two in the low-occupancy build)"), (9, 10, "step A, remaining trips"),
+                     (10, 11, "step B, first trip of four queries: survivors' exact distances"), (11, 12, "step B, first trip: rank and store"), (12, 13, "step B, remaining trips"), (13, 2, "wait for the other waves")):
+        print("    %-70s %7d" % (n, tb[b_] - tb[a]))
