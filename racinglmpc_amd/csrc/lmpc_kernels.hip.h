@@ -117,10 +117,13 @@ __device__ __forceinline__ void flag_retry(const lmpc_solve_io &io, int st) {
 #endif
 
 // ---- cross-lane primitives (gfx950): DPP inside a row of 16 lanes, v_permlane16/32_swap across rows ----
+// (CTRL: full permutations only -- quad_perm, row mirrors, row rotations -- every lane has a source; bound_ctrl then changes nothing in the result
+//  and tells the compiler that the old value is dead: written with old = src, every move was a v_mov_b32 + v_mov_b32_dpp pair)
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+    static_assert(CTRL <= 0xFF || (CTRL >= 0x121 && CTRL <= 0x12F) || CTRL == 0x140 || CTRL == 0x141, "dpp_mov: full permutations only");
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // returns (a, b): a = v with odd rows replaced by the partner's even rows, b = the complementary half
@@ -295,7 +298,7 @@ __device__ __forceinline__ bool k1_less(double da, int ia, double db, int ib) { 
 template <int ROT> __device__ __forceinline__ void k1_row_rank(double d, int i, int &rank) {
     if constexpr (ROT < 16) {
         const double od = dpp_mov<0x120 + ROT>(d);
-        const int oi = __builtin_amdgcn_update_dpp(i, i, 0x120 + ROT, 0xf, 0xf, false);
+        const int oi = __builtin_amdgcn_update_dpp(0, i, 0x120 + ROT, 0xf, 0xf, true);
         rank += k1_less(od, oi, d, i) ? 1 : 0;
         k1_row_rank<ROT + 1>(d, i, rank);
     }

@@ -132,7 +132,7 @@ def kkt_solve(qp, f, th_lane, th_s, gx, gu, gs, h_lane, h_u, h_s, gl, re_dyn, re
     return dx, du, ds, dl
 
 
-def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True, polish=None, pex=None, so_w=1.0):
+def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True, polish=None, pex=None, so_w=1.0, start=None):
     """Returns dict(x,u,s,lam,sT, mu (ineq duals in reference row order), iters, gap, rd, re).
     exact_nu (round 3): the multipliers of the dynamics rows are not iterates of their own; every iteration takes them from the adjoint recursion
     nu_{k-1} = A_k' nu_k - w_k (w_k: gradient of the state rows' other terms), so the x rows of the dual residual vanish identically and the
@@ -144,6 +144,10 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
     T = np.diag(2 * par.QterminalSlack) if qp.term else None
     # ---- strictly interior start
     x = np.zeros((N + 1, 6)); u = np.zeros((N, 2)); x[0] = qp.x0
+    start = start or {}
+    if start.get("u") == "uold":                                             # (experiment: the previous input held over the horizon, pulled inside the box)
+        ub = np.array([bu[0], bu[2]]) * start.get("shrink", 0.9)
+        u[:] = np.clip(qp.uOld, -ub, ub)
     for k in range(N):
         x[k + 1] = A[k] @ x[k] + B[k] @ u[k] + C[k]
     viol = x[:N] @ Fx.T - bx
@@ -154,7 +158,7 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         fl = x[:N] @ Fx.T
         return bx - (fl - s), bu - u @ Fu.T, s.copy(), lam.copy()
     t_lane, t_u, t_s, t_l = slacks()
-    mu0 = max(1.0, 0.01 * (np.max(np.abs(qp.Qsel)) if qp.term else 1.0))
+    mu0 = max(1.0, 0.01 * (np.max(np.abs(qp.Qsel)) if qp.term else 1.0)) * start.get("mu_scale", 1.0)
     m_lane, m_u, m_s, m_l = mu0 / t_lane, mu0 / t_u, mu0 / t_s, (mu0 / t_l if qp.term else np.zeros(0))
     mtot = 8 * N + S
     info = {}
