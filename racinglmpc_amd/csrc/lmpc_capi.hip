@@ -101,9 +101,12 @@ struct lmpc_ctx {
 #ifdef LMPC_DEV_FAST
 // developer build (racinglmpc_amd.build.build_flavour("dev", ["LMPC_DEV_FAST"])): only the N = 12 variants, seconds to compile; LMPC_FORCE_NW=<1|2|4>
 // picks the waves per QP at every batch size (1 = the one-wave kernel)
+#ifndef LMPC_DEV_N
+#define LMPC_DEV_N 12
+#endif
 static bool builtin_variant(lmpc_variant_api *v, int n, int s) {
-    if (n == 12 && s == 48) return lmpc_variant_fill<12, 48>(v);
-    return n == 12 && s == 0 && lmpc_variant_fill<12, 0>(v);
+    if (n == LMPC_DEV_N && s == 48) return lmpc_variant_fill<LMPC_DEV_N, 48>(v);
+    return n == LMPC_DEV_N && s == 0 && lmpc_variant_fill<LMPC_DEV_N, 0>(v);
 }
 #else
 template <int N, int S> static bool try_builtin(lmpc_variant_api *v, int n, int s) { return n == N && s == S && lmpc_variant_fill<N, S>(v); }

@@ -117,10 +117,13 @@ __device__ __forceinline__ void flag_retry(const lmpc_solve_io &io, int st) {
 #endif
 
 // ---- cross-lane primitives (gfx950): DPP inside a row of 16 lanes, v_permlane16/32_swap across rows ----
-// (old = src, bound_ctrl off: a lane whose source lane is switched off by EXEC keeps its own value, so that a max / min reduction inside a
-//  partially active region still returns the maximum / minimum over the active lanes.  Round 4 tried bound_ctrl with old = 0 -- the compiler
-//  then drops the v_mov_b32 that pairs with every v_mov_b32_dpp, 3100 instructions in the library, 1 % per Newton step -- and the N = 40 kernel
-//  took 12.4 instead of 11.0 iterations and three times as long: some reduction there runs under a partial EXEC and read zeros from the inactive lanes.)
+// (old = src, bound_ctrl off: a lane whose source lane is switched off by EXEC keeps its own value.  Round 4 tried bound_ctrl with old = 0 -- the
+//  compiler then drops the v_mov_b32 that pairs with every v_mov_b32_dpp, 3100 instructions in the library, 1 % per Newton step -- and the N = 40
+//  kernel with [A_k | B_k] in global memory took 12.4 instead of 11.0 iterations and three times as long, every certificate still green.  Bisected with
+//  -DLMPC_DPP_BC=<bits> (below): each reduction alone is indifferent to the change, sum_over_c and sum_over_g TOGETHER (the register sweeps of
+//  kkt_solve, unrolled 40 times around exec-masked stores, in a kernel that keeps 190 registers in AGPRs) reproduce it, and only in that kernel: not the
+//  semantics of the move but what the compiler makes of that kernel without the copies.  The moves stay as they were; the N = 40 iteration statistics
+//  are asserted in tests/test_gpu_certificates.py.)
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
@@ -156,14 +159,24 @@ __device__ __forceinline__ double rdlane(double v, int src) {       // wave-unif
 #define DPP_QP_X2 0x4E          // quad_perm [2,3,0,1]
 #define DPP_HALF_MIRROR 0x141
 #define DPP_MIRROR 0x140
-struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
-struct OpMax { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
-struct OpMin { __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); } };
+struct OpSum { static constexpr int bit = 1; __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+struct OpMax { static constexpr int bit = 2; __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
+struct OpMin { static constexpr int bit = 4; __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); } };
+#ifdef LMPC_DPP_BC      // (developer experiment, see dpp_mov: bound_ctrl moves at the sites whose bit is set -- 1 / 2 / 4 wave sum / max / min, 8 sum_over_c, 16 sum_over_g, 32 / 64 K1's rank rotations)
+template <int CTRL> __device__ __forceinline__ double dpp_mov_bc(double v) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true));
+}
+#define DPP_RED(CTRL, v) ((LMPC_DPP_BC & Op::bit) ? dpp_mov_bc<CTRL>(v) : dpp_mov<CTRL>(v))
+#define DPP_SITE(BIT, CTRL, v) ((LMPC_DPP_BC & (BIT)) ? dpp_mov_bc<CTRL>(v) : dpp_mov<CTRL>(v))
+#else
+#define DPP_RED(CTRL, v) dpp_mov<CTRL>(v)
+#define DPP_SITE(BIT, CTRL, v) dpp_mov<CTRL>(v)
+#endif
 template <class Op> __device__ __forceinline__ double wave_allreduce(double v, Op op) {
-    v = op(v, dpp_mov<DPP_QP_X1>(v));
-    v = op(v, dpp_mov<DPP_QP_X2>(v));
-    v = op(v, dpp_mov<DPP_HALF_MIRROR>(v));
-    v = op(v, dpp_mov<DPP_MIRROR>(v));
+    v = op(v, DPP_RED(DPP_QP_X1, v));
+    v = op(v, DPP_RED(DPP_QP_X2, v));
+    v = op(v, DPP_RED(DPP_HALF_MIRROR, v));
+    v = op(v, DPP_RED(DPP_MIRROR, v));
     double a, b;
     swap16(v, a, b); v = op(a, b);
     swap32(v, a, b); v = op(a, b);
@@ -298,8 +311,12 @@ __device__ __forceinline__ bool k1_less(double da, int ia, double db, int ib) { 
 // rank of (d, i) among the 16 entries of its row of lanes, lexicographic: every other lane's entry passes by once
 template <int ROT> __device__ __forceinline__ void k1_row_rank(double d, int i, int &rank) {
     if constexpr (ROT < 16) {
-        const double od = dpp_mov<0x120 + ROT>(d);
+        const double od = DPP_SITE(32, 0x120 + ROT, d);
+#if defined(LMPC_DPP_BC) && (LMPC_DPP_BC & 64)
+        const int oi = __builtin_amdgcn_update_dpp(0, i, 0x120 + ROT, 0xf, 0xf, true);
+#else
         const int oi = __builtin_amdgcn_update_dpp(i, i, 0x120 + ROT, 0xf, 0xf, false);
+#endif
         rank += k1_less(od, oi, d, i) ? 1 : 0;
         k1_row_rank<ROT + 1>(d, i, rank);
     }
@@ -995,11 +1012,11 @@ __device__ __forceinline__ double wave_uniform(double v) {
 
 // sum over the 8 lanes of a group (lane = 8 g + c, all lanes of the group receive it) / over the 8 groups (same c)
 __device__ __forceinline__ double sum_over_c(double v) {
-    v += dpp_mov<DPP_QP_X1>(v); v += dpp_mov<DPP_QP_X2>(v); v += dpp_mov<DPP_HALF_MIRROR>(v);
+    v += DPP_SITE(8, DPP_QP_X1, v); v += DPP_SITE(8, DPP_QP_X2, v); v += DPP_SITE(8, DPP_HALF_MIRROR, v);
     return v;
 }
 __device__ __forceinline__ double sum_over_g(double v) {
-    v += dpp_mov<0x128>(v);                 // row_ror:8  (lane c <-> c+8 inside a row of 16)
+    v += DPP_SITE(16, 0x128, v);                 // row_ror:8  (lane c <-> c+8 inside a row of 16)
     double a, b;
     swap16(v, a, b); v = a + b;
     swap32(v, a, b); v = a + b;
