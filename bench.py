@@ -188,22 +188,18 @@ def cpu_baseline(N, B, seconds=6.0, max_procs=None):
     import multiprocessing as mp
     n1, t1 = _cpu_worker((0, min(seconds, 3.0), N, B))
     one = n1 / t1
-    cores = min(os.cpu_count() or 1, max_procs or (os.cpu_count() or 1))      # every host core, one single-threaded process each
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(i * 7, seconds, N, B) for i in range(cores)])
-    done = sum(r[0] for r in res); busy = max(r[1] for r in res)
-    fewer = None
-    if cores > 64:      # (round 4: 256 processes on the GPU box's 256 hardware threads measured 1351 steps/s, 64 processes 2330 -- both are reported)
-        with mp.get_context("fork").Pool(64) as pool:
-            res64 = pool.map(_cpu_worker, [(i * 7, min(seconds, 4.0), N, B) for i in range(64)])
-        d64 = sum(r[0] for r in res64); b64 = max(r[1] for r in res64)
-        fewer = {"value": d64 / b64, "unit": "solves/s", "cores": 64, "sample": "%d steps in %.1f s on 64 single-threaded processes" % (d64, b64)}
-    out = dict(value=done / busy, unit="solves/s", cores=cores, kind="port",
-               sample="%d full steps (a3-a19, restated OSQP eps=1e-3 + polish) of the bench batch in %.1f s on %d single-threaded processes "
-                      "(host has %d cores)" % (done, busy, cores, os.cpu_count() or 1),
-               single_core={"value": one, "unit": "solves/s", "cores": 1, "sample": "%d steps in %.1f s" % (n1, t1)})
-    if fewer:
-        out["fewer_processes"] = fewer
+    ncpu = os.cpu_count() or 1
+    legs = []                                        # one single-threaded process per core: first on at most 64 cores, then on every hardware thread of the box
+    for cores in sorted({min(ncpu, max_procs or ncpu, 64), min(ncpu, max_procs or ncpu)}):
+        budget = seconds if cores <= 64 else min(seconds, 4.0)
+        with mp.get_context("fork").Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(i * 7, budget, N, B) for i in range(cores)])
+        done = sum(r[0] for r in res); busy = max(r[1] for r in res)
+        legs.append({"value": done / busy, "unit": "solves/s", "cores": cores,
+                     "sample": "%d full steps (a3-a19, restated OSQP eps=1e-3 + polish) of the bench batch in %.1f s on %d single-threaded processes" % (done, busy, cores)})
+    best = max(legs, key=lambda l: l["value"])       # (round 4: 256 processes on the box's 256 hardware threads run SLOWER than 64 -- both legs are in the line, the better one is `value`)
+    out = dict(value=best["value"], unit="solves/s", cores=best["cores"], kind="port", sample=best["sample"] + " (host has %d hardware threads)" % ncpu,
+               legs=legs, single_core={"value": one, "unit": "solves/s", "cores": 1, "sample": "%d steps in %.1f s" % (n1, t1)})
     ref = os.path.join(ROOT, "profiles", "cpu_reference.json")
     if os.path.exists(ref):
         try:   # the reference's OWN classes timed in the build container (different box: /root/reference does not exist here)

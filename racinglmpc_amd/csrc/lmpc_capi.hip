@@ -212,6 +212,9 @@ static int create_body(lmpc_ctx *c) {
     // safe sets wider than 58 points (several terminal-block columns per lane): the two-wave kernel is built for one wave per SIMD
     // (two QPs per CU), so its regime ends at two QPs per CU
     if (cfg->numSS_it > 0 && cfg->numSS_points + 6 > WAVE && c->mw2_max_batch > 2 * c->n_cu) c->mw2_max_batch = 2 * c->n_cu;
+    // ... and never beyond what is resident at once: a second round of two-wave work-groups loses to the one-wave kernel (N = 12, batch 1024,
+    // solve kernel: 0.425 ms in two rounds against 0.349 ms; round 4 found it out the hard way -- 512 bytes more static LDS, three QPs per CU instead of four)
+    if (c->var.occ_mw2 > 0 && c->mw2_max_batch > c->var.occ_mw2 * c->n_cu) c->mw2_max_batch = c->var.occ_mw2 * c->n_cu;
     if (c->var.lds_mw == 0) { c->mw_max_batch = 0; c->mw2_max_batch = 0; }        // (a variant without multi-wave kernels)
     if (const char *e = getenv("LMPC_MW2_MAX_BATCH")) c->mw2_max_batch = atoi(e);        // (experiments)
     // Fused step (regression inside the one-wave solve kernel): bit-identical results, 42 MB less HBM traffic per step at batch 4096, but

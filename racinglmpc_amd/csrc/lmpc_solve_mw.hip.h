@@ -53,11 +53,14 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     double *par = sm + LL::opar;
     const double *Fx = par + PAR_FX, *Fu = par + PAR_FU, *bx = par + PAR_BX, *bu = par + PAR_BU, *Q2 = par + PAR_Q2, *Qf2 = par + PAR_QF2,
                  *R2 = par + PAR_R2, *dR2 = par + PAR_DR2, *T2p = par + PAR_T2, *xRef = par + PAR_XREF;
-    __shared__ double red[12 * 4];                           // cross-wave reduction slots
+    __shared__ double red[10 * 4];                           // cross-wave reduction slots
     __shared__ double phi_sh[8 * N];
-    __shared__ double dump_sh[WAVE];                         // wave 0's lanes that have nothing to store in a stage of the recursion store here (no exec-mask region on the chain)
     __shared__ int st_sh, bad_sh;
     __shared__ double gs0[WAVE];                             // wave 0's per-lane share of sum t mu (it does not take part in the residual reductions)
+    // wave 0's lanes that have nothing to store in a stage of the recursion store here (no exec-mask region on the chain).  Same words as gs0, which is
+    // written in the step phase and read in phase 1, i.e. dead during the recursion: with 512 bytes of its own the kernel's LDS was 41 496 bytes and
+    // the fourth QP of the two-wave kernel no longer fitted a CU (163 840 / 4 = 40 960) -- batch 1024 ran in two rounds, 2.85 -> 2.18 M steps/s.
+    double *const dump_sh = gs0;
     __shared__ int sel_start[LMPC_MAX_USED_LAPS];
     __shared__ double ss_rowsum[6];                          // sum over the selected safe-set points of each state (loop invariant)
     double *phi = phi_sh;
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             }
         }
         red_put(7, wmin(apx)); red_put(8, wmin(adx));
-        if constexpr (term) red_put(10, wsum(dsum));
+        if constexpr (term) red_put(9, wsum(dsum));
         if constexpr (term) { if (wave == NW - 1) ss_times<S>(SS, dl, dx + N * 6, w7, lane); }          // d s_T
         __syncthreads();
         const double frac = step_fraction(sig, gap);
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         // terms above, the third is sum_j T_j ds_T[j] (sum_c SS[j][c]) with the row sums of SS formed once (every thread: same value)
         double deta = 0.0;
         if constexpr (term) {
-            deta = red_sum(10);
+            deta = red_sum(9);
 #pragma unroll
             for (int j = 0; j < 6; j++) deta -= T2p[j] * w7[j] * ss_rowsum[j];
             deta /= (double)S;

@@ -23,6 +23,7 @@ struct lmpc_variant_api {
     size_t lds_cd;                            // condensed one-wave kernel (lmpc_solve_cd.hip.h): dynamic LDS per QP without the state-cost block; 0 = not built for this (N, S)
     size_t lds_cd_q;                          //   ... with it (Q or Qf non-zero)
     int (*launch_cd)(hipStream_t, const lmpc_dev_params &, int B, const lmpc_solve_io &, int hasQ);   // lmpc_solve_kernel_cd<N,S>
+    int occ_mw2;                              // work-groups of the two-wave kernel the runtime keeps resident per CU (asked, not assumed: 0 = unknown)
 };
 
 template <int N, int S> struct lmpc_variant_launchers {
@@ -80,6 +81,11 @@ template <int N, int S> static bool lmpc_variant_fill(lmpc_variant_api *v) {
         if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_mw<N, S, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v->lds_mw) != hipSuccess) return false;
     }
     v->launch_1w = &L::l1; v->launch_retry = &L::lr; v->launch_mw4 = &L::l4; v->launch_mw2 = &L::l2;
+    v->occ_mw2 = 0;
+    if constexpr (L::has_mw) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)lmpc_solve_kernel_mw<N, S, 2>, 2 * WAVE, v->lds_mw) == hipSuccess) v->occ_mw2 = nb;
+    }
     v->lds_1w_abg = 0;
     if constexpr (L::use_abg) {
         v->lds_1w_abg = L::lds1g;
