@@ -372,3 +372,15 @@ def test_k1_k2_match_oracle_on_every_bench_problem(built):
     print("4096 / 30 laps, 256 evenly spaced problems: worst relative |A,B,C - oracle| %.2e, selections identical" % worst)
     assert worst < common.TOL_ABC
     ctx.close()
+
+
+def test_kernel_routes_of_the_bench_configuration(built):
+    """Which solve kernel serves which batch size at N = 12 / 48 safe-set points (lmpc_solver_waves): four waves per QP up to one QP per CU, two
+    waves up to FOUR QPs per CU, one wave beyond.  The two-wave range is capped by the occupancy the runtime reports for that kernel: round 4 added
+    512 bytes of static LDS to it, the fourth QP no longer fitted a CU (40 960 bytes each), batch 1024 silently ran in two rounds (2.85 -> 2.18 M
+    steps/s) and nothing failed.  Now the cap would move and this test says so."""
+    g = common.load_lmpc_golden()
+    ctx, par = common.make_lmpc_ctx(g, 4, max_batch=8)
+    n_cu = 256
+    assert [ctx.solver_waves(b) for b in (1, n_cu, n_cu + 1, 3 * n_cu, 4 * n_cu, 4 * n_cu + 1, 8192)] == [4, 4, 2, 2, 2, 1, 1]
+    ctx.close()
