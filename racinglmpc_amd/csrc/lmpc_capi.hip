@@ -571,6 +571,8 @@ static void k1_grid(lmpc_ctx *c, int B, int *qg, int *nblk) {
 static void launch_k1(lmpc_ctx *c, int nblk, int B, int qg, const double *xLin, int xstride, const double *uLin, double *dA, double *dB, double *dC, int *dst) {
     bool small = true;
     for (int i = 0; i < c->cfg.trToUse; i++) small = small && c->dp.mlen[i] - 1 <= 8 * WAVE;
+    static const bool force16 = getenv("LMPC_K1_RPL16") != nullptr;      // (developer switch: A / B of the two scan builds)
+    if (force16) small = false;
     const bool occ = nblk > c->n_cu;
     auto k = occ ? (small ? lmpc_regress_kernel<true, 8> : lmpc_regress_kernel<true, K1_RPL>) : (small ? lmpc_regress_kernel<false, 8> : lmpc_regress_kernel<false, K1_RPL>);
     hipLaunchKernelGGL(k, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, xLin, xstride, uLin, dA, dB, dC, dst);
