@@ -781,6 +781,7 @@ struct ricc_consts {                                       // per-lane loop-inva
     int qr, qR, qC, cA, oB0, oA0, oB1, oA1, oBe, oTop, qT;
     bool w_xx;
     double wq, wf0, wf1, wfu[4], d2base, ud2, idB1, idA1, idBe;
+    double mR2, mBe, mXX, mU;        // 0 / 1 per lane: operand selects written as multiply-adds (one instruction instead of two v_cndmask per double)
 };
 __device__ __forceinline__ ricc_consts ricc_setup(int lane, const double *Q2, const double *Fx, const double *R2, const double *dR2, const double *Fu) {
     ricc_consts c;
@@ -811,6 +812,7 @@ __device__ __forceinline__ ricc_consts ricc_setup(int lane, const double *Q2, co
     c.idBe = (qr < 2 && cA == 6 + qr) ? 1.0 : 0.0;
     c.oTop = (qR < 6 ? qR : 0) * 8 + (qC < 6 ? qC : 0);
     c.qT = 4 * (16 * qc + 4 * (2 * qJ + qI) + qr);                                    // byte index of the lane holding the transposed entry
+    c.mR2 = qr < 2 ? 1.0 : 0.0; c.mBe = cA < 6 ? 1.0 : 0.0; c.mXX = w_xx ? 1.0 : 0.0; c.mU = (qr < 2 && qC < 6) ? 1.0 : 0.0;
     return c;
 }
 // Backward recursion over the augmented stages xi_k = (x_k, u_{k-1}), [x'; u] = Ar [x; u], Ar = [[A, B], [0, I]] (8 x 8):
@@ -851,13 +853,21 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
         Wq = w;
     };
     stage_loads(N - 1); stage_hessian();
+    int kl = N - 2;                                                                        // stage whose operands are fetched next (a scalar of its own: the
+                                                                                           // clamp inside the address cost two vector instructions per read)
 #pragma unroll 1
     for (int k = N - 1; k >= 0; k--) {
         const double cB0 = lB0, cA0 = lA0, cW = Wq;
-        const double arB1 = qr < 2 ? lB1 : c.idB1, arA1 = qr < 2 ? lA1 : c.idA1;           // Ar (B form) and Ar' (A form), K = 1
-        const double be = c.cA < 6 ? lBe : c.idBe;                                         // [B; I] as A operand; its K >= 2 lanes meet K = 0
-        const double top = c.w_xx ? lTop : 0.0;
-        stage_loads(k > 0 ? k - 1 : 0);                                                    // (stage 0 re-reads itself: no branch in the loop body)
+        double arB1, arA1, be, top;
+        if constexpr (SWEEP_BF<N>) {     // (the clamped rows the other lanes read are finite: x * 0 + id is exact)
+            arB1 = fma(lB1, c.mR2, c.idB1); arA1 = fma(lA1, c.mR2, c.idA1); be = fma(lBe, c.mBe, c.idBe); top = lTop * c.mXX;
+        } else {
+            arB1 = qr < 2 ? lB1 : c.idB1; arA1 = qr < 2 ? lA1 : c.idA1;                    // Ar (B form) and Ar' (A form), K = 1
+            be = c.cA < 6 ? lBe : c.idBe;                                                  // [B; I] as A operand; its K >= 2 lanes meet K = 0
+            top = c.w_xx ? lTop : 0.0;
+        }
+        if constexpr (SWEEP_BF<N>) { stage_loads(kl); kl = kl > 0 ? kl - 1 : 0; }
+        else stage_loads(k > 0 ? k - 1 : 0);                                               // (stage 0 re-reads itself: no branch in the loop body)
         // T = Pi Ar: A form of the symmetric Pi = in-row block copies [0,0,1,1] (K = 0) and [2,2,3,3] (K = 1) of its quad form
         const double pA0 = dpp_blk<0x118, 0x8>(dpp_blk<0x114, 0x6>(Piq, Piq), Piq);       // row_shr:4 -> banks 1, 2; row_shr:8 -> bank 3
         const double pA1 = dpp_blk<0x108, 0x1>(dpp_blk<0x104, 0x6>(Piq, Piq), Piq);       // row_shl:4 -> banks 1, 2; row_shl:8 -> bank 0
@@ -876,7 +886,7 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
         double sa, sb, ua, ub;
         swap32(Mq, sa, sb);                                                                // rows 6, 7 (lanes 32..63) -> lanes 0..31
         const double um = dpp_blk<0x128, 0x3>(sb, sb);                                     // columns 0..7 in both halves of the row (B form)
-        const double Ub = qr < 2 ? (c.qC < 6 ? um : c.ud2) : 0.0;
+        const double Ub = SWEEP_BF<N> ? fma(um, c.mU, c.ud2) : (qr < 2 ? (c.qC < 6 ? um : c.ud2) : 0.0);
         swap16(Ub, ua, ub);
         const double Uo = (qr & 1) ? ua : ub;                                              // the other row of U
         // (round 4: adj(M_uu) U formed beside the reciprocal's chain and multiplied by 1 / det last, and one Newton step instead of two on the
@@ -884,7 +894,7 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
         //  next to it is as long a chain)
         const double nKb = -((qr == 0 ? i00 : i11) * Ub + i01 * Uo);                       // -K = -M_uu^-1 U (B form; zero in lanes qr >= 2)
         const double Ua = dpp_blk<0x104, 0x4>(dpp_blk<0x114, 0x2>(Ub, Ub), Ub);            // A form of U': blocks [0,0,3,3]
-        const double Bs = c.w_xx ? Mq : c.d2base;
+        const double Bs = SWEEP_BF<N> ? fma(Mq, c.mXX, c.d2base) : (c.w_xx ? Mq : c.d2base);
         const double Piu = __builtin_amdgcn_mfma_f64_4x4x4f64(Ua, nKb, Bs, 0, 0, 0);       // Pi_k = Base - U' K
         const double Phq = __builtin_amdgcn_mfma_f64_4x4x4f64(be, nKb, top, 0, 0, 0);      // Phi_k = [[A, 0], [0, 0]] - [B; I] K
         // Rounding leaves Pi slightly unsymmetric, the A form of the next stage reads Pi', and U above takes rows for columns:
