@@ -119,11 +119,11 @@ __device__ __forceinline__ void flag_retry(const lmpc_solve_io &io, int st) {
 // ---- cross-lane primitives (gfx950): DPP inside a row of 16 lanes, v_permlane16/32_swap across rows ----
 // (old = src, bound_ctrl off: a lane whose source lane is switched off by EXEC keeps its own value.  Round 4 tried bound_ctrl with old = 0 -- the
 //  compiler then drops the v_mov_b32 that pairs with every v_mov_b32_dpp, 3100 instructions in the library, 1 % per Newton step -- and the N = 40
-//  kernel with [A_k | B_k] in global memory took 12.4 instead of 11.0 iterations and three times as long, every certificate still green.  Bisected with
-//  -DLMPC_DPP_BC=<bits> (below): each reduction alone is indifferent to the change, sum_over_c and sum_over_g TOGETHER (the register sweeps of
+//  kernel with [A_k | B_k] in global memory took 12.4 instead of 11.0 iterations and three times as long, every certificate still green.  Bisected
+//  site by site (developer builds of that round): each reduction alone is indifferent to the change, sum_over_c and sum_over_g TOGETHER (the register sweeps of
 //  kkt_solve, unrolled 40 times around exec-masked stores, in a kernel that keeps 190 registers in AGPRs) reproduce it, and only in that kernel: not the
-//  semantics of the move but what the compiler makes of that kernel without the copies.  The moves stay as they were; the N = 40 iteration statistics
-//  are asserted in tests/test_gpu_certificates.py.)
+//  semantics of the move but what the compiler makes of that kernel without the copies.  The long horizons keep this form everywhere; the short ones
+//  use dpp_mv<.., true> where the EXEC mask is full; the N = 40 iteration statistics are asserted in tests/test_gpu_certificates.py.)
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
@@ -159,32 +159,30 @@ __device__ __forceinline__ double rdlane(double v, int src) {       // wave-unif
 #define DPP_QP_X2 0x4E          // quad_perm [2,3,0,1]
 #define DPP_HALF_MIRROR 0x141
 #define DPP_MIRROR 0x140
-struct OpSum { static constexpr int bit = 1; __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
-struct OpMax { static constexpr int bit = 2; __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
-struct OpMin { static constexpr int bit = 4; __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); } };
-#ifdef LMPC_DPP_BC      // (developer experiment, see dpp_mov: bound_ctrl moves at the sites whose bit is set -- 1 / 2 / 4 wave sum / max / min, 8 sum_over_c, 16 sum_over_g, 32 / 64 K1's rank rotations)
-template <int CTRL> __device__ __forceinline__ double dpp_mov_bc(double v) {
-    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true));
+struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+struct OpMax { __device__ __forceinline__ double operator()(double a, double b) const { return fmax(a, b); } };
+struct OpMin { __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); } };
+// The same move with bound_ctrl and old = 0: identical under a full EXEC mask (every lane has a source), and the compiler no longer needs the
+// v_mov_b32 that preloads the destination -- three instructions per reduction step instead of five, on a wave that is bound by instruction issue.
+// Used ONLY where the EXEC mask is full by construction and only in the short-horizon kernels (BC = SWEEP_BF<N>): see dpp_mov for what the long-horizon
+// kernels made of it.
+template <int CTRL, bool BC> __device__ __forceinline__ double dpp_mv(double v) {
+    if constexpr (BC) return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true));
+    else return dpp_mov<CTRL>(v);
 }
-#define DPP_RED(CTRL, v) ((LMPC_DPP_BC & Op::bit) ? dpp_mov_bc<CTRL>(v) : dpp_mov<CTRL>(v))
-#define DPP_SITE(BIT, CTRL, v) ((LMPC_DPP_BC & (BIT)) ? dpp_mov_bc<CTRL>(v) : dpp_mov<CTRL>(v))
-#else
-#define DPP_RED(CTRL, v) dpp_mov<CTRL>(v)
-#define DPP_SITE(BIT, CTRL, v) dpp_mov<CTRL>(v)
-#endif
-template <class Op> __device__ __forceinline__ double wave_allreduce(double v, Op op) {
-    v = op(v, DPP_RED(DPP_QP_X1, v));
-    v = op(v, DPP_RED(DPP_QP_X2, v));
-    v = op(v, DPP_RED(DPP_HALF_MIRROR, v));
-    v = op(v, DPP_RED(DPP_MIRROR, v));
+template <class Op, bool BC = false> __device__ __forceinline__ double wave_allreduce(double v, Op op) {
+    v = op(v, dpp_mv<DPP_QP_X1, BC>(v));
+    v = op(v, dpp_mv<DPP_QP_X2, BC>(v));
+    v = op(v, dpp_mv<DPP_HALF_MIRROR, BC>(v));
+    v = op(v, dpp_mv<DPP_MIRROR, BC>(v));
     double a, b;
     swap16(v, a, b); v = op(a, b);
     swap32(v, a, b); v = op(a, b);
     return v;
 }
-__device__ __forceinline__ double wsum(double v) { return wave_allreduce(v, OpSum()); }
-__device__ __forceinline__ double wmax(double v) { return wave_allreduce(v, OpMax()); }
-__device__ __forceinline__ double wmin(double v) { return wave_allreduce(v, OpMin()); }
+template <bool BC = false> __device__ __forceinline__ double wsum(double v) { return wave_allreduce<OpSum, BC>(v, OpSum()); }
+template <bool BC = false> __device__ __forceinline__ double wmax(double v) { return wave_allreduce<OpMax, BC>(v, OpMax()); }
+template <bool BC = false> __device__ __forceinline__ double wmin(double v) { return wave_allreduce<OpMin, BC>(v, OpMin()); }
 
 // fast FP64 reciprocal / reciprocal square root: hardware estimate + two Newton steps (full double accuracy up to ~1 ulp;
 // an IEEE divide costs ~75 and a sqrt ~125 dependent cycles on this path, these ~35)
@@ -311,12 +309,8 @@ __device__ __forceinline__ bool k1_less(double da, int ia, double db, int ib) { 
 // rank of (d, i) among the 16 entries of its row of lanes, lexicographic: every other lane's entry passes by once
 template <int ROT> __device__ __forceinline__ void k1_row_rank(double d, int i, int &rank) {
     if constexpr (ROT < 16) {
-        const double od = DPP_SITE(32, 0x120 + ROT, d);
-#if defined(LMPC_DPP_BC) && (LMPC_DPP_BC & 64)
-        const int oi = __builtin_amdgcn_update_dpp(0, i, 0x120 + ROT, 0xf, 0xf, true);
-#else
+        const double od = dpp_mov<0x120 + ROT>(d);
         const int oi = __builtin_amdgcn_update_dpp(i, i, 0x120 + ROT, 0xf, 0xf, false);
-#endif
         rank += k1_less(od, oi, d, i) ? 1 : 0;
         k1_row_rank<ROT + 1>(d, i, rank);
     }
@@ -1024,12 +1018,12 @@ __device__ __forceinline__ double wave_uniform(double v) {
 }
 
 // sum over the 8 lanes of a group (lane = 8 g + c, all lanes of the group receive it) / over the 8 groups (same c)
-__device__ __forceinline__ double sum_over_c(double v) {
-    v += DPP_SITE(8, DPP_QP_X1, v); v += DPP_SITE(8, DPP_QP_X2, v); v += DPP_SITE(8, DPP_HALF_MIRROR, v);
+template <bool BC = false> __device__ __forceinline__ double sum_over_c(double v) {
+    v += dpp_mv<DPP_QP_X1, BC>(v); v += dpp_mv<DPP_QP_X2, BC>(v); v += dpp_mv<DPP_HALF_MIRROR, BC>(v);
     return v;
 }
-__device__ __forceinline__ double sum_over_g(double v) {
-    v += DPP_SITE(16, 0x128, v);                 // row_ror:8  (lane c <-> c+8 inside a row of 16)
+template <bool BC = false> __device__ __forceinline__ double sum_over_g(double v) {
+    v += dpp_mv<0x128, BC>(v);                   // row_ror:8  (lane c <-> c+8 inside a row of 16)
     double a, b;
     swap16(v, a, b); v = a + b;
     swap32(v, a, b); v = a + b;
@@ -1472,8 +1466,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
 #pragma unroll
                 for (int k = N - 1; k >= 0; k--) {
                     double pr = ph[k] * pv;
-                    if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; *wO = pv; wO += wd.dO; }
-                    else { pr = sum_over_g(pr); pv = pr + gm[k]; *wE = pv; wE += wd.dE; }
+                    if (k & 1) { pr = sum_over_c<true>(pr); pv = pr + gm[k]; *wO = pv; wO += wd.dO; }
+                    else { pr = sum_over_g<true>(pr); pv = pr + gm[k]; *wE = pv; wE += wd.dE; }
                     SWEEP_PIN(wE, wO);
                 }
             } else {
@@ -1515,7 +1509,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
 #pragma unroll
                 for (int k = 0; k < N; k++) {
                     double pr = ph[k] * xi;
-                    if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
+                    if (k & 1) pr = sum_over_g<true>(pr); else pr = sum_over_c<true>(pr);
                     xi = pr + fm[k];
                     if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
                     SWEEP_PIN(wE, wO);

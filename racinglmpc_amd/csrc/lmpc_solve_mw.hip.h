@@ -31,6 +31,7 @@ template <int N, int S, int NW>
 // 256-register build spilled 221 VGPRs to scratch)
 __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 > 160 * 1024 || solve_lds<N, S>::CH > 1) ? 1 : 2) void lmpc_solve_kernel_mw(lmpc_dev_params p, int B, lmpc_solve_io io) {
     static_assert(NW == 2 || NW == 4, "wave 0 runs the sequential recursions, waves 1 .. NW-1 everything that can run beside them");
+    constexpr bool BCF = SWEEP_BF<N>;                       // bound_ctrl cross-lane moves (dpp_mv) where the EXEC mask is full: short horizons only
     extern __shared__ double sm[];
     using LL = solve_lds<N, S>;
     constexpr int M = LL::M;
@@ -347,8 +348,8 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
 #pragma unroll
                     for (int k = N - 1; k >= 0; k--) {
                         double pr = ph[k] * pv;
-                        if (k & 1) { pr = sum_over_c(pr); pv = pr + gm[k]; *wO = pv; wO += wd.dO; }
-                        else { pr = sum_over_g(pr); pv = pr + gm[k]; *wE = pv; wE += wd.dE; }
+                        if (k & 1) { pr = sum_over_c<true>(pr); pv = pr + gm[k]; *wO = pv; wO += wd.dO; }
+                        else { pr = sum_over_g<true>(pr); pv = pr + gm[k]; *wE = pv; wE += wd.dE; }
                         SWEEP_PIN(wE, wO);
                     }
                 } else {
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 const double pq = pst[(kk + 1) * 8 + lc], gq = lc >= 6 ? gup[2 * kk + lc - 6] : 0.0;
                 const double m00 = Mi[kk * 4], m01 = Mi[kk * 4 + 1], m10 = Mi[kk * 4 + 2], m11 = Mi[kk * 4 + 3];
                 LDS_GROUP();
-                const double w0_ = sum_over_c(fma(bq0, pq, lc == 6 ? gq : 0.0)), w1_ = sum_over_c(fma(bq1, pq, lc == 7 ? gq : 0.0));
+                const double w0_ = sum_over_c<BCF>(fma(bq0, pq, lc == 6 ? gq : 0.0)), w1_ = sum_over_c<BCF>(fma(bq1, pq, lc == 7 ? gq : 0.0));
                 const double k00 = m00 * w0_ + m01 * w1_, k01 = m10 * w0_ + m11 * w1_;
                 if (on) phi[k * 8 + lc] = -(bq0 * k00 + bq1 * k01);
             }
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
 #pragma unroll
                     for (int k = 0; k < N; k++) {
                         double pr = ph[k] * xi;
-                        if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
+                        if (k & 1) pr = sum_over_g<true>(pr); else pr = sum_over_c<true>(pr);
                         xi = pr + fm[k];
                         if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
                         SWEEP_PIN(wE, wO);
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             }
             double gsum = gsum_c;
             if (wave == 1) gsum += gs0[lane];                // (written by wave 0 together with the step, a barrier ago)
-            red_put(0, wsum(gsum)); red_put(1, wmax(rmax)); red_put(2, wsum(lsum)); red_put(3, wmax(remax));
+            red_put(0, wsum<BCF>(gsum)); red_put(1, wmax<BCF>(rmax)); red_put(2, wsum<BCF>(lsum)); red_put(3, wmax<BCF>(remax));
             TSMW(111);
         }
         __syncthreads();                                     // B1
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                     const double bq0 = lc < 6 ? AB[k * 48 + lc * 8 + 6] : (lc == 6 ? 1.0 : 0.0), bq1 = lc < 6 ? AB[k * 48 + lc * 8 + 7] : (lc == 7 ? 1.0 : 0.0);
                     const double pq = pst[(k + 1) * 8 + lc], gq = lc >= 6 ? gup[2 * k + lc - 6] : 0.0;
                     const double m00 = Mi[k * 4], m01 = Mi[k * 4 + 1], m10 = Mi[k * 4 + 2], m11 = Mi[k * 4 + 3];
-                    const double w0_ = sum_over_c(fma(bq0, pq, lc == 6 ? gq : 0.0)), w1_ = sum_over_c(fma(bq1, pq, lc == 7 ? gq : 0.0));
+                    const double w0_ = sum_over_c<BCF>(fma(bq0, pq, lc == 6 ? gq : 0.0)), w1_ = sum_over_c<BCF>(fma(bq1, pq, lc == 7 ? gq : 0.0));
                     const double k00 = m00 * w0_ + m01 * w1_, k01 = m10 * w0_ + m11 * w1_;
                     if (lane < 8) phi[k * 8 + lc] = -(bq0 * k00 + bq1 * k01);
                 }
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
 #pragma unroll
                 for (int k = 0; k < N; k++) {
                     double pr = ph[k] * xi;
-                    if (k & 1) pr = sum_over_g(pr); else pr = sum_over_c(pr);
+                    if (k & 1) pr = sum_over_g<true>(pr); else pr = sum_over_c<true>(pr);
                     xi = pr + fm[k];
                     if (k & 1) { *wO = xi; wO += wd.dO; } else { *wE = xi; wE += wd.dE; }
                     SWEEP_PIN(wE, wO);
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 if (dma < 0.0) admax = fmin(admax, -mr * frcp(dma));
             }
         }
-        red_put(4, wmin(apmax)); red_put(5, wmin(admax));
+        red_put(4, wmin<BCF>(apmax)); red_put(5, wmin<BCF>(admax));
         __syncthreads();
         apmax = red_min(4); admax = red_min(5);
         if (!sep) { apmax = fmin(apmax, admax); admax = apmax; }
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             const int r = slot_row(j);
             if (r >= 0) { gaff = fma(t_r[j] + apmax * dt_r[j], m[r] + admax * dma_r[j], gaff); tp_r[j] = dt_r[j] * dma_r[j]; }
         }
-        red_put(6, wsum(gaff));
+        red_put(6, wsum<BCF>(gaff));
         __syncthreads();
         gaff = red_sum(6) / (double)M;
         double sig = gaff / gap; sig = sig * sig * sig;
@@ -742,8 +743,8 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 if constexpr (term) { if (r >= 8 * N) dsum += dmm - rl[r - 8 * N]; }
             }
         }
-        red_put(7, wmin(apx)); red_put(8, wmin(adx));
-        if constexpr (term) red_put(9, wsum(dsum));
+        red_put(7, wmin<BCF>(apx)); red_put(8, wmin<BCF>(adx));
+        if constexpr (term) red_put(9, wsum<BCF>(dsum));
         if constexpr (term) { if (wave == NW - 1) ss_times<S>(SS, dl, dx + N * 6, w7, lane); }          // d s_T
         __syncthreads();
         const double frac = step_fraction(sig, gap);
