@@ -80,6 +80,7 @@ struct lmpc_ctx {
     lmpc_variant_api var;                    // launchers of the (N, numSS_points) instantiation of the solve kernels in use
     void *var_dl;                            // dlopen handle when that instantiation lives in its own shared object (lmpc_variant.hip)
     int mw_max_batch, mw2_max_batch, n_cu;   // largest batch served by the four-wave / the two-wave solve kernel
+    bool k1_force16;                         // regression kernel: never the 8-rows-per-lane scan (launch_k1)
     int fuse_k1;                             // fused step for one-wave batches (LMPC_FUSE=0 turns it off)
     double *ab_pack;                         // global scratch of the one-wave kernel's long-horizon variant ([A_k | B_k] per problem), max_batch x 48 N doubles
     int cd_ok, cd_hasq, cd_mode;             // condensed one-wave kernel (opt-in: libraries built with -DLMPC_WITH_CD only): usable for this configuration / state cost present / LMPC_CD=1 in the environment selects it, at every batch size
@@ -193,6 +194,7 @@ static int create_body(lmpc_ctx *c) {
     const lmpc_config *cfg = &c->cfg;
     HIPCHK(hipSetDevice(cfg->device));
     // an unsupported (N, numSS_points) pair is an ordinary user error: find that out before anything is allocated
+    c->k1_force16 = getenv("LMPC_K1_RPL16") != nullptr;
     { const int rc = pick_solver(c); if (rc) return rc; }
     {   // batches that leave SIMDs idle (B <= number of CUs) run the 4-waves-per-QP kernel
         const char *e = getenv("LMPC_MW_MAX_BATCH"); hipDeviceProp_t prop; int cus = 256;
@@ -571,8 +573,7 @@ static void k1_grid(lmpc_ctx *c, int B, int *qg, int *nblk) {
 static void launch_k1(lmpc_ctx *c, int nblk, int B, int qg, const double *xLin, int xstride, const double *uLin, double *dA, double *dB, double *dC, int *dst) {
     bool small = true;
     for (int i = 0; i < c->cfg.trToUse; i++) small = small && c->dp.mlen[i] - 1 <= 8 * WAVE;
-    static const bool force16 = getenv("LMPC_K1_RPL16") != nullptr;      // (developer switch: A / B of the two scan builds)
-    if (force16) small = false;
+    if (c->k1_force16) small = false;                                    // (LMPC_K1_RPL16 at lmpc_create: A / B of the two scan builds, tests/test_gpu_configs.py)
     const bool occ = nblk > c->n_cu;
     auto k = occ ? (small ? lmpc_regress_kernel<true, 8> : lmpc_regress_kernel<true, K1_RPL>) : (small ? lmpc_regress_kernel<false, 8> : lmpc_regress_kernel<false, K1_RPL>);
     hipLaunchKernelGGL(k, dim3(nblk), dim3(K1_NT), 0, c->stream, c->dp, B, qg, xLin, xstride, uLin, dA, dB, dC, dst);

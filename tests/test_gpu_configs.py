@@ -384,3 +384,35 @@ def test_kernel_routes_of_the_bench_configuration(built):
     n_cu = 256
     assert [ctx.solver_waves(b) for b in (1, n_cu, n_cu + 1, 3 * n_cu, 4 * n_cu, 4 * n_cu + 1, 8192)] == [4, 4, 2, 2, 2, 1, 1]
     ctx.close()
+
+
+def test_the_two_scan_builds_of_the_regression_kernel_agree(built):
+    """K1 scans 8 rows per lane when every lap in use has at most 512 rows and 16 otherwise (launch_k1).  Same prefilter image, same exact
+    re-rank: on laps of 208..396 rows (30 PID laps, the four fastest in use) the two builds must return identical bits, in the occupancy
+    build (batch 4096) and in the low-occupancy one (batch 64)."""
+    import os
+    import bench
+    from racinglmpc_amd import _capi
+    g = bench.load_seed()
+    N = 12
+    outs = {}
+    for force16 in (False, True):
+        if force16:
+            os.environ["LMPC_K1_RPL16"] = "1"
+        try:
+            ctx = bench.make_ctx(g, N, 4096, 0, laps=[], max_laps=40, max_lap_len=1024)
+        finally:
+            os.environ.pop("LMPC_K1_RPL16", None)
+        laps = bench.pid_laps(ctx, g, 30)
+        for x, u in laps:
+            ctx.model_add_trajectory(x, u); ctx.ss_add_trajectory(x, u)
+        assert max(x.shape[0] for x, u in laps) <= 512
+        for B in (4096, 64):
+            inp = bench.synth_batch(g, B, N, lap=laps[29])
+            A, Bm, C, st = ctx.regress_batch(inp["xLin"], inp["uLin"])
+            outs[(force16, B)] = (A, Bm, C, st)
+        ctx.close()
+    for B in (4096, 64):
+        for a, b in zip(outs[(False, B)], outs[(True, B)]):
+            assert np.array_equal(a, b)
+        assert np.all(outs[(False, B)][3] == 0)
