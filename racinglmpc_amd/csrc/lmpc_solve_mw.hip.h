@@ -37,7 +37,8 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     constexpr int M = LL::M;
     constexpr bool term = S > 0;
     constexpr int NT = WAVE * NW;
-    constexpr int RPL = (M + NT - 1) / NT;                  // inequality rows per thread
+    constexpr bool ROWS_OFF_W0 = S > 0 && S <= WAVE && NT >= 8 * N + WAVE && SWEEP_BF<N>;     // wave 0 owns the lambda rows and nothing else (see slot_row; the four-wave kernel: the other rows fit threads 64 .. 255)
+    constexpr int RPL = ((ROWS_OFF_W0 ? 8 * N + WAVE : M) + NT - 1) / NT;           // inequality rows per thread
     const int b = blockIdx.x;
     if (b >= B) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -153,7 +154,14 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     // weights the moment it has updated its own rows, and starts the next iteration's terminal factor (Gram matrix part) inside the step phase
     // instead of behind the barrier that ends it (TEARLY; four waves per QP, one terminal-block column per lane).
     constexpr bool TEARLY = term && NW == 4 && LL::CH == 1 && S <= WAVE;
-    auto slot_row = [&](int j) -> int { const int s_ = tid + NT * j; return s_ >= M ? -1 : (s_ < S ? 8 * N + s_ : s_ - S); };
+    // (ROWS_OFF_W0: the other rows start at thread 64.  Wave 0's spare lanes used to take the first 64 - S lane rows, so every pass over the rows
+    //  made the critical wave run the lane rows' code as well as the lambda rows' -- divergent paths cost the sum of both -- on a wave that is bound by
+    //  instruction issue.)
+    auto slot_row = [&](int j) -> int {
+        const int s_ = tid + NT * j;
+        if constexpr (ROWS_OFF_W0) return s_ < S ? 8 * N + s_ : (s_ >= WAVE && s_ - WAVE < 8 * N ? s_ - WAVE : -1);
+        else return s_ >= M ? -1 : (s_ < S ? 8 * N + s_ : s_ - S);
+    };
     double t_r[RPL], rt_r[RPL], tp_r[RPL], dt_r[RPL];
     double gsum_c = 0.0;                                   // this thread's share of sum t mu (the complementarity gap)
 #pragma unroll
