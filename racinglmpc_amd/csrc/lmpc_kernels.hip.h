@@ -1655,7 +1655,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
                 rl_r[t] = v; rmax = fmax(rmax, fabs(v)); lsum += lam[c];
             }
         }
-        gap = wave_uniform(wsum(gsum) / (double)M);
+        gap = wave_uniform(SWEEP_BF<N> ? wsum(gsum) * (1.0 / (double)M) : wsum(gsum) / (double)M);    // (short horizons: no IEEE divisions in the loop, ~30 instructions each)
         rdn = wmax(rmax);
         const double re_sum = term ? wave_uniform(wsum(lsum) - 1.0) : 0.0;
         // The dynamics rows are linear and every step keeps them (the roll-out start satisfies them, the Newton direction lies in their null
@@ -1818,8 +1818,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             const int r = lane + WAVE * j;
             if (r < M) { gaff = fma(t_r[j] + apmax * dt_r[j], m[r] + admax * dma_r[j], gaff); tp_r[j] = dt_r[j] * dma_r[j]; }
         }
-        gaff = wsum(gaff) / (double)M;
-        double sig = gaff / gap; sig = sig * sig * sig;
+        gaff = SWEEP_BF<N> ? wsum(gaff) * (1.0 / (double)M) : wsum(gaff) / (double)M;
+        double sig = SWEEP_BF<N> ? gaff * frcp(gap) : gaff / gap; sig = sig * sig * sig;
         const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);   // keep the complementarity products off the rounding floor
         // ---- corrector: h = (t mu - sigma gap + dt_aff dmu_aff) / t ----------------------------------------
         __syncthreads();
@@ -1874,7 +1874,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             FOR_LANES_T(c, t, S) { v += -rl_r[t] + dm[8 * N + c];
 #pragma unroll
                 for (int j = 0; j < 6; j++) v -= SS[j * S + c] * T2p[j] * w7[j]; }
-            deta = wsum(v) / (double)S;
+            deta = SWEEP_BF<N> ? wsum(v) * (1.0 / (double)S) : wsum(v) / (double)S;
         }
         FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
         FOR_LANES(i, 2 * N) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }

@@ -41,9 +41,13 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     constexpr int RPL = ((ROWS_OFF_W0 ? 8 * N + WAVE : M) + NT - 1) / NT;           // inequality rows per thread
     const int b = blockIdx.x;
     if (b >= B) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: tests on it are scalar branches, not exec-mask regions with a v_cmp each
     const int lg = lane >> 3, lc = lane & 7;
     const bool w0 = wave == 0;
+    // the critical wave first wherever an arbiter chooses between waves (LDS, scalar cache): four waves per QP only -- +0.3 % there; with two waves per QP
+    // the helper shares its SIMD with another QP's wave 0 and starves: batch 1024 lost 4 %
+    if constexpr (NW == 4) { if (w0) __builtin_amdgcn_s_setprio(3); }
     double *AB = sm + LL::oAB, *C = sm + LL::oC, *x = sm + LL::ox, *u = sm + LL::ou, *s = sm + LL::os, *lam = sm + LL::olam;
     double *dx = sm + LL::odx, *du = sm + LL::odu, *ds = sm + LL::ods, *dl = sm + LL::odl, *nu = sm + LL::onu, *dnu = sm + LL::odnu;
     double *m = sm + LL::om, *th = sm + LL::oth, *h = sm + LL::oh, *dm = sm + LL::odm;
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         {
             double gs = 0.0, rm = 0.0, ls = 0.0, rem = 0.0;
             for (int w = 1; w < NW; w++) { gs += red[w]; rm = fmax(rm, red[4 + w]); ls += red[8 + w]; rem = fmax(rem, red[12 + w]); }
-            gap = gs / (double)M; rdn = rm; ren = rem; lsum_all = ls;
+            gap = SWEEP_BF<N> ? gs * (1.0 / (double)M) : gs / (double)M; rdn = rm; ren = rem; lsum_all = ls;   // (an IEEE division is ~30 instructions on every wave; four per Newton step went)
         }
         const double re_sum = term ? lsum_all - 1.0 : 0.0;
         ren = fmax(ren, fabs(re_sum));
@@ -728,8 +732,8 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         }
         red_put(6, wsum<BCF>(gaff));
         __syncthreads();
-        gaff = red_sum(6) / (double)M;
-        double sig = gaff / gap; sig = sig * sig * sig;
+        gaff = SWEEP_BF<N> ? red_sum(6) * (1.0 / (double)M) : red_sum(6) / (double)M;
+        double sig = SWEEP_BF<N> ? gaff * frcp(gap) : gaff / gap; sig = sig * sig * sig;
         const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);
         TSMW(15);
         // ---- corrector ---------------------------------------------------------------------------------------
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             deta = red_sum(9);
 #pragma unroll
             for (int j = 0; j < 6; j++) deta -= T2p[j] * w7[j] * ss_rowsum[j];
-            deta /= (double)S;
+            if constexpr (SWEEP_BF<N>) deta *= 1.0 / (double)S; else deta /= (double)S;
         }
         FOR_WAVE2(i, 6 * (N + 1), 1, 2) x[i] = fma(al, dx[i], x[i]);
         FOR_WAVE(i, 2 * N, 2) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
