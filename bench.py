@@ -91,6 +91,7 @@ def pid_laps(ctx, g, n_laps, max_steps=600):
     return [(X[i, :min(done[i] + 20, X.shape[1])], U[i, :min(done[i] + 20, X.shape[1])]) for i in range(n_laps)]
 
 
+ROLLOUT_WATCHDOG_S = 240   # multi-rank closed-loop leg: seconds before the watchdog gives it up (it takes about one second)
 PROFILE_EVERY = 5      # HIP events around every 5th launch of each kernel inside the timed region (an event record costs ~4 us of stream time)
 
 
@@ -401,10 +402,26 @@ def main():
                 out["extras_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
             if host_event:
                 sig_path = parallel.host_signal("extras", port)
+        # The multi-rank form of this leg (one all-gather per lap between different devices) has never run on hardware before the driver's own
+        # multi-GPU run: a collective that one rank never enters would hang the job and cost the headline line.  Every rank therefore arms a
+        # watchdog; if the leg is not back in time, rank 0 prints the line it has -- still ONE line, still the last thing on stdout -- and all exit.
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def _bail():
+                if rank == 0:
+                    out["config_rollouts"] = {"error": "multi-rank rollout leg did not return within %d s (watchdog)" % ROLLOUT_WATCHDOG_S}
+                    sys.stdout.flush()
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(ROLLOUT_WATCHDOG_S, _bail); watchdog.daemon = True; watchdog.start()
         try:                                         # (deterministic failures -- e.g. too few valid laps -- occur on every rank alike)
             leg = rollout_leg(g, comm, ctx, args.rollouts_per_gpu)
         except RuntimeError as e:
             leg = {"error": str(e)[:300]}
+        if watchdog is not None:
+            watchdog.cancel()
         if rank == 0:
             out["config_rollouts"] = dict(leg, note="BASELINE configs[3]: closed-loop LMPC laps sharded over the ranks, lap stores replicated, one all-gather per lap")
     if rank == 0 and not args.no_cpu_baseline:
