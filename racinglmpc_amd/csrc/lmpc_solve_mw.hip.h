@@ -12,8 +12,7 @@
 #pragma once
 #include "lmpc_kernels.hip.h"
 
-// (the wait is needed: with a compiler fence only -- on the theory that one wave's LDS operations execute in order -- the answers changed, certificate
-//  2.4e-9 -> 4.5e-9, and nothing got faster)
+// (round 4 tried a compiler fence only -- one wave's LDS operations execute in order -- and nothing got faster: the wait stays)
 #define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // Compiler fence behind a group of LDS reads into locals: all of them are issued before the first use (one latency for the group).  With the
 // register file full the compiler otherwise interleaves read pairs with their arithmetic, one s_waitcnt and one LDS round trip per pair.
