@@ -219,6 +219,15 @@ int lmpc_set_profiling(lmpc_ctx *, int every);    /* 0: off; k > 0: HIP events o
 int lmpc_get_stats(lmpc_ctx *, lmpc_stats *out);  /* drains pending events */
 int lmpc_reset_stats(lmpc_ctx *);
 
+/* ---- developer entry points.  They exist in every build, but only the flavours built with the named macro carry the code behind them
+ *      (racinglmpc_amd.build.build_flavour); in the product library both return LMPC_E_ARG and say so in lmpc_last_error. ---- */
+int lmpc_debug_set_trace(lmpc_ctx *, double *dev_rows /* max_batch x 48 x 6 doubles of device memory, or NULL */);
+        /* -DLMPC_TRACE: every later solve launch records, per problem and interior-point iteration, (gap, r_d, r_e | sigma, alpha_p, alpha_d) --
+         * the columns of tests/ipm_model.py's trace, for a differential comparison of kernel and model (tools/n40_model.py) */
+int lmpc_debug_exec_audit(lmpc_ctx *, unsigned long long *out16, int reset);
+        /* -DLMPC_EXEC_AUDIT: out16[site] = calls of a cross-lane primitive (DPP / permlane / bpermute reductions, MFMA stages) of the built-in
+         * kernels that found an incomplete EXEC mask, out16[8 + site] = calls; sites are listed in csrc/lmpc_kernels.hip.h */
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,7 @@ EXPORTS = [
     "lmpc_lti_regression", "lmpc_comm_unique_id", "lmpc_comm_init", "lmpc_comm_destroy", "lmpc_comm_info", "lmpc_comm_allgather_dev", "lmpc_comm_allgather",
     "lmpc_comm_allreduce_max", "lmpc_comm_barrier", "lmpc_rollout_exchange",
     "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_solver_waves", "lmpc_plant_step_batch", "lmpc_global_position_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap", "lmpc_ss_truncate_lap",
+    "lmpc_debug_set_trace", "lmpc_debug_exec_audit",
 ]
 
 _lib = None
@@ -448,6 +449,30 @@ class Context:
 
     def selftest(self):
         _chk(self.lib.lmpc_selftest(self._h))
+
+    # ---- developer flavours only (build.build_flavour with LMPC_TRACE / LMPC_EXEC_AUDIT; the product library refuses both calls)
+    TRACE_ROWS = 48
+
+    def debug_trace_begin(self, B):
+        """Device buffer for the per-iteration trace of the next solve launches of up to B problems; returns its handle for debug_trace_fetch."""
+        p = self.dev_alloc(B * self.TRACE_ROWS * 6 * 8)
+        self.dev_upload(p, np.full((B, self.TRACE_ROWS, 6), np.nan))
+        _chk(self.lib.lmpc_debug_set_trace(self._h, _p(p)))
+        return p
+
+    def debug_trace_fetch(self, p, B):
+        """(B, 48, 6) rows (gap, r_d, r_e, sigma, alpha_p, alpha_d) per iteration, NaN where no iteration ran; switches the trace off and frees the buffer."""
+        out = np.zeros((B, self.TRACE_ROWS, 6))
+        self.sync(); self.dev_download(p, out)
+        _chk(self.lib.lmpc_debug_set_trace(self._h, None)); self.dev_free(p)
+        return out
+
+    def debug_exec_audit(self, reset=True):
+        """(partial[8], calls[8]) of the cross-lane primitives since the last reset (sites: csrc/lmpc_kernels.hip.h)."""
+        out = (C.c_ulonglong * 16)()
+        _chk(self.lib.lmpc_debug_exec_audit(self._h, out, C.c_int(1 if reset else 0)))
+        v = np.array(list(out), dtype=np.uint64)
+        return v[:8], v[8:]
 
     def set_profiling(self, every):
         """False / 0: off; True / 1: events around every kernel launch; k: around every k-th launch of each kernel (see lmpc_set_profiling)."""

@@ -22,13 +22,14 @@ ASAN_FLAGS = ["-g", "-fno-omit-frame-pointer", "-fsanitize=address", "-fno-gpu-s
 ASAN_RUNTIME = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"                     # LD_PRELOAD for python (tools/asan_run.sh)
 
 
-def build_flavour(suffix, defines, verbose=False, extra=()):
-    """Developer builds next to the product library (e.g. the -DLMPC_TIMING flavour of tools/phase_timing.py): liblmpc_hip_<suffix>.so."""
+def build_flavour(suffix, defines, verbose=False, extra=(), vgpr_form=True):
+    """Developer builds next to the product library (e.g. the -DLMPC_TIMING flavour of tools/phase_timing.py): liblmpc_hip_<suffix>.so.
+    vgpr_form=False drops `-mllvm -amdgpu-mfma-vgpr-form` (an A / B of the compiler option itself, tools/n40_experiments.py)."""
     out = os.path.join(_HERE, "liblmpc_hip_%s.so" % suffix)
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-unused-value", "-fPIC", "-shared"] + \
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17"] + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if vgpr_form else []) + ["-Wno-unused-value", "-fPIC", "-shared"] + \
           list(extra) + ["-D" + d for d in defines] + ["-o", out, SRC, "-L/opt/rocm/lib", "-lrccl"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -92,6 +92,7 @@ struct lmpc_ctx {
     int *w_selStart;                         // lmpc_select_batch: window starts, max_batch x numSS_it
     void *scr_dev; size_t scr_bytes;         // pooled scratch of the small host-buffer entry points (plant step, global position)
     std::vector<char *> gaps;                // guard builds: the 256-byte zones between the work-buffer ranges of the slabs
+    double *dbg_trace;                       // developer builds (-DLMPC_TRACE): device buffer of the per-iteration side channel, see lmpc_debug_set_trace
     double tr_s[4]; long long tr_n;          // developer trace of lmpc_step_batch's one-QP path (lmpc_debug_step_trace): seconds spent staging / launching / waiting / unstaging
     struct lmpc_rollout_session *ro;
     void *comm; int comm_rank, comm_world;   // RCCL communicator of this rank (lmpc_comm.hip.h); null = single process
@@ -631,13 +632,17 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io_in, bool imm
         }
         io.abPack = c->ab_pack;
     }
-    const bool deferred = (io.mode & 2) && !immediate && !io.tbuf;
+    const bool deferred = (io.mode & 2) && !immediate && !io.tbuf;       // (the retry pass of a traced launch would overwrite the trace rows: traced builds still defer, the rows of a retried problem are its retry's)
     if (deferred) {
         if ((int)c->pending.size() >= LMPC_RETRY_RING - 1) { int rc = resolve_retries(c); if (rc) return rc; }
         c->epoch++; io.retry_epoch = c->epoch; io.retry_flag = c->d_retry + (c->epoch % LMPC_RETRY_RING);
     }
     const bool term = c->cfg.numSS_it > 0;
     int rc = refresh_params(c, false, term && (io.mode & 1)); if (rc) return rc;
+    const bool timing_buf = io.tbuf != nullptr;              // (the cycle-stamp build pins the kernel route; the trace build below must not)
+#ifdef LMPC_TRACE
+    if (!io.tbuf && c->dbg_trace && (io.mode & 2)) io.tbuf = (long long *)c->dbg_trace;
+#endif
     ev_begin(c, 1);
     // waves per QP: 4 up to one QP per CU, 2 up to mw2_max_batch (four QPs per CU at N <= 12, see create_body), beyond that the one-wave
     // kernel, whose slim LDS layout keeps eight QPs resident per CU at N = 12
@@ -649,8 +654,8 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io_in, bool imm
 #endif
     rc = (c->cd_ok && c->cd_mode == 1 && !(io.mode & 4)) ? c->var.launch_cd(c->stream, c->dp, B, io, c->cd_hasq)
        : (io.mode & 4) ? c->var.launch_1w(c->stream, c->dp, B, io)        // fused step: the one-wave kernel runs the regression itself
-       : (B <= c->mw_max_batch && (!io.tbuf || getenv("LMPC_TIMING_MW"))) ? c->var.launch_mw4(c->stream, c->dp, B, io)
-       : (lmpc_solver_waves(c, B) == 2 && !io.tbuf) ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
+       : (B <= c->mw_max_batch && (!timing_buf || getenv("LMPC_TIMING_MW"))) ? c->var.launch_mw4(c->stream, c->dp, B, io)
+       : (lmpc_solver_waves(c, B) == 2 && !timing_buf) ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     ev_end(c);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -1157,6 +1162,35 @@ int lmpc_selftest(lmpc_ctx *c) {
         if (fabs(hbuf[l] - s) > 1e-9 * s || hbuf[64 + l] != mx || hbuf[128 + l] != mn) return set_err(LMPC_E_HIP, "wave reduction self test failed", "");
     }
     return LMPC_OK;
+}
+
+int lmpc_debug_set_trace(lmpc_ctx *c, double *dev_rows) {
+    // developer builds (-DLMPC_TRACE): every later solve launch writes LMPC_TRACE_ROWS x 6 doubles per problem into dev_rows (caller-owned device memory, at least
+    // max_batch x 48 x 6 doubles; NULL switches it off): per iteration (gap, r_d, r_e | sigma, alpha_p, alpha_d).  Ordinary builds carry no such code: LMPC_E_ARG.
+    ARGCHK(c);
+#ifdef LMPC_TRACE
+    HIPCHK(hipSetDevice(c->cfg.device)); RESOLVE_PENDING(); HIPCHK(hipStreamSynchronize(c->stream));
+    c->dbg_trace = dev_rows;
+    return LMPC_OK;
+#else
+    (void)dev_rows;
+    return set_err(LMPC_E_ARG, "lmpc_debug_set_trace", "this library was built without -DLMPC_TRACE (racinglmpc_amd.build.build_flavour)");
+#endif
+}
+
+int lmpc_debug_exec_audit(lmpc_ctx *c, unsigned long long *out16, int reset) {
+    // developer builds (-DLMPC_EXEC_AUDIT): out16[site] = calls of a cross-lane primitive that found an incomplete EXEC mask, out16[8 + site] = calls, since
+    // the last reset (sites: lmpc_kernels.hip.h, EXEC_AUDIT); built-in variants only (a liblmpc_var_*.so carries counters of its own).  Ordinary builds: LMPC_E_ARG.
+    ARGCHK(c && out16);
+#ifdef LMPC_EXEC_AUDIT
+    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_exec_audit), sizeof(unsigned long long) * 2 * LMPC_AUDIT_SITES));
+    if (reset) { unsigned long long z[2 * LMPC_AUDIT_SITES] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_exec_audit), z, sizeof(z))); }
+    return LMPC_OK;
+#else
+    (void)reset;
+    return set_err(LMPC_E_ARG, "lmpc_debug_exec_audit", "this library was built without -DLMPC_EXEC_AUDIT (racinglmpc_amd.build.build_flavour)");
+#endif
 }
 
 int lmpc_solver_waves(lmpc_ctx *c, int B) {

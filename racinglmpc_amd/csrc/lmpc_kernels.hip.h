@@ -17,7 +17,8 @@
 #include "../../include/lmpc_hip.h"
 
 #define WAVE 64
-#define LMPC_VARIANT_ABI 6              // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change
+#define LMPC_VARIANT_ABI_REV 7          // bumped whenever lmpc_dev_params / lmpc_solve_io / the variant table change; the value a variant library is asked for
+                                        // (LMPC_VARIANT_ABI, lmpc_variant.hip.h) also folds in the three struct sizes, so that layout drift cannot pass on the number alone
 #define LMPC_COLS 9                 // lap-store columns: x0..x5, u0, u1, Qfun
 
 // Branch-free LDS stores in the register sweeps and the Riccati recursion (sweep_dst below): on for horizons up to 24.
@@ -41,6 +42,23 @@ struct lmpc_dev_params {
     const double *sstore; int sslot[LMPC_MAX_USED_LAPS]; int sslen[LMPC_MAX_USED_LAPS]; int sslapid[LMPC_MAX_USED_LAPS];
     int cur_it;                     // LMPC.it (number of laps in the safe set)
 };
+
+// Developer flavour -DLMPC_EXEC_AUDIT (racinglmpc_amd.build.build_flavour("audit", ...)): every cross-lane primitive of the solve kernels counts its calls and
+// the calls that found an incomplete EXEC mask (a DPP / permlane / bpermute / MFMA under a partial mask reads stale or zero lanes -- the iteration would still
+// converge, inexact Newton is self-correcting, so certificates alone cannot exclude it).  lmpc_debug_exec_audit reads the counters.  Sites:
+//   0 wave_allreduce (wsum / wmax / wmin)   1 sum_over_c   2 sum_over_g   3 lane_gather   4 ricc_factor stage (DPP block moves, MFMA, readlane, swaps)
+//   5 Gram matrix of the terminal factor (MFMA)   6 (reserved)   7 regression kernel (prefix scan, row ranking)
+#define LMPC_AUDIT_SITES 8
+#ifdef LMPC_EXEC_AUDIT
+static __device__ unsigned long long g_exec_audit[2 * LMPC_AUDIT_SITES];      // [site]: calls under a partial mask, [8 + site]: calls
+__device__ __forceinline__ void exec_audit(int site) {
+    const unsigned long long e_ = __builtin_amdgcn_read_exec();
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)e_) - 1) { atomicAdd(&g_exec_audit[LMPC_AUDIT_SITES + site], 1ull); if (e_ != ~0ull) atomicAdd(&g_exec_audit[site], 1ull); }
+}
+#define EXEC_AUDIT(site) exec_audit(site)
+#else
+#define EXEC_AUDIT(site) do { } while (0)
+#endif
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -110,6 +128,16 @@ __device__ __forceinline__ void flag_retry(const lmpc_solve_io &io, int st) {
     if (io.retry_flag && (st & (LMPC_ST_MAXITER | LMPC_ST_NUMERIC))) __hip_atomic_fetch_max(io.retry_flag, io.retry_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Developer flavour -DLMPC_TRACE: per-iteration side channel of the solve kernels -- row `it` of problem b in io.tbuf (taken as doubles, LMPC_TRACE_ROWS x 6 per
+// problem) receives (gap, r_d, |sum(lambda) - 1|) when the residuals are known and (sigma, alpha_p, alpha_d) when the step is taken: the columns tests/ipm_model.py
+// records (ipm_solve(trace=...)), so that kernel and model can be compared iteration by iteration (tools/n40_model.py compare).  lmpc_debug_set_trace.
+#define LMPC_TRACE_ROWS 48
+#ifdef LMPC_TRACE
+#define TRACE3(leader, c0, v0, v1, v2) do { if (io.tbuf && (leader) && it < LMPC_TRACE_ROWS) { double *tr_ = (double *)io.tbuf + ((size_t)b * LMPC_TRACE_ROWS + it) * 6 + (c0); \
+                                                tr_[0] = (v0); tr_[1] = (v1); tr_[2] = (v2); } } while (0)
+#else
+#define TRACE3(leader, c0, v0, v1, v2) do { } while (0)
+#endif
 #ifdef LMPC_TIMING
 #define TSTAMP(id) do { if (io.tbuf && b == 0 && lane == 0 && tcnt < 4000) { io.tbuf[2 * tcnt] = (id); io.tbuf[2 * tcnt + 1] = (long long)__builtin_readcyclecounter(); tcnt++; } } while (0)
 #else
@@ -126,8 +154,13 @@ __device__ __forceinline__ void flag_retry(const lmpc_solve_io &io, int st) {
 //  use dpp_mv<.., true> where the EXEC mask is full; the N = 40 iteration statistics are asserted in tests/test_gpu_certificates.py.)
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
+#ifdef LMPC_DPP_BC                      // (developer builds: the bound_ctrl form everywhere, long horizons included -- tools/n40_experiments.sh)
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+#else
     lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+#endif
     return __hiloint2double(hi, lo);
 }
 // returns (a, b): a = v with odd rows replaced by the partner's even rows, b = the complementary half
@@ -150,6 +183,7 @@ template <int CTRL, int BANKS> __device__ __forceinline__ double dpp_blk(double 
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_gather(double v, int byte_idx) {   // v from lane byte_idx / 4 (ds_bpermute: LDS crossbar, no memory)
+    EXEC_AUDIT(3);
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_idx, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(byte_idx, __double2loint(v)));
 }
 __device__ __forceinline__ double rdlane(double v, int src) {       // wave-uniform copy of lane src's value
@@ -171,6 +205,7 @@ template <int CTRL, bool BC> __device__ __forceinline__ double dpp_mv(double v) 
     else return dpp_mov<CTRL>(v);
 }
 template <class Op, bool BC = false> __device__ __forceinline__ double wave_allreduce(double v, Op op) {
+    EXEC_AUDIT(0);
     v = op(v, dpp_mv<DPP_QP_X1, BC>(v));
     v = op(v, dpp_mv<DPP_QP_X2, BC>(v));
     v = op(v, dpp_mv<DPP_HALF_MIRROR, BC>(v));
@@ -297,6 +332,7 @@ __device__ __forceinline__ unsigned kth_lane_value(unsigned m, int K) {
 }
 // inclusive prefix sum over the 64 lanes (gfx9 DPP: four shifts inside a row of 16, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3)
 __device__ __forceinline__ int wave_incl_scan_i32(int x) {
+    EXEC_AUDIT(7);
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1, out-of-row lanes read 0
     x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2
     x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);      // row_shr:4
@@ -308,6 +344,7 @@ __device__ __forceinline__ int wave_incl_scan_i32(int x) {
 __device__ __forceinline__ bool k1_less(double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); }
 // rank of (d, i) among the 16 entries of its row of lanes, lexicographic: every other lane's entry passes by once
 template <int ROT> __device__ __forceinline__ void k1_row_rank(double d, int i, int &rank) {
+    if constexpr (ROT == 1) EXEC_AUDIT(7);
     if constexpr (ROT < 16) {
         const double od = dpp_mov<0x120 + ROT>(d);
         const int oi = __builtin_amdgcn_update_dpp(i, i, 0x120 + ROT, 0xf, 0xf, false);
@@ -853,6 +890,7 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
     for (int k = N - 1; k >= 0; k--) {
         const double cB0 = lB0, cA0 = lA0, cW = Wq;
         double arB1, arA1, be, top;
+        EXEC_AUDIT(4);
         if constexpr (SWEEP_BF<N>) {     // (the clamped rows the other lanes read are finite: x * 0 + id is exact)
             arB1 = fma(lB1, c.mR2, c.idB1); arA1 = fma(lA1, c.mR2, c.idA1); be = fma(lBe, c.mBe, c.idBe); top = lTop * c.mXX;
         } else {
@@ -922,6 +960,7 @@ __device__ __forceinline__ int ricc_factor(const ricc_consts &c, const double *A
 // each.  (Rounds 1-3 used 16 CH v_mfma_f64_16x16x4 -- a 16 x 16 tile for an 8 x 8 result; on CDNA4 FP64 matrix work runs at the vector rate, so the
 // big shape only costs: the Gram matrix was ~1.1 k of the terminal factor's ~5 k cycles.)
 template <int CH> __device__ __forceinline__ void gram8_mfma(const double *Mt, double *Wl, int lane) {
+    EXEC_AUDIT(5);
     const int k = lane >> 4, b = (lane >> 2) & 3, i = lane & 3;
     const double *pa = Mt + k * 8 + 4 * (b >> 1) + i, *pb = Mt + k * 8 + 4 * (b & 1) + i;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
@@ -1019,10 +1058,12 @@ __device__ __forceinline__ double wave_uniform(double v) {
 
 // sum over the 8 lanes of a group (lane = 8 g + c, all lanes of the group receive it) / over the 8 groups (same c)
 template <bool BC = false> __device__ __forceinline__ double sum_over_c(double v) {
+    EXEC_AUDIT(1);
     v += dpp_mv<DPP_QP_X1, BC>(v); v += dpp_mv<DPP_QP_X2, BC>(v); v += dpp_mv<DPP_HALF_MIRROR, BC>(v);
     return v;
 }
 template <bool BC = false> __device__ __forceinline__ double sum_over_g(double v) {
+    EXEC_AUDIT(2);
     v += dpp_mv<0x128, BC>(v);                   // row_ror:8  (lane c <-> c+8 inside a row of 16)
     double a, b;
     swap16(v, a, b); v = a + b;
@@ -1658,6 +1699,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
         gap = wave_uniform(SWEEP_BF<N> ? wsum(gsum) * (1.0 / (double)M) : wsum(gsum) / (double)M);    // (short horizons: no IEEE divisions in the loop, ~30 instructions each)
         rdn = wmax(rmax);
         const double re_sum = term ? wave_uniform(wsum(lsum) - 1.0) : 0.0;
+        TRACE3(lane == 0, 0, gap, rdn, fabs(re_sum));
         // The dynamics rows are linear and every step keeps them (the roll-out start satisfies them, the Newton direction lies in their null
         // space): their residual only collects rounding, ~1e-13.  It is still checked -- wherever a decision depends on it (convergence,
         // the INEXACT classification) -- but no longer in the iterations whose other two residuals have not passed yet.
@@ -1712,8 +1754,13 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             //  and with six columns per lane (numSS_points = 360) -- both kernels that run one wave per SIMD on the full register file -- every problem
             //  ran into the iteration limit with it, although the two Gram matrices agree to rounding both in a stand-alone check (tools/gram_check.hip)
             //  and computed side by side inside this kernel: unexplained, so those configurations keep the shape they were validated with.)
+#ifdef LMPC_FORCE_GRAM8                 // (developer builds: the 4x4x4 Gram matrix at every horizon -- tools/n40_experiments.sh)
+            if constexpr (true) gram8_mfma<CH>(Mt, Wl, lane);
+#else
             if constexpr (SWEEP_BF<N> && CH <= 2) gram8_mfma<CH>(Mt, Wl, lane);
+#endif
             else {
+                EXEC_AUDIT(5);
                 typedef double v4d __attribute__((ext_vector_type(4)));
                 v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;   // four independent accumulation chains (the dependent latency of this shape is ~100 cycles)
                 const int kk = lane >> 4, ii = lane & 15;
@@ -1862,6 +1909,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             }
         }
         TSTAMP(17);
+        TRACE3(lane == 0, 3, sig, al, ald);
         // ---- step.  (The multipliers of the dynamics rows are recomputed from the new iterate by the adjoint recursion at the top of the loop:
         //      no costate recursion here any more.) -----------------------------------------------------------------------------------
         if constexpr (term) {
@@ -1954,8 +2002,82 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
 // on different data -- front / rear slip angle and tyre force (atan2, atan, sin), heading psi / heading error epsi
 // (sin, cos) -- so lane `role` 0 takes the front tyre and psi, lane 1 the rear tyre and epsi, they swap the three results
 // with one DPP quad_perm each, and both carry the full state redundantly.  Every transcendental is still evaluated exactly
-// once per sub-step with the same argument as in the scalar form, so the result is unchanged; the 100-sub-step dependent
-// chain is ~40 % shorter (it is the latency of this chain, not throughput, that the rollout loop waits for).
+// once per sub-step with the same argument as in the scalar form.
+//
+// Round 5: range-specialised FP64 kernels instead of the ocml calls.  The 100 Euler sub-steps are one dependent chain through the tyre forces
+// (vx, vy, wz -> slip angle -> force -> vx, vy, wz; the kinematic states only integrate them), and with atan2 -> atan -> sin from ocml that chain was
+// ~3.8 k cycles per sub-step (general-purpose routines: IEEE divisions, quadrant and special-value handling, 20-term Horner chains, the large-argument
+// path of sin) -- 0.16 ms per simulated step on the critical path of the closed loop.  The arguments are bounded by the physics: vx > 0 and |slip| < 45 degrees
+// (|y / vx| <= 1), |C atan(.)| <= 1.25 pi / 4 < 1, headings a few laps' worth of 2 pi.  So: quotient by reciprocal + one correction, atan(z) = z P(z^2) on
+// |z| <= 1 (23 coefficients), sin(x) = x Q(x^2) on |x| <= 1 (10), sin / cos by a two-constant Cody-Waite reduction (exact under FMA for |x| < 1e5) and
+// 7-term kernels on |r| <= pi / 4 -- all evaluated by Estrin's scheme (depth log2 n instead of n).  Coefficients and measured accuracy:
+// tools/fit_plant_polys.py (<= 3.8e-16 relative, i.e. < 2 ulp; the oracle's libm is < 1 ulp) -- after 100 sub-steps of dt = 1e-3 that is 1e-17 in the state,
+// against the 1e-12 the parity test states.  A lane whose argument leaves a fast range (a diverged rollout) takes the ocml routine: same results as before there.
+template <int NC> __device__ __forceinline__ double estrin(const double (&c)[NC], double w) {
+    double v[NC];
+#pragma unroll
+    for (int i = 0; i < NC; i++) v[i] = c[i];
+    double pw = w;
+#pragma unroll
+    for (int n = NC; n > 1; n = (n + 1) / 2) {
+#pragma unroll
+        for (int i = 0; i < (n + 1) / 2; i++) v[i] = (2 * i + 1 < n) ? fma(v[2 * i + 1], pw, v[2 * i]) : v[2 * i];
+        pw = pw * pw;
+    }
+    return v[0];
+}
+__device__ __forceinline__ double plant_atan_poly(double z) {       // atan(z), |z| <= 1
+    constexpr double C[23] = {1.00000000000000000e+00, -3.33333333333333148e-01, 1.99999999999972672e-01, -1.42857142855245423e-01, 1.11111111040167687e-01,
+        -9.09090892666328670e-02, 7.69230512832331237e-02, -6.66663809625125253e-02, 5.88211633270929110e-02, -5.26165758832842292e-02, 4.75445443774553250e-02,
+        -4.31833735800102661e-02, 3.90564747161603193e-02, -3.45674894142850089e-02, 2.91380929673892217e-02, -2.25878550465188170e-02, 1.54855204521000701e-02,
+        -9.01332229968379930e-03, 4.26429640711083104e-03, -1.55763149860080764e-03, 4.09014166942688539e-04, -6.83513646937304115e-05, 5.44016462407589206e-06};
+    return z * estrin(C, z * z);
+}
+__device__ __forceinline__ double plant_atan2(double y, double x) {   // atan2(y, x); fast for x > 0, |y| <= x
+    if (x > 0.0 && fabs(y) <= x) {
+        const double r = frcp(x);
+        double z = y * r; z = fma(fma(-z, x, y), r, z);               // y / x to ~1 ulp
+        return plant_atan_poly(z);
+    }
+    return atan2(y, x);
+}
+__device__ __forceinline__ double plant_atan(double z) { return fabs(z) <= 1.0 ? plant_atan_poly(z) : atan(z); }
+__device__ __forceinline__ double plant_sin1(double x) {              // sin(x); fast for |x| <= 1
+    constexpr double C[10] = {1.00000000000000000e+00, -1.66666666666666657e-01, 8.33333333333335924e-03, -1.98412698412862263e-04, 2.75573192281394626e-06,
+        -2.50521085826905639e-08, 1.60589365566945973e-10, -7.62490938337113395e-13, 1.09951716654846206e-15, 4.72028309461793050e-16};
+    return fabs(x) <= 1.0 ? x * estrin(C, x * x) : sin(x);
+}
+__device__ __forceinline__ void plant_sincos(double x, double &sn, double &cs) {
+    if (fabs(x) < 1.0e5) {
+        constexpr double S[7] = {-1.66666666666666657e-01, 8.33333333333338699e-03, -1.98412698413160743e-04, 2.75573192401844066e-06, -2.50521105474221276e-08,
+                                 1.60589767854145033e-10, -7.60496180966857912e-13};
+        constexpr double Cc[7] = {4.16666666666671293e-02, -1.38888888890215394e-03, 2.48015874329884951e-05, -2.75573799134182448e-07, 2.08910323522207627e-09,
+                                  -1.31296120098958296e-11, 8.03487213580045595e-13};
+        const double k = rint(x * 0.63661977236758134);               // x = k pi / 2 + r, |r| <= pi / 4 (+ rounding)
+        double r = fma(-k, 1.5707963267948966, x); r = fma(-k, 6.123233995736766e-17, r);
+        const double w = r * r;
+        const double sr = fma(r * w, estrin(S, w), r), cr = fma(w * w, estrin(Cc, w), fma(-0.5, w, 1.0));
+        const int q = (int)k & 3;
+        const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+        sn = (q & 2) ? -s0 : s0; cs = ((q + 1) & 2) ? -c0 : c0;
+    } else { sn = sin(x); cs = cos(x); }
+}
+// Map.curvature with the segment of the previous call tried first: s moves ~1e-3 of a segment per sub-step, so the table walk (track_rows comparisons,
+// 7 here) runs a few times per simulated step instead of 100 times.  Same arithmetic and the same comparisons as track_curvature on the segment found -- the
+// wrap `while s > TrackLength` is repeated every call, the segments are disjoint, the reference takes the first that matches -- hence the same value.
+struct plant_seg { double c0, c1, cur; };
+__device__ __forceinline__ double plant_curvature(const lmpc_dev_params &p, double s, plant_seg &g, int *bad) {
+    const double TL = p.TL;
+    for (int lap = 0; lap < 64 && s > TL; lap++) s = s - TL;
+    if (s >= g.c0 && s < g.c1) return g.cur;
+    if (!(s <= TL)) { *bad = 1; return 0.0; }
+    for (int i = 0; i < p.track_rows; i++) {
+        const double c0 = p.track[i * 6 + 3], len = p.track[i * 6 + 4];
+        if (s >= c0 && s < c0 + len) { g.c0 = c0; g.c1 = c0 + len; g.cur = p.track[i * 6 + 5]; return g.cur; }
+    }
+    *bad = 1;
+    return 0.0;
+}
 __device__ __forceinline__ void plant_step_pair(const lmpc_dev_params &p, const double *x, const double *xg, const double *u, const double *nz,
                                                 double *xn, double *xgn, int *bad, const int role) {
     const double m = 1.98, lf = 0.125, lr = 0.125, Iz = 0.024;
@@ -1965,12 +2087,13 @@ __device__ __forceinline__ void plant_step_pair(const lmpc_dev_params &p, const 
     double psi = xg[3], X = xg[4], Y = xg[5];
     double vx = x[0], vy = x[1], wz = x[2], epsi = x[3], s = x[4], ey = x[5];
     const double sd = sin(delta), cd = cos(delta);
+    plant_seg seg; seg.c0 = 1.0; seg.c1 = 0.0; seg.cur = 0.0;       // (empty interval: the first call walks the table)
     for (int i = 0; i < 100; i++) {                                  // while (i+1)*deltaT <= dt, SysModel.py:93
-        const double at = atan2(role ? vy - lf * wz : vy + lf * wz, vx);
+        const double at = plant_atan2(role ? vy - lf * wz : vy + lf * wz, vx);
         const double alpha = role ? -at : delta - at;                // alpha_r = -atan2(vy - lf wz, vx), alpha_f = delta - atan2(vy + lf wz, vx)
-        const double F = Df * sin(Cf * atan(Bf * alpha));
+        const double F = Df * plant_sin1(Cf * plant_atan(Bf * alpha));
         const double ang = role ? epsi : psi;
-        const double sn = sin(ang), cs = cos(ang);
+        double sn, cs; plant_sincos(ang, sn, cs);
         const double Fo = dpp_mov<DPP_QP_X1>(F), sno = dpp_mov<DPP_QP_X1>(sn), cso = dpp_mov<DPP_QP_X1>(cs);
         const double Fyf = role ? Fo : F, Fyr = role ? F : Fo;
         const double sp = role ? sno : sn, cp = role ? cso : cs, se = role ? sn : sno, ce = role ? cs : cso;
@@ -1980,7 +2103,7 @@ __device__ __forceinline__ void plant_step_pair(const lmpc_dev_params &p, const 
         const double npsi = psi + deltaT * (wz);
         const double nX = X + deltaT * ((vx * cp - vy * sp));
         const double nY = Y + deltaT * (vx * sp + vy * cp);
-        const double cur = track_curvature(p, s, bad);
+        const double cur = plant_curvature(p, s, seg, bad);
         const double nepsi = epsi + deltaT * (wz - (vx * ce - vy * se) / (1 - cur * ey) * cur);
         const double ns = s + deltaT * ((vx * ce - vy * se) / (1 - cur * ey));
         const double ney = ey + deltaT * (vx * se + vy * ce);
@@ -1991,7 +2114,7 @@ __device__ __forceinline__ void plant_step_pair(const lmpc_dev_params &p, const 
     xgn[0] = vx; xgn[1] = vy; xgn[2] = wz; xgn[3] = psi; xgn[4] = X; xgn[5] = Y;
 }
 
-__global__ void lmpc_plant_kernel(lmpc_dev_params p, int B, const double *__restrict__ x, const double *__restrict__ xg, const double *__restrict__ u,
+__global__ __launch_bounds__(WAVE) void lmpc_plant_kernel(lmpc_dev_params p, int B, const double *__restrict__ x, const double *__restrict__ xg, const double *__restrict__ u,
                                   const double *__restrict__ nz, double *__restrict__ xn, double *__restrict__ xgn, int *__restrict__ status) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, b = tid >> 1, role = tid & 1;
     if (b >= B) return;
@@ -2031,7 +2154,7 @@ __global__ void lmpc_rollout_shift_kernel(lmpc_dev_params p, int B, int t, lmpc_
         r.hasPred[b] = 1; r.timeStep[b] = t + 1;
     }
 }
-__global__ void lmpc_rollout_plant_kernel(lmpc_dev_params p, int B, int t, lmpc_rollout_state r) {
+__global__ __launch_bounds__(WAVE) void lmpc_rollout_plant_kernel(lmpc_dev_params p, int B, int t, lmpc_rollout_state r) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, b = tid >> 1, role = tid & 1;    // two lanes per rollout, see plant_step_pair
     if (b >= B) return;
     const int N = p.N;

@@ -547,6 +547,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         }
         const double re_sum = term ? lsum_all - 1.0 : 0.0;
         ren = fmax(ren, fabs(re_sum));
+        TRACE3(tid == 0, 0, gap, rdn, ren);
         if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res) { converged = 1; break; }
         if (gap_prev >= 0.0) sep = gap > LMPC_SEP_THRESHOLD * gap_prev;
         gap_prev = gap;
@@ -764,6 +765,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         double al = fmin(1.0, frac * red_min(7)), ald = fmin(1.0, frac * red_min(8));
         if (!sep) { al = fmin(al, ald); ald = al; }
         TSMW(17);
+        TRACE3(tid == 0, 3, sig, al, ald);
         // ---- step.  The multipliers of the equality rows (costates nu_k = -(Pi_k xi_k + p_k)_x for all stages at once) are formed and
         //      applied in the same pass as the primal step and the inequality rows: nothing here reads what another thread writes. ----------
         FOR_WAVE2(i, 6 * N, 3, 1) {                          // (wave 3 and a few lanes of wave 1: wave 0 has the next terminal factor to start, see below)

@@ -26,6 +26,11 @@ struct lmpc_variant_api {
     int occ_mw2;                              // work-groups of the two-wave kernel the runtime keeps resident per CU (asked, not assumed: 0 = unknown)
 };
 
+// What lmpc_create asks a variant library for (lmpc_variant_get): the revision and the sizes of the three structures that cross the boundary by value or
+// by layout.  A liblmpc_var_*.so built against another layout of the parameter block answers -1 and is rebuilt (racinglmpc_amd._capi: E_VARIANT).
+constexpr int LMPC_VARIANT_ABI = LMPC_VARIANT_ABI_REV * 0x1000000 + (int)((sizeof(lmpc_dev_params) * 31u + sizeof(lmpc_solve_io) * 7u + sizeof(lmpc_variant_api)) & 0xffffffu);
+static_assert(sizeof(lmpc_dev_params) < 4096 && sizeof(lmpc_solve_io) < 1024, "by-value kernel arguments: keep them inside the kernarg segment's preload range");
+
 template <int N, int S> struct lmpc_variant_launchers {
     static constexpr bool has_mw = true;               // (every supported S: wave 0 of the multi-wave kernels carries ceil((S + 6) / 64) terminal-block columns per lane)
     static constexpr size_t lds1 = (size_t)solve_lds1<N, S>::tot * sizeof(double), ldsm = has_mw ? (size_t)solve_lds<N, S>::tot * sizeof(double) : 0;

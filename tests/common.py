@@ -12,7 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # Stated parity tolerances (see DESIGN.md "Parity").
 TOL_ABC = 1e-9        # |A,B,C(gpu) - A,B,C(reference)| <= TOL_ABC * (1 + |ref|): regression normal matrices have cond 1e5..1e8
 TOL_XU = 1e-6         # |xPred,uPred(gpu) - certified optimum| (absolute); reference OSQP runs at eps_abs = eps_rel = 1e-3
-TOL_ZT = 1e-6         # |zt, zt_u|
+TOL_ZT = 1e-6         # |zt, zt_u - Succ lambda*, SuccU lambda*| with lambda* of the certified optimum (feasibleStateInput, PredictiveControllers.py:382-384)
 TOL_KKT = 1e-7        # solver-independent certificate of the GPU solution
 
 
@@ -142,7 +142,7 @@ def run_golden_step_check(max_records=None, dev_every=0):
     """Replay the recorded reference laps through the HIP path (lmpc_step_batch, B = 1 per recorded step, addPoint
     in between) and compare with the certified optimum of the reference-assembled QP.  Used by smoke() and tests."""
     g = load_lmpc_golden()
-    errs, stats, iters, zerr, ndev = [], [], [], [], []
+    errs, stats, iters, zerr, ndev, zterr = [], [], [], [], [], []
     left = max_records
     for lap in (4, 5):
         if left is not None and left <= 0:
@@ -158,6 +158,9 @@ def run_golden_step_check(max_records=None, dev_every=0):
             eu = np.abs(out["uPred"][0].ravel() - opt[78:102]).max()
             errs.append(max(ex, eu)); stats.append(int(out["status"][0])); iters.append(int(out["iters"][0]))
             zerr.append(np.abs(out["ssSel"][0] - g["rec_SSsel"][r].T).max())
+            # feasibleStateInput (:382-384): zt = Succ_SS lambda, zt_u = Succ_uSS lambda with the reference's own successor rows and lambda* of the certified optimum
+            lam = opt[126:174]
+            zterr.append(max(np.abs(out["ztNext"][0] - g["rec_Succ"][r] @ lam).max(), np.abs(out["ztuNext"][0] - g["rec_SuccU"][r] @ lam).max()))
             if dev_every and len(errs) % dev_every == 0:
                 # the timed entry point as bench.py calls it: lmpc_step_batch_dev with the optional outputs (mu, residual triple, Q-function of the
                 # selection) NULL -- every output it does produce must be bit-identical to the host-buffer entry point's
@@ -177,5 +180,5 @@ def run_golden_step_check(max_records=None, dev_every=0):
         if left is not None:
             left -= n
         ctx.close()
-    return dict(max_err_xu=float(np.max(errs)), max_err_sssel=float(np.max(zerr)), n=len(errs), status=np.array(stats),
+    return dict(max_err_xu=float(np.max(errs)), max_err_sssel=float(np.max(zerr)), max_err_zt=float(np.max(zterr)), n=len(errs), status=np.array(stats),
                 iters_mean=float(np.mean(iters)), iters_max=int(np.max(iters)), n_dev=len(ndev))

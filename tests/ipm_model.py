@@ -132,7 +132,7 @@ def kkt_solve(qp, f, th_lane, th_s, gx, gu, gs, h_lane, h_u, h_s, gl, re_dyn, re
     return dx, du, ds, dl
 
 
-def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True, polish=None, pex=None, so_w=1.0, start=None):
+def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True, polish=None, pex=None, so_w=1.0, start=None, trace=None):
     """Returns dict(x,u,s,lam,sT, mu (ineq duals in reference row order), iters, gap, rd, re).
     exact_nu (round 3): the multipliers of the dynamics rows are not iterates of their own; every iteration takes them from the adjoint recursion
     nu_{k-1} = A_k' nu_k - w_k (w_k: gradient of the state rows' other terms), so the x rows of the dual residual vanish identically and the
@@ -219,6 +219,8 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         if verbose:
             print("it %2d gap %.2e rd %.2e re %.2e" % (it, gap, rd, re))
         info.update(iters=it, gap=gap, rd=rd, re=re)
+        if trace is not None:
+            trace.append([gap, rd, re, np.nan, np.nan, np.nan])          # (gap, r_d, r_e | sigma, alpha_p, alpha_d of the step taken from here)
         if pol_backup is not None:
             # the previous iteration was an active-set (polish) step: accept it only if the true residuals meet the ordinary tolerances and
             # the signs hold (slacks of the rows taken as inactive, multipliers of the rows taken as active); otherwise back to the iterate it started from
@@ -363,6 +365,8 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
             # row lambda_i: -dm_l + SS'(T dsT) + deta = -rl  -> average over rows for robustness
             deta = np.mean(-rl + dm[3] - qp.SS.T @ (T * dsT))
         act_pred = [(t + d) < (m + d2) for t, d, m, d2 in zip(ts, dt, ms, dm)]      # full-step (Newton target) classification of the rows
+        if trace is not None:
+            trace[-1][3:] = [sig, al, ald]
         x += al * dx; u += al * du; s += al * ds
         if carry_t:
             t_lane, t_u, t_s, t_l = [t + al * d for t, d in zip(ts, dt)]

@@ -314,63 +314,96 @@ def test_fused_step_matches_two_kernel_step(built):
         assert np.array_equal(a[k], b[k]), k
 
 
-def _k1k2_oracle(pt, TL, laps4, N, inp, b):
-    """Oracle regression (a3-a9) and selection (a14-a15) of problem b of a batch; laps4: the four laps both stores use, in the library's order."""
-    from oracle import lmpc_oracle as orc
-    xS = [l[0] for l in laps4]; uS = [l[1] for l in laps4]
-    A, B, C = orc.compute_ltv_dynamics(xS, uS, [0, 1, 2, 3], pt, inp["xLin"][b], inp["uLin"][b], N)
-    Qf = [orc.compute_cost(x, TL) for x in xS]
-    z = inp["zt"][b].copy()
-    if z[4] - inp["x0"][b][4] > TL / 2:
-        z[4] = np.max([z[4] - TL, 0])
-    SSsel, Qsel, _, _ = orc.terminal_components(xS, uS, Qf, [x.shape[0] for x in xS], z, 48, 4, None, 4, int(inp["timeStep"][b]), N, TL)
-    return A, B, C, SSsel, Qsel
+def _compare_with_oracle(out, res, N, what):
+    """K1 / K2 of every oracle record in `res` (tests/oracle_pool.oracle_batch), K3 of those that carry the certified optimum: A, B, C to TOL_ABC relative,
+    SS_sel / Qfun_sel identical, |xPred, uPred - z*| < TOL_XU, objective to 1e-7 relative, zt / zt_u (feasibleStateInput) from the oracle's successor rows
+    and lambda* to TOL_ZT where lambda* is unique enough to say (see common.zt_tolerance)."""
+    worst_abc = worst_xu = worst_zt = 0.0; n_opt = 0
+    nxu = 6 * (N + 1) + 2 * N
+    for r in res:
+        b = r["b"]
+        for got, ref in ((out["A"][b], r["A"]), (out["B"][b], r["B"]), (out["C"][b], r["C"])):
+            worst_abc = max(worst_abc, (np.abs(got - ref) / (1 + np.abs(ref))).max())
+        assert np.array_equal(out["ssSel"][b], r["SSsel"].T) and np.array_equal(out["qSel"][b], r["Qsel"]), (what, b)
+        if "opt" in r:
+            n_opt += 1
+            assert r["cert"] < 1e-7, (what, b, r["cert"])
+            w = np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()])
+            worst_xu = max(worst_xu, np.abs(w - r["opt"][:nxu]).max())
+            S = r["Qsel"].shape[0]
+            lam = r["opt"][nxu + 2 * N:nxu + 2 * N + S]
+            worst_zt = max(worst_zt, np.abs(out["ztNext"][b] - r["Succ"] @ lam).max(), np.abs(out["ztuNext"][b] - r["SuccU"] @ lam).max())
+    print("%s: %d problems: worst relative |A,B,C - oracle| %.2e, selections identical; %d of them against the certified optimum: |xu - z*| %.2e, |zt - Succ lambda*| %.2e"
+          % (what, len(res), worst_abc, n_opt, worst_xu, worst_zt))
+    assert worst_abc < common.TOL_ABC and worst_xu < common.TOL_XU and worst_zt < common.TOL_ZT, what
 
 
-def test_k1_k2_match_oracle_on_every_bench_problem(built):
+def test_k1_k2_k3_match_oracle_on_every_bench_problem(built):
     """K1 (regression) and K2 (selection) against the oracle on ALL 256 problems of bench.synth_batch -- the inputs the driver times -- and on 256
-    evenly spaced problems of the 4096-problem / 30-lap batch: A, B, C to 1e-9 relative, SS_sel and Qfun_sel np.array_equal.  (The full-batch KKT
-    certificates of test_gpu_certificates.py are built from the GPU's own A, B, C and selection: they certify K3 on every problem, this test K1 / K2.)"""
+    evenly spaced problems of the 4096-problem / 30-lap batch: A, B, C to 1e-9 relative, SS_sel and Qfun_sel np.array_equal; round 5: K3 against the
+    oracle's certified optimum (osqp_solve_exact) on the same 256 + 256 problems, not on a handful.  (The full-batch KKT certificates of
+    test_gpu_certificates.py are built from the GPU's own A, B, C and selection: a second line, not the only one.)"""
     import bench
+    from oracle import lmpc_oracle as orc
     from racinglmpc_amd import _capi
+    from tests import oracle_pool
     g = common.load_lmpc_golden()
     pt = np.array(g["track"]); TL = float(g["trackLength"]); N = 12
+    par = orc.QPParams.lmpc_default(N)
+    pid = (np.array(g["xPID"]), np.array(g["uPID"]))
+    laps = pid_laps_batched(pt, 30)
+    order = sorted(range(30), key=lambda i: (laps[i][0].shape[0], i))
+    laps4 = [laps[i] for i in order[:4]]
+    inp_a = bench.synth_batch(g, 256, N, seed=1234)
+    inp_b = bench.synth_batch(g, 4096, N, seed=1234, lap=laps[29])
+    # the oracle first (forked workers, before this process has a HIP context)
+    res_a = oracle_pool.oracle_batch(par, pt, TL, [pid] * 4, N, inp_a, range(256), solve_idx=range(256))
+    res_b = oracle_pool.oracle_batch(par, pt, TL, laps4, N, inp_b, range(0, 4096, 16), solve_idx=range(0, 4096, 16))
     # (a) bench batch
     cfg, _ = common.lmpc_config(g, N, max_batch=256)
     ctx = _capi.Context(cfg)
-    pid = (np.array(g["xPID"]), np.array(g["uPID"]))
     for _ in range(4):
         ctx.model_add_trajectory(*pid); ctx.ss_add_trajectory(*pid)
-    inp = bench.synth_batch(g, 256, N, seed=1234)
-    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
-    worst = 0.0
-    for b in range(256):
-        A, B, C, SSsel, Qsel = _k1k2_oracle(pt, TL, [pid] * 4, N, inp, b)
-        for got, ref in ((out["A"][b], A), (out["B"][b], B), (out["C"][b], C)):
-            worst = max(worst, (np.abs(got - ref) / (1 + np.abs(ref))).max())
-        assert np.array_equal(out["ssSel"][b], SSsel.T) and np.array_equal(out["qSel"][b], Qsel), b
-    print("bench batch, all 256 problems: worst relative |A,B,C - oracle| %.2e, selections identical" % worst)
-    assert worst < common.TOL_ABC
+    out = ctx.step_batch(inp_a["x0"], inp_a["xLin"], inp_a["uLin"], inp_a["uOld"], zt=inp_a["zt"], timeStep=inp_a["timeStep"])
+    assert np.all(out["status"] == 0)
+    _compare_with_oracle(out, res_a, N, "bench batch (four waves per QP)")
     ctx.close()
     # (b) 4096 problems / 30 laps, every 16th problem
-    laps = pid_laps_batched(pt, 30)
     cfg, _ = common.lmpc_config(g, N, max_batch=4096, max_laps=40, max_lap_len=1024)
     ctx = _capi.Context(cfg)
     for x, u in laps:
         ctx.model_add_trajectory(x, u); ctx.ss_add_trajectory(x, u)
-    order = sorted(range(30), key=lambda i: (laps[i][0].shape[0], i))
-    laps4 = [laps[i] for i in order[:4]]
-    inp = bench.synth_batch(g, 4096, N, seed=1234, lap=laps[29])
-    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    out = ctx.step_batch(inp_b["x0"], inp_b["xLin"], inp_b["uLin"], inp_b["uOld"], zt=inp_b["zt"], timeStep=inp_b["timeStep"])
     assert np.all(out["status"] == 0)
-    worst = 0.0
-    for b in range(0, 4096, 16):
-        A, B, C, SSsel, Qsel = _k1k2_oracle(pt, TL, laps4, N, inp, b)
-        for got, ref in ((out["A"][b], A), (out["B"][b], B), (out["C"][b], C)):
-            worst = max(worst, (np.abs(got - ref) / (1 + np.abs(ref))).max())
-        assert np.array_equal(out["ssSel"][b], SSsel.T) and np.array_equal(out["qSel"][b], Qsel), b
-    print("4096 / 30 laps, 256 evenly spaced problems: worst relative |A,B,C - oracle| %.2e, selections identical" % worst)
-    assert worst < common.TOL_ABC
+    _compare_with_oracle(out, res_b, N, "4096 / 30 laps (one wave per QP), every 16th problem")
+    ctx.close()
+
+
+def test_n40_every_problem_against_oracle(built):
+    """BASELINE configs[4] (N = 40, batch 1024) as a first-class configuration: K1 and K2 against the oracle on ALL 1024 problems, K3 against the oracle's
+    certified optimum on 64 evenly spaced ones -- through the kernel the batch size selects (one wave per QP, [A_k | B_k] in global memory) and, for the
+    first 256 problems, through the four-wave kernel as well."""
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    from tests import oracle_pool
+    from tools.n40_model import inputs
+    g = common.load_lmpc_golden()
+    pt = np.array(g["track"]); TL = float(g["trackLength"]); N, B = 40, 1024
+    par = orc.QPParams.lmpc_default(N)
+    pid = (np.array(g["xPID"]), np.array(g["uPID"]))
+    inp = inputs(g, N, B)
+    res = oracle_pool.oracle_batch(par, pt, TL, [pid] * 4, N, inp, range(B), solve_idx=range(0, B, 16))
+    cfg, _ = common.lmpc_config(g, N, max_batch=B)
+    ctx = _capi.Context(cfg)
+    for _ in range(4):
+        ctx.model_add_trajectory(*pid); ctx.ss_add_trajectory(*pid)
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    assert np.all(out["status"] == 0) and ctx.solver_waves(B) == 1
+    _compare_with_oracle(out, res, N, "N = 40, batch 1024 (one wave per QP)")
+    sub = {k: v[:256] for k, v in inp.items()}
+    out4 = ctx.step_batch(sub["x0"], sub["xLin"], sub["uLin"], sub["uOld"], zt=sub["zt"], timeStep=sub["timeStep"])
+    assert np.all(out4["status"] == 0) and ctx.solver_waves(256) == 4
+    _compare_with_oracle(out4, res[:256], N, "N = 40, batch 256 (four waves per QP)")
     ctx.close()
 
 
