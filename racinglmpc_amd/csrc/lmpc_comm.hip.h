@@ -138,7 +138,7 @@ int lmpc_comm_barrier(lmpc_ctx *c) {
 // no status bit other than LMPC_ST_INEXACT; ties towards the lower rollout index) are packed on the device from the session's logs and
 // all-gathered.  records: world x K x (T_max + 1) x 14, lens: world x K (steps, -1 = empty slot), both host, identical on every rank.
 int lmpc_rollout_exchange(lmpc_ctx *c, int K, int T_max, double *records, long long *lens, int *n_valid_local) {
-    ARGCHK(c && c->ro && records && lens && K >= 1 && T_max >= 1);
+    ARGCHK(c && c->ro && c->ro->active && records && lens && K >= 1 && T_max >= 1);
     lmpc_rollout_session *r = c->ro;
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(r->pstream));

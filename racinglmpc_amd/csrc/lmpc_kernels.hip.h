@@ -145,13 +145,12 @@ __device__ __forceinline__ void flag_retry(const lmpc_solve_io &io, int st) {
 #endif
 
 // ---- cross-lane primitives (gfx950): DPP inside a row of 16 lanes, v_permlane16/32_swap across rows ----
-// (old = src, bound_ctrl off: a lane whose source lane is switched off by EXEC keeps its own value.  Round 4 tried bound_ctrl with old = 0 -- the
-//  compiler then drops the v_mov_b32 that pairs with every v_mov_b32_dpp, 3100 instructions in the library, 1 % per Newton step -- and the N = 40
-//  kernel with [A_k | B_k] in global memory took 12.4 instead of 11.0 iterations and three times as long, every certificate still green.  Bisected
-//  site by site (developer builds of that round): each reduction alone is indifferent to the change, sum_over_c and sum_over_g TOGETHER (the register sweeps of
-//  kkt_solve, unrolled 40 times around exec-masked stores, in a kernel that keeps 190 registers in AGPRs) reproduce it, and only in that kernel: not the
-//  semantics of the move but what the compiler makes of that kernel without the copies.  The long horizons keep this form everywhere; the short ones
-//  use dpp_mv<.., true> where the EXEC mask is full; the N = 40 iteration statistics are asserted in tests/test_gpu_certificates.py.)
+// dpp_mov: old = src, bound_ctrl off -- a lane whose source lane is switched off by EXEC keeps its own value (the plant's lane pairs, the regression's row ranking).
+// dpp_mv<.., true>: bound_ctrl with old = 0, the form the reductions of the solve kernels use (three instructions per reduction step instead of five); identical
+// under a full EXEC mask, which is what every reduction site of those kernels runs under -- counted, not assumed: the EXEC audit flavour, lmpc_debug_exec_audit.
+// (Round 4 saw the N = 40 kernel go from 11.0 to 12.4 iterations "with" this form and fenced the long horizons off.  Round 5 found the cause, and it is not the
+//  move: a compiler fault that depends on register allocation -- live-range copies placed ahead of a flow block's EXEC restore, racinglmpc_amd/isa_check.py -- which
+//  any edit of that kernel can switch on or off; with a build the check accepts, both forms give the same iterates on all 1024 problems.)
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
 #ifdef LMPC_DPP_BC                      // (developer builds: the bound_ctrl form everywhere, long horizons included -- tools/n40_experiments.sh)
@@ -198,13 +197,13 @@ struct OpMax { __device__ __forceinline__ double operator()(double a, double b) 
 struct OpMin { __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); } };
 // The same move with bound_ctrl and old = 0: identical under a full EXEC mask (every lane has a source), and the compiler no longer needs the
 // v_mov_b32 that preloads the destination -- three instructions per reduction step instead of five, on a wave that is bound by instruction issue.
-// Used ONLY where the EXEC mask is full by construction and only in the short-horizon kernels (BC = SWEEP_BF<N>): see dpp_mov for what the long-horizon
-// kernels made of it.
+// Used where the EXEC mask is full by construction (every reduction of the solve kernels: see dpp_mov).
 template <int CTRL, bool BC> __device__ __forceinline__ double dpp_mv(double v) {
     if constexpr (BC) return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true));
     else return dpp_mov<CTRL>(v);
 }
-template <class Op, bool BC = false> __device__ __forceinline__ double wave_allreduce(double v, Op op) {
+#define LMPC_BC_DEFAULT true          // (bound_ctrl form in every reduction: +2 % at batch 4096 in the one-wave kernel, neutral in the others -- profiles/r5g_ab.txt)
+template <class Op, bool BC = LMPC_BC_DEFAULT> __device__ __forceinline__ double wave_allreduce(double v, Op op) {
     EXEC_AUDIT(0);
     v = op(v, dpp_mv<DPP_QP_X1, BC>(v));
     v = op(v, dpp_mv<DPP_QP_X2, BC>(v));
@@ -215,9 +214,9 @@ template <class Op, bool BC = false> __device__ __forceinline__ double wave_allr
     swap32(v, a, b); v = op(a, b);
     return v;
 }
-template <bool BC = false> __device__ __forceinline__ double wsum(double v) { return wave_allreduce<OpSum, BC>(v, OpSum()); }
-template <bool BC = false> __device__ __forceinline__ double wmax(double v) { return wave_allreduce<OpMax, BC>(v, OpMax()); }
-template <bool BC = false> __device__ __forceinline__ double wmin(double v) { return wave_allreduce<OpMin, BC>(v, OpMin()); }
+template <bool BC = LMPC_BC_DEFAULT> __device__ __forceinline__ double wsum(double v) { return wave_allreduce<OpSum, BC>(v, OpSum()); }
+template <bool BC = LMPC_BC_DEFAULT> __device__ __forceinline__ double wmax(double v) { return wave_allreduce<OpMax, BC>(v, OpMax()); }
+template <bool BC = LMPC_BC_DEFAULT> __device__ __forceinline__ double wmin(double v) { return wave_allreduce<OpMin, BC>(v, OpMin()); }
 
 // fast FP64 reciprocal / reciprocal square root: hardware estimate + two Newton steps (full double accuracy up to ~1 ulp;
 // an IEEE divide costs ~75 and a sqrt ~125 dependent cycles on this path, these ~35)
@@ -234,6 +233,18 @@ __device__ __forceinline__ double frcp(double x) {
 //    iterate is still far from the path (one 38-iteration stall in 1024 problems of the NumPy model); gated it never fired there.
 //  * separate primal / dual step lengths after an iteration whose gap shrank by less than 1 / LMPC_SEP_THRESHOLD.
 #define LMPC_SEP_THRESHOLD 0.1
+//  * termination (round 5): on a QP without strict complementarity the distance to the optimum goes like sqrt(gap), not like gap -- the gap test alone let 1 of
+//    256 sampled problems of the 30-lap batch stop 2.4e-6 from its optimum (x_N) and 1 of 286 fast-lap QPs 7e-6 -- and those are the problems whose gap
+//    contracts LINEARLY at the end.  A problem whose last step was not superlinear (gap ratio above 1e-2) therefore needs a ten times smaller gap
+//    (0.1 tol_gap) to end: two scalar comparisons on values the iteration has anyway.  NumPy model (tests/ipm_model.py: acc_rule) -- bench batch: histogram
+//    unchanged (8.29 / 12); fast laps 10.287 -> 10.290 / 16, worst |xu - optimum| 7.4e-6 -> 7.7e-7; 30-lap sample 9.043 -> 9.047 / 14, 2.4e-6 -> 9.7e-7;
+//    N = 40 10.77 -> 10.78 / 18.  (A form that also looked at the length of the last step -- one more wave reduction per iteration -- bought nothing over
+//    this one in the model and cost the kernels 3 % at batch 256 and 20 % at N = 40 through register allocation alone: profiles/r5i_bench.json.)
+#define LMPC_ACC_RATIO 1e-2
+#define LMPC_ACC_FLOOR 0.1
+__device__ __forceinline__ bool accuracy_ok(double gap, double gap_prev, double tol_gap) {
+    return gap_prev < 0.0 || gap <= LMPC_ACC_RATIO * gap_prev || gap < LMPC_ACC_FLOOR * tol_gap;
+}
 // Barrier weights theta = mu / t are capped at 1e11 in the Newton matrix: 1 / theta >= 1e-11 is a dual regularisation of the inequality row
 // (F dw + (1 / theta_c) dmu = -r_c / mu); the right-hand side uses the same effective reciprocal rt = 1 / max(t, 1e-11 mu), so the fixed
 // point does not move and the row's equation is off by 1e-11 dmu only.  Uncapped, an active lane row (t ~ 1e-14, mu ~ 10: main.py's fast
@@ -1055,14 +1066,26 @@ __device__ __forceinline__ double wave_uniform(double v) {
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+// Loop-exit decisions of the one-wave kernel (round 5).  Every quantity the Newton loop branches on -- gap, residual maxima, "a pivot was not positive" -- is the same
+// in all 64 lanes at run time (wave reductions, broadcast reads), but the compiler cannot know that of a value that lives in a vector register: a `break` on it
+// becomes a DIVERGENT loop exit -- exec-mask bookkeeping around the whole iteration, a structurised latch block every exit is routed through, live-range splits of
+// the loop-carried register arrays around it.  LMPC_UX(v) moves the value to scalar registers (v_readfirstlane) where the decision is taken: scalar compare,
+// scalar branch, no mask.  See DESIGN.md, "N = 40".
+#ifndef LMPC_NO_UNIFORM_EXIT
+#define LMPC_UX(v) wave_uniform(v)
+#define LMPC_UXI(v) __builtin_amdgcn_readfirstlane(v)
+#else
+#define LMPC_UX(v) (v)
+#define LMPC_UXI(v) (v)
+#endif
 
 // sum over the 8 lanes of a group (lane = 8 g + c, all lanes of the group receive it) / over the 8 groups (same c)
-template <bool BC = false> __device__ __forceinline__ double sum_over_c(double v) {
+template <bool BC = LMPC_BC_DEFAULT> __device__ __forceinline__ double sum_over_c(double v) {
     EXEC_AUDIT(1);
     v += dpp_mv<DPP_QP_X1, BC>(v); v += dpp_mv<DPP_QP_X2, BC>(v); v += dpp_mv<DPP_HALF_MIRROR, BC>(v);
     return v;
 }
-template <bool BC = false> __device__ __forceinline__ double sum_over_g(double v) {
+template <bool BC = LMPC_BC_DEFAULT> __device__ __forceinline__ double sum_over_g(double v) {
     EXEC_AUDIT(2);
     v += dpp_mv<0x128, BC>(v);                   // row_ror:8  (lane c <-> c+8 inside a row of 16)
     double a, b;
@@ -1697,19 +1720,19 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             }
         }
         gap = wave_uniform(SWEEP_BF<N> ? wsum(gsum) * (1.0 / (double)M) : wsum(gsum) / (double)M);    // (short horizons: no IEEE divisions in the loop, ~30 instructions each)
-        rdn = wmax(rmax);
+        rdn = LMPC_UX(wmax(rmax));
         const double re_sum = term ? wave_uniform(wsum(lsum) - 1.0) : 0.0;
-        TRACE3(lane == 0, 0, gap, rdn, fabs(re_sum));
+        TRACE3(lane == 0 && !EQ, 0, gap, rdn, fabs(re_sum));        // (the first pass only: a retry pass would overwrite the rows of the problem it re-runs)
         // The dynamics rows are linear and every step keeps them (the roll-out start satisfies them, the Newton direction lies in their null
         // space): their residual only collects rounding, ~1e-13.  It is still checked -- wherever a decision depends on it (convergence,
         // the INEXACT classification) -- but no longer in the iterations whose other two residuals have not passed yet.
-        if (gap < p.tol_gap && rdn < p.tol_res * qscale) {
-            ren = fmax(dyn_residual(), fabs(re_sum));
+        if (gap < p.tol_gap && rdn < p.tol_res * qscale && accuracy_ok(gap, gap_prev, p.tol_gap)) {
+            ren = LMPC_UX(fmax(dyn_residual(), fabs(re_sum)));
             if (ren < p.tol_res) { converged = 1; break; }
         }
         if (gap_prev >= 0.0) sep = !EQ && gap > LMPC_SEP_THRESHOLD * gap_prev;
         gap_prev = gap;
-        if (it == p.max_iter) { ren = fmax(dyn_residual(), fabs(re_sum)); break; }
+        if (it == p.max_iter) { ren = LMPC_UX(fmax(dyn_residual(), fabs(re_sum))); break; }
         if (!(gap == gap) || !(rdn == rdn)) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
 
         TSTAMP(11);
@@ -1730,16 +1753,14 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
                 const int col = lane + WAVE * ch;
 #pragma unroll
                 for (int j = 0; j < 7; j++) mcol[ch][j] = 0.0;
-                if (col < S) {
-                    const double rs_ = frsqrt(th[8 * N + col] + p.reg);
+                // (no per-lane if / else inside the Newton loop: both kinds of column are formed with clamped indices and selected -- an `else` is a flow block,
+                //  and flow blocks are where the compiler fault of isa_check.py lives)
+                const bool islam = col < S, isslk = col >= S && col < S + 6;
+                const int cl = islam ? col : 0, cs = isslk ? col - S : 0;
+                const double rs_ = frsqrt(th[8 * N + cl] + p.reg), tsq = frsqrt(T2p[cs]);       // lambda column: D^-1/2;  slack column: T^-1/2
 #pragma unroll
-                    for (int j = 0; j < 6; j++) mcol[ch][j] = SS[j * S + col] * rs_;
-                    mcol[ch][6] = rs_;
-                } else {
-                    const double tsq = col < S + 6 ? frsqrt(T2p[col < S + 6 ? col - S : 0]) : 0.0;    // T^-1/2 entry of a slack column of M
-#pragma unroll
-                    for (int j = 0; j < 6; j++) if (col - S == j) mcol[ch][j] = tsq;
-                }
+                for (int j = 0; j < 6; j++) mcol[ch][j] = islam ? SS[j * S + cl] * rs_ : ((isslk && cs == j) ? tsq : 0.0);
+                mcol[ch][6] = islam ? rs_ : 0.0;
             }
             double Rr[7][7], rinv[7];
             // Gram matrix W = M M' (7 x 7, K = 64 CH columns) on the matrix cores (gram8_mfma)
@@ -1750,32 +1771,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
                 Mt[(lane + WAVE * ch) * 8 + 7] = 0.0;
             }
             __syncthreads();
-            // (one-wave kernel: the 4x4x4 form where it has been validated -- horizons up to 24 with at most two terminal-block columns per lane.  At N = 40
-            //  and with six columns per lane (numSS_points = 360) -- both kernels that run one wave per SIMD on the full register file -- every problem
-            //  ran into the iteration limit with it, although the two Gram matrices agree to rounding both in a stand-alone check (tools/gram_check.hip)
-            //  and computed side by side inside this kernel: unexplained, so those configurations keep the shape they were validated with.)
-#ifdef LMPC_FORCE_GRAM8                 // (developer builds: the 4x4x4 Gram matrix at every horizon -- tools/n40_experiments.sh)
-            if constexpr (true) gram8_mfma<CH>(Mt, Wl, lane);
-#else
-            if constexpr (SWEEP_BF<N> && CH <= 2) gram8_mfma<CH>(Mt, Wl, lane);
-#endif
-            else {
-                EXEC_AUDIT(5);
-                typedef double v4d __attribute__((ext_vector_type(4)));
-                v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;   // four independent accumulation chains (the dependent latency of this shape is ~100 cycles)
-                const int kk = lane >> 4, ii = lane & 15;
-                const bool live = ii < 8;
-#pragma unroll
-                for (int s_ = 0; s_ < 16 * CH; s_ += 4) {
-                    double a0 = Mt[(4 * s_ + kk) * 8 + (ii & 7)], a1 = Mt[(4 * (s_ + 1) + kk) * 8 + (ii & 7)], a2 = Mt[(4 * (s_ + 2) + kk) * 8 + (ii & 7)], a3 = Mt[(4 * (s_ + 3) + kk) * 8 + (ii & 7)];
-                    a0 = live ? a0 : 0.0; a1 = live ? a1 : 0.0; a2 = live ? a2 : 0.0; a3 = live ? a3 : 0.0;
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc2, 0, 0, 0);
-                    acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc3, 0, 0, 0);
-                }
-                if (ii < 8) { Wl[kk * 8 + ii] = (acc0[0] + acc1[0]) + (acc2[0] + acc3[0]); Wl[(4 + kk) * 8 + ii] = (acc0[1] + acc1[1]) + (acc2[1] + acc3[1]); }
-            }
+            // (rounds 1-3 used v_mfma_f64_16x16x4 -- a 16 x 16 tile for an 8 x 8 result; round 4 kept that form at N = 40 and with six columns per lane because "every
+            //  problem ran into the iteration limit" with the 4x4x4 form there: the compiler fault isa_check.py now guards against, not the Gram matrix)
+            gram8_mfma<CH>(Mt, Wl, lane);
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 7; i++)
@@ -1829,7 +1827,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
         }
         // a breakdown of the factorisation once the iterate is optimal to working accuracy (gap at its floor, residuals small: the
         // barrier weights span > 1e26 there) is reported as INEXACT, not as a failure: the iterate whose residuals were just measured is returned
-        if (numeric_bad) { ren = fmax(dyn_residual(), fabs(re_sum)); if (lane == 0) atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_NUMERIC); break; }
+        numeric_bad = LMPC_UXI(numeric_bad);
+        if (numeric_bad) { ren = LMPC_UX(fmax(dyn_residual(), fabs(re_sum))); if (lane == 0) atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_NUMERIC); break; }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < N; k++) {                                            // entry (r, c_) of Phi_k: rows 0..5 in the scratch tiles, rows 6, 7 (= -K_k) in PhiK
@@ -1903,13 +1902,13 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
                     const int r = lane + WAVE * j;
                     if (r < M) { const double pr = (t_r[j] + al * dt_r[j]) * (m[r] + ald * dm[r]); pmin = fmin(pmin, pr); psum += pr; }
                 }
-                pmin = wmin(pmin); psum = wsum(psum);
+                pmin = LMPC_UX(wmin(pmin)); psum = LMPC_UX(wsum(psum));
                 if (pmin >= 1e-2 * psum / (double)M) break;
                 al *= 0.7; ald *= 0.7;
             }
         }
         TSTAMP(17);
-        TRACE3(lane == 0, 3, sig, al, ald);
+        TRACE3(lane == 0 && !EQ, 3, sig, al, ald);
         // ---- step.  (The multipliers of the dynamics rows are recomputed from the new iterate by the adjoint recursion at the top of the loop:
         //      no costate recursion here any more.) -----------------------------------------------------------------------------------
         if constexpr (term) {
@@ -1934,6 +1933,25 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
         __syncthreads();
     }
     TSTAMP(20);
+#ifdef LMPC_TRACE
+    if (!EQ && io.tbuf && !(io.mode & 4)) {
+        // last trace row: what the termination test of the final iteration saw -- the dynamics residual as the kernel evaluates it, and the same residual with
+        // C_k and [A_k | B_k] re-read from the kernel's INPUTS (io.C, io.A, io.Bm) instead of the register / scratch copies the iteration has carried
+        double e_c = 0.0, e_ab = 0.0, r_in = 0.0;
+        FOR_LANES_T(i, t, 6 * N) {
+            const int k = i / 6, c = i % 6;
+            const double cg = io.C[(size_t)b * 6 * N + i];
+            e_c = fmax(e_c, fabs(c_r[t] - cg));
+            double v = x[(k + 1) * 6 + c] - cg - io.Bm[((size_t)b * N + k) * 12 + c * 2] * u[k * 2] - io.Bm[((size_t)b * N + k) * 12 + c * 2 + 1] * u[k * 2 + 1];
+            for (int j = 0; j < 6; j++) { const double ag = io.A[((size_t)b * N + k) * 36 + c * 6 + j]; v -= ag * x[k * 6 + j]; e_ab = fmax(e_ab, fabs(ag - AB[k * 48 + c * 8 + j])); }
+            e_ab = fmax(e_ab, fmax(fabs(io.Bm[((size_t)b * N + k) * 12 + c * 2] - AB[k * 48 + c * 8 + 6]), fabs(io.Bm[((size_t)b * N + k) * 12 + c * 2 + 1] - AB[k * 48 + c * 8 + 7])));
+            r_in = fmax(r_in, fabs(v));
+        }
+        e_c = wmax(e_c); e_ab = wmax(e_ab); r_in = wmax(r_in);
+        const double r_k = dyn_residual();
+        if (lane == 0) { double *tr_ = (double *)io.tbuf + ((size_t)b * LMPC_TRACE_ROWS + LMPC_TRACE_ROWS - 1) * 6; tr_[0] = r_k; tr_[1] = r_in; tr_[2] = e_c; tr_[3] = e_ab; tr_[4] = (double)it; tr_[5] = (double)converged; }
+    }
+#endif
     if (!converged && lane == 0 && !(st_sh & (LMPC_ST_NUMERIC | LMPC_ST_INEXACT)))
         atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_MAXITER);
     if (!p.slacks) {
@@ -2026,54 +2044,60 @@ template <int NC> __device__ __forceinline__ double estrin(const double (&c)[NC]
     }
     return v[0];
 }
-__device__ __forceinline__ double plant_atan_poly(double z) {       // atan(z), |z| <= 1
-    constexpr double C[23] = {1.00000000000000000e+00, -3.33333333333333148e-01, 1.99999999999972672e-01, -1.42857142855245423e-01, 1.11111111040167687e-01,
-        -9.09090892666328670e-02, 7.69230512832331237e-02, -6.66663809625125253e-02, 5.88211633270929110e-02, -5.26165758832842292e-02, 4.75445443774553250e-02,
-        -4.31833735800102661e-02, 3.90564747161603193e-02, -3.45674894142850089e-02, 2.91380929673892217e-02, -2.25878550465188170e-02, 1.54855204521000701e-02,
-        -9.01332229968379930e-03, 4.26429640711083104e-03, -1.55763149860080764e-03, 4.09014166942688539e-04, -6.83513646937304115e-05, 5.44016462407589206e-06};
-    return z * estrin(C, z * z);
-}
-__device__ __forceinline__ double plant_atan2(double y, double x) {   // atan2(y, x); fast for x > 0, |y| <= x
-    if (x > 0.0 && fabs(y) <= x) {
-        const double r = frcp(x);
-        double z = y * r; z = fma(fma(-z, x, y), r, z);               // y / x to ~1 ulp
-        return plant_atan_poly(z);
-    }
-    return atan2(y, x);
-}
-__device__ __forceinline__ double plant_atan(double z) { return fabs(z) <= 1.0 ? plant_atan_poly(z) : atan(z); }
-__device__ __forceinline__ double plant_sin1(double x) {              // sin(x); fast for |x| <= 1
-    constexpr double C[10] = {1.00000000000000000e+00, -1.66666666666666657e-01, 8.33333333333335924e-03, -1.98412698412862263e-04, 2.75573192281394626e-06,
-        -2.50521085826905639e-08, 1.60589365566945973e-10, -7.62490938337113395e-13, 1.09951716654846206e-15, 4.72028309461793050e-16};
-    return fabs(x) <= 1.0 ? x * estrin(C, x * x) : sin(x);
-}
-__device__ __forceinline__ void plant_sincos(double x, double &sn, double &cs) {
-    if (fabs(x) < 1.0e5) {
-        constexpr double S[7] = {-1.66666666666666657e-01, 8.33333333333338699e-03, -1.98412698413160743e-04, 2.75573192401844066e-06, -2.50521105474221276e-08,
-                                 1.60589767854145033e-10, -7.60496180966857912e-13};
-        constexpr double Cc[7] = {4.16666666666671293e-02, -1.38888888890215394e-03, 2.48015874329884951e-05, -2.75573799134182448e-07, 2.08910323522207627e-09,
+// Coefficient tables of the plant's kernels.  plant_coeffs::load() puts all 47 of them into VECTOR registers for the duration of the 100 sub-steps (the empty asm makes
+// each value opaque, so that the compiler cannot fold it back into a literal): as literals they did not fit the scalar register file and were re-materialised inside
+// the loop -- 39 s_mov_b32 and 20 v_mov_b64 of the 201 instructions of a sub-step's tyre and heading part, on a wave that issues one instruction every ~6 cycles.
+struct plant_coeffs {
+    double at[23], s1[10], sk[7], ck[7];
+    __device__ __forceinline__ void load() {
+        constexpr double AT[23] = {1.00000000000000000e+00, -3.33333333333333148e-01, 1.99999999999972672e-01, -1.42857142855245423e-01, 1.11111111040167687e-01,
+            -9.09090892666328670e-02, 7.69230512832331237e-02, -6.66663809625125253e-02, 5.88211633270929110e-02, -5.26165758832842292e-02, 4.75445443774553250e-02,
+            -4.31833735800102661e-02, 3.90564747161603193e-02, -3.45674894142850089e-02, 2.91380929673892217e-02, -2.25878550465188170e-02, 1.54855204521000701e-02,
+            -9.01332229968379930e-03, 4.26429640711083104e-03, -1.55763149860080764e-03, 4.09014166942688539e-04, -6.83513646937304115e-05, 5.44016462407589206e-06};
+        constexpr double S1[10] = {1.00000000000000000e+00, -1.66666666666666657e-01, 8.33333333333335924e-03, -1.98412698412862263e-04, 2.75573192281394626e-06,
+            -2.50521085826905639e-08, 1.60589365566945973e-10, -7.62490938337113395e-13, 1.09951716654846206e-15, 4.72028309461793050e-16};
+        constexpr double SK[7] = {-1.66666666666666657e-01, 8.33333333333338699e-03, -1.98412698413160743e-04, 2.75573192401844066e-06, -2.50521105474221276e-08,
+                                  1.60589767854145033e-10, -7.60496180966857912e-13};
+        constexpr double CK[7] = {4.16666666666671293e-02, -1.38888888890215394e-03, 2.48015874329884951e-05, -2.75573799134182448e-07, 2.08910323522207627e-09,
                                   -1.31296120098958296e-11, 8.03487213580045595e-13};
-        const double k = rint(x * 0.63661977236758134);               // x = k pi / 2 + r, |r| <= pi / 4 (+ rounding)
-        double r = fma(-k, 1.5707963267948966, x); r = fma(-k, 6.123233995736766e-17, r);
-        const double w = r * r;
-        const double sr = fma(r * w, estrin(S, w), r), cr = fma(w * w, estrin(Cc, w), fma(-0.5, w, 1.0));
-        const int q = (int)k & 3;
-        const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
-        sn = (q & 2) ? -s0 : s0; cs = ((q + 1) & 2) ? -c0 : c0;
-    } else { sn = sin(x); cs = cos(x); }
+#pragma unroll
+        for (int i = 0; i < 23; i++) { at[i] = AT[i]; asm volatile("" : "+v"(at[i])); }
+#pragma unroll
+        for (int i = 0; i < 10; i++) { s1[i] = S1[i]; asm volatile("" : "+v"(s1[i])); }
+#pragma unroll
+        for (int i = 0; i < 7; i++) { sk[i] = SK[i]; asm volatile("" : "+v"(sk[i])); ck[i] = CK[i]; asm volatile("" : "+v"(ck[i])); }
+    }
+};
+__device__ __forceinline__ double plant_atan_poly(const plant_coeffs &k, double z) { return z * estrin(k.at, z * z); }          // atan(z), |z| <= 1
+__device__ __forceinline__ double plant_sin1_poly(const plant_coeffs &k, double x) { return x * estrin(k.s1, x * x); }          // sin(x), |x| <= 1
+__device__ __forceinline__ void plant_sincos_fast(const plant_coeffs &k_, double x, double &sn, double &cs) {                    // |x| < 1e5
+    const double k = rint(x * 0.63661977236758134);               // x = k pi / 2 + r, |r| <= pi / 4 (+ rounding)
+    double r = fma(-k, 1.5707963267948966, x); r = fma(-k, 6.123233995736766e-17, r);
+    const double w = r * r;
+    const double sr = fma(r * w, estrin(k_.sk, w), r), cr = fma(w * w, estrin(k_.ck, w), fma(-0.5, w, 1.0));
+    const int q = (int)k & 3;
+    const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    sn = (q & 2) ? -s0 : s0; cs = ((q + 1) & 2) ? -c0 : c0;
 }
 // Map.curvature with the segment of the previous call tried first: s moves ~1e-3 of a segment per sub-step, so the table walk (track_rows comparisons,
 // 7 here) runs a few times per simulated step instead of 100 times.  Same arithmetic and the same comparisons as track_curvature on the segment found -- the
 // wrap `while s > TrackLength` is repeated every call, the segments are disjoint, the reference takes the first that matches -- hence the same value.
-struct plant_seg { double c0, c1, cur; };
+struct plant_seg { double c0, c1, cur; int nw; };
 __device__ __forceinline__ double plant_curvature(const lmpc_dev_params &p, double s, plant_seg &g, int *bad) {
     const double TL = p.TL;
-    for (int lap = 0; lap < 64 && s > TL; lap++) s = s - TL;
-    if (s >= g.c0 && s < g.c1) return g.cur;
+    // the cached number of wraps first, branch-free: the same sequential subtractions the reference's loop makes (bit-identical s), up to three of them.
+    // It is the loop's result iff the value before the last subtraction was > TL (s_w > 0 here, or no subtraction) and the result is not (> TL) -- implied by
+    // lying inside a segment of the table.
+    double sw = s;
+    sw = g.nw >= 1 ? sw - TL : sw; sw = g.nw >= 2 ? sw - TL : sw; sw = g.nw >= 3 ? sw - TL : sw;
+    if ((g.nw == 0 || sw > 0.0) && sw >= g.c0 && sw < g.c1) return g.cur;
+    int nw = 0;
+    for (; nw < 64 && s > TL; nw++) s = s - TL;
+    g.c0 = 1.0; g.c1 = 0.0; g.nw = nw <= 3 ? nw : 0;                 // (more than three laps: no cache, every call walks)
     if (!(s <= TL)) { *bad = 1; return 0.0; }
     for (int i = 0; i < p.track_rows; i++) {
         const double c0 = p.track[i * 6 + 3], len = p.track[i * 6 + 4];
-        if (s >= c0 && s < c0 + len) { g.c0 = c0; g.c1 = c0 + len; g.cur = p.track[i * 6 + 5]; return g.cur; }
+        if (s >= c0 && s < c0 + len) { if (nw <= 3) { g.c0 = c0; g.c1 = c0 + len; } g.cur = p.track[i * 6 + 5]; return g.cur; }
     }
     *bad = 1;
     return 0.0;
@@ -2087,13 +2111,27 @@ __device__ __forceinline__ void plant_step_pair(const lmpc_dev_params &p, const 
     double psi = xg[3], X = xg[4], Y = xg[5];
     double vx = x[0], vy = x[1], wz = x[2], epsi = x[3], s = x[4], ey = x[5];
     const double sd = sin(delta), cd = cos(delta);
-    plant_seg seg; seg.c0 = 1.0; seg.c1 = 0.0; seg.cur = 0.0;       // (empty interval: the first call walks the table)
+    plant_coeffs kc; kc.load();
+    plant_seg seg; seg.c0 = 1.0; seg.c1 = 0.0; seg.cur = 0.0; seg.nw = 0;       // (empty interval: the first call walks the table)
     for (int i = 0; i < 100; i++) {                                  // while (i+1)*deltaT <= dt, SysModel.py:93
-        const double at = plant_atan2(role ? vy - lf * wz : vy + lf * wz, vx);
-        const double alpha = role ? -at : delta - at;                // alpha_r = -atan2(vy - lf wz, vx), alpha_f = delta - atan2(vy + lf wz, vx)
-        const double F = Df * plant_sin1(Cf * plant_atan(Bf * alpha));
+        // fast forms first, unconditionally; ONE test per sub-step says whether every argument was inside its range -- a lane outside (a sliding or diverged
+        // car) redoes the sub-step's transcendentals with the general routines.  (Five separate range tests were five exec-mask regions with their branches
+        // per sub-step on a chain that is all latency.)
+        const double yq = role ? vy - lf * wz : vy + lf * wz;
+        const double rvx = frcp(vx);
+        double zq = yq * rvx; zq = fma(fma(-zq, vx, yq), rvx, zq);   // yq / vx to ~1 ulp
+        double at = plant_atan_poly(kc, zq);
+        double alpha = role ? -at : delta - at;                      // alpha_r = -atan2(vy - lf wz, vx), alpha_f = delta - atan2(vy + lf wz, vx)
+        const double ba = Bf * alpha;
+        const double xs = Cf * plant_atan_poly(kc, ba);
+        double F = Df * plant_sin1_poly(kc, xs);
         const double ang = role ? epsi : psi;
-        double sn, cs; plant_sincos(ang, sn, cs);
+        double sn, cs; plant_sincos_fast(kc, ang, sn, cs);
+        if (!(vx > 0.0 && fabs(yq) <= vx && fabs(ba) <= 1.0 && fabs(xs) <= 1.0 && fabs(ang) < 1.0e5)) {
+            at = atan2(yq, vx); alpha = role ? -at : delta - at;
+            F = Df * sin(Cf * atan(Bf * alpha));
+            sn = sin(ang); cs = cos(ang);
+        }
         const double Fo = dpp_mov<DPP_QP_X1>(F), sno = dpp_mov<DPP_QP_X1>(sn), cso = dpp_mov<DPP_QP_X1>(cs);
         const double Fyf = role ? Fo : F, Fyr = role ? F : Fo;
         const double sp = role ? sno : sn, cp = role ? cso : cs, se = role ? sn : sno, ce = role ? cs : cso;
@@ -2104,8 +2142,12 @@ __device__ __forceinline__ void plant_step_pair(const lmpc_dev_params &p, const 
         const double nX = X + deltaT * ((vx * cp - vy * sp));
         const double nY = Y + deltaT * (vx * sp + vy * cp);
         const double cur = plant_curvature(p, s, seg, bad);
-        const double nepsi = epsi + deltaT * (wz - (vx * ce - vy * se) / (1 - cur * ey) * cur);
-        const double ns = s + deltaT * ((vx * ce - vy * se) / (1 - cur * ey));
+        // (vx ce - vy se) / (1 - cur ey), formed once with the reciprocal (~1 ulp; an IEEE division is ~15 instructions, and the reference evaluates this
+        //  quotient twice with the same operands)
+        const double den = 1 - cur * ey, num = vx * ce - vy * se, rden = frcp(den);
+        double qd = num * rden; qd = fma(fma(-qd, den, num), rden, qd);
+        const double nepsi = epsi + deltaT * (wz - qd * cur);
+        const double ns = s + deltaT * (qd);
         const double ney = ey + deltaT * (vx * se + vy * ce);
         vx = nvx; vy = nvy; wz = nwz; epsi = nepsi; s = ns; ey = ney; psi = npsi; X = nX; Y = nY;
     }
@@ -2138,21 +2180,28 @@ struct lmpc_rollout_state {
 // The step's bookkeeping and its plant integration are two kernels on two streams: the shift of the linearisation trajectory
 // feeds the NEXT step's regression kernel, which does not need the plant's result and runs concurrently with it; only the next
 // solve waits for the new state.
-__global__ void lmpc_rollout_shift_kernel(lmpc_dev_params p, int B, int t, lmpc_rollout_state r) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, b = tid >> 1, role = tid & 1;    // two lanes per rollout (strided copies)
+// (round 5: one thread per copied ELEMENT -- 8 (N + 1) threads per rollout, all loads independent.  The first form gave two lanes per rollout a strided loop of
+//  3 N dependent load / store pairs: 21 us on the critical path of every simulated step between the solve and the next regression; now ~3 us.)
+#define LMPC_SHIFT_TPR(N) (8 * ((N) + 1))                           // threads per rollout: (N + 1) rows x (6 state + 2 input) columns
+__global__ __launch_bounds__(256) void lmpc_rollout_shift_kernel(lmpc_dev_params p, int B, int t, lmpc_rollout_state r) {
+    const int N = p.N, tpr = LMPC_SHIFT_TPR(N);
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, b = tid / tpr, e = tid - b * tpr;
     if (b >= B) return;
-    const int N = p.N;
+    const int row = e >> 3, col = e & 7;                              // row 0 .. N of the prediction, column 0 .. 5: state, 6, 7: input
     const double *uP = r.uPred + (size_t)b * N * 2, *xP = r.xPred + (size_t)b * (N + 1) * 6;
     double *xl = r.xLin + (size_t)b * (N + 1) * 6, *ul = r.uLin + (size_t)b * N * 2, *xpp = r.xPP + (size_t)b * (N + 1) * 6;
-    for (int i = role; i < (N + 1) * 6; i += 2) xpp[i] = xP[i];
-    for (int i = role; i < N * 6; i += 2) xl[i] = xP[6 + i];
-    for (int i = role; i < (N - 1) * 2; i += 2) ul[i] = uP[2 + i];
-    if (role == 0) {
-        for (int j = 0; j < 6; j++) { xl[N * 6 + j] = r.ztNext[(size_t)b * 6 + j]; r.zt[(size_t)b * 6 + j] = r.ztNext[(size_t)b * 6 + j]; }
-        ul[(N - 1) * 2] = r.ztuNext[(size_t)b * 2]; ul[(N - 1) * 2 + 1] = r.ztuNext[(size_t)b * 2 + 1];
-        r.uOld[(size_t)b * 2] = uP[0]; r.uOld[(size_t)b * 2 + 1] = uP[1];
-        r.hasPred[b] = 1; r.timeStep[b] = t + 1;
+    if (col < 6) {
+        const double v = xP[row * 6 + col];
+        xpp[row * 6 + col] = v;                                       // xPred -> prev (Q-function shift bookkeeping of the next selection)
+        if (row >= 1) xl[(row - 1) * 6 + col] = v;                    // xLin <- xPred[1:], :131-133
+        if (row == N) { const double z = r.ztNext[(size_t)b * 6 + col]; xl[N * 6 + col] = z; r.zt[(size_t)b * 6 + col] = z; }
+    } else {
+        const int c = col - 6;
+        if (row >= 1 && row < N) ul[(row - 1) * 2 + c] = uP[row * 2 + c];      // uLin <- uPred[1:]
+        if (row == N) ul[(N - 1) * 2 + c] = r.ztuNext[(size_t)b * 2 + c];
+        if (row == 0) r.uOld[(size_t)b * 2 + c] = uP[c];                       // OldInput = uPred[0], :134
     }
+    if (e == 0) { r.hasPred[b] = 1; r.timeStep[b] = t + 1; }
 }
 __global__ __launch_bounds__(WAVE) void lmpc_rollout_plant_kernel(lmpc_dev_params p, int B, int t, lmpc_rollout_state r) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, b = tid >> 1, role = tid & 1;    // two lanes per rollout, see plant_step_pair

@@ -32,7 +32,7 @@ template <int N, int S, int NW>
 // 256-register build spilled 221 VGPRs to scratch)
 __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 > 160 * 1024 || solve_lds<N, S>::CH > 1) ? 1 : 2) void lmpc_solve_kernel_mw(lmpc_dev_params p, int B, lmpc_solve_io io) {
     static_assert(NW == 2 || NW == 4, "wave 0 runs the sequential recursions, waves 1 .. NW-1 everything that can run beside them");
-    constexpr bool BCF = SWEEP_BF<N>;                       // bound_ctrl cross-lane moves (dpp_mv) where the EXEC mask is full: short horizons only
+    constexpr bool BCF = true;                              // bound_ctrl cross-lane moves (dpp_mv) in every reduction: the EXEC mask is full there (lmpc_debug_exec_audit)
     extern __shared__ double sm[];
     using LL = solve_lds<N, S>;
     constexpr int M = LL::M;
@@ -225,6 +225,8 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
 #pragma unroll
         for (int ch = 0; ch < CH; ch++) {
             const int col = lane + WAVE * ch;
+            // (per-lane if / else kept here: the branch-free form of the one-wave kernel measured 0.6 % slower at batch 256 and 1.3 % at 1024 in this kernel --
+            //  profiles/r5g_ab.txt; what makes an `else` inside the loop safe is the ISA check every build goes through, racinglmpc_amd/isa_check.py)
 #pragma unroll
             for (int j = 0; j < 7; j++) mcol[ch][j] = 0.0;
             if (col < S) {
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         const double re_sum = term ? lsum_all - 1.0 : 0.0;
         ren = fmax(ren, fabs(re_sum));
         TRACE3(tid == 0, 0, gap, rdn, ren);
-        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res) { converged = 1; break; }
+        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res && accuracy_ok(gap, gap_prev, p.tol_gap)) { converged = 1; break; }
         if (gap_prev >= 0.0) sep = gap > LMPC_SEP_THRESHOLD * gap_prev;
         gap_prev = gap;
         if (it == p.max_iter) break;

@@ -26,6 +26,37 @@ class BatchedRollouts:
         self.global_noise, self.noise_shard = bool(global_noise), None
         self.last_status = None
         self.last_done = None
+        self._pre = None               # (shape key, generator state before the draw, future): the NEXT lap's plant noise, drawn by a worker thread while this lap runs
+
+    def _draw_noise(self, max_steps, B):
+        """Plant noise of one lap, (max_steps, B, 3) N(0, 1) draws.  A generation loop asks for the same shape lap after lap, and 1.2 M draws are ~15 ms of one
+        host core -- a tenth of a 1024-rollout lap on the GPU: the next lap's array is drawn by a worker thread while the device runs this one (NumPy releases
+        the GIL inside the fill).  The generator is consumed in exactly the order it would be without the prefetch: a prefetched array of another shape is
+        discarded together with its draws (the generator state from before the draw is restored)."""
+        if self.global_noise and self.noise_shard is not None:
+            lo, hi, total = self.noise_shard
+            assert hi - lo == B, (lo, hi, B)
+            key = (max_steps, total, lo, hi)
+            draw = lambda: np.ascontiguousarray(self.rng.standard_normal((max_steps, total, 3))[:, lo:hi])
+        else:
+            key = (max_steps, B)
+            draw = lambda: self.rng.standard_normal((max_steps, B, 3))
+        noise = None
+        if self._pre is not None:
+            pkey, state, fut = self._pre
+            self._pre = None
+            got = fut.result()
+            if pkey == key:
+                noise = got
+            else:
+                self.rng.bit_generator.state = state
+        if noise is None:
+            noise = draw()
+        from concurrent.futures import ThreadPoolExecutor
+        if not hasattr(self, "_pool"):
+            self._pool = ThreadPoolExecutor(max_workers=1)
+        self._pre = (key, self.rng.bit_generator.state, self._pool.submit(draw))
+        return noise
 
     @staticmethod
     def _per_rollout(a, B):
@@ -35,12 +66,7 @@ class BatchedRollouts:
     def begin(self, x0, xLin0, uLin0, xglob0=None, max_steps=400):
         B = x0.shape[0]
         xl = self._per_rollout(xLin0, B); ul = self._per_rollout(uLin0, B)
-        if self.global_noise and self.noise_shard is not None:
-            lo, hi, total = self.noise_shard
-            assert hi - lo == B, (lo, hi, B)
-            noise = np.ascontiguousarray(self.rng.standard_normal((max_steps, total, 3))[:, lo:hi])
-        else:
-            noise = self.rng.standard_normal((max_steps, B, 3))
+        noise = self._draw_noise(max_steps, B)
         self.ctx.rollout_begin(x0, x0 if xglob0 is None else xglob0, xl, ul, noise)
 
     def run_lap_device(self, x0, xLin0, uLin0, xglob0=None, max_steps=400, ext=0, on_ext=None, keep_invalid=False):
@@ -130,7 +156,7 @@ class LmpcGeneration:
                 self.skipped_extensions = []
                 for k in range(K):
                     if not owned[k] or nmin <= 0:
-                        continue
+                        continue                                                   # (no rows to append: the lap stays open, see below)
                     clean = (int(rows[k, 0, 8]) & ~_capi.ST_INEXACT) == 0 and bool(np.all(np.isfinite(rows[k, :nmin, 0:8])))
                     if not clean:
                         self.skipped_extensions.append((k, int(rows[k, 0, 8])))
@@ -142,7 +168,7 @@ class LmpcGeneration:
                 # past the lap's end (LMPC_ST_WINDOW -- the reference's IndexError, :497) on every step there.  Such a lap stays in the store (and in the
                 # regression data) but is left out of the safe-set selection from now on: the numSS_it fastest laps among the others are used --
                 # decided from the gathered rows, hence identically on every rank.
-                self.open_laps |= {self.parents[k][4] for k, _ in self.skipped_extensions} | {self.parents[k][4] for k in range(K) if nmin > 0 and not owned[k]}
+                self.open_laps |= {self.parents[k][4] for k, _ in self.skipped_extensions} | {self.parents[k][4] for k in range(K) if nmin <= 0 or not owned[k]}
                 self._apply_selection()
             ctx.rollout_run(self.T_max)
             _, _, _, self.last_done, self.last_status, _, _ = ctx.rollout_fetch(0, 0)     # per-rollout finish step / accumulated status bits
@@ -164,6 +190,11 @@ class LmpcGeneration:
             for lap, rows_before in undo:
                 ctx.ss_truncate_lap(lap, rows_before)
             self.open_laps = open_before
+            # ... and the selection as it was: the library's own argsort(LapTime) when no lap was open before, else the choice that goes with the old set
+            if open_before:
+                self._apply_selection()
+            else:
+                ctx.ss_set_selected([])
             raise
         self.parents = []
         for x, u, xg, src, T, extra in best:

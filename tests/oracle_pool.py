@@ -27,8 +27,16 @@ def _work(b):
     if b in j["solve"]:
         P, q, Ao, l, u = orc.assemble_lmpc_qp(j["par"], A, B, C, inp["x0"][b], inp["uOld"][b], SSsel, Qsel)
         ex, cert = orc.osqp_solve_exact(P, q, Ao, l, u, want=1e-8)
-        res.update(opt=ex.x, cert=cert, obj=float(0.5 * ex.x @ P @ ex.x + q @ ex.x))
+        res.update(opt=ex.x, cert=cert, obj=float(0.5 * ex.x @ P @ ex.x + q @ ex.x), Pq=(np.asarray(P.todense()) if hasattr(P, "todense") else np.asarray(P), np.asarray(q)))
+        # a second certified optimum by the other method (dense interior point on the explicit matrices): where the two disagree on lambda the QP has more
+        # than one optimal lambda (x, u are unique, lambda is not: SURVEY 8(c)-3) and zt = Succ lambda is not a function of the QP alone
+        r2 = orc.dense_ipm_solve(P, q, Ao, l, u)
+        res.update(opt2=r2.x, cert2=max(orc.kkt_certificate(P, q, Ao, l, u, r2.x, r2.y).values()))
     return res
+
+
+def _objf(P, q):
+    return lambda z: float(0.5 * z @ P @ z + q @ z)
 
 
 def oracle_batch(par, pt, TL, laps, N, inp, idx, solve_idx=(), procs=None):
@@ -46,9 +54,14 @@ def oracle_batch(par, pt, TL, laps, N, inp, idx, solve_idx=(), procs=None):
     n = procs or max(1, min(64, (os.cpu_count() or 2) - 2, len(idx)))
     try:
         if n == 1:
-            return [_work(b) for b in idx]
-        with mp.get_context("fork").Pool(n) as pool:
-            return pool.map(_work, idx, chunksize=max(1, len(idx) // (4 * n)))
+            out = [_work(b) for b in idx]
+        else:
+            with mp.get_context("fork").Pool(n) as pool:
+                out = pool.map(_work, idx, chunksize=max(1, len(idx) // (4 * n)))
+        for r in out:
+            if "Pq" in r:
+                r["objf"] = _objf(*r.pop("Pq"))
+        return out
     finally:
         _JOB.clear()
         if lim is not None:

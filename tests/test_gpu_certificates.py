@@ -26,6 +26,13 @@ def _ctx_pid(g, N, B, **kw):
     return ctx, orc.QPParams.lmpc_default(N)
 
 
+def _no_retry(ctx, what):
+    """No problem of a benign batch may need the retry pass.  (A first pass that fails on EVERY problem and is rescued by the retry kernel still passes every
+    certificate -- at 12.4 instead of 11.0 iterations and a third of the speed: what the compiler fault of racinglmpc_amd/isa_check.py looked like from outside.)"""
+    n = int(ctx.stats().n_retry)
+    assert n == 0, "%s: the retry kernel ran (%d pass(es)): the first pass ended at the iteration limit or broke down" % (what, n)
+
+
 def _certify(par, out, inp, tol=common.TOL_KKT, what=""):
     ok = (out["status"] & ~64) == 0                      # LMPC_ST_INEXACT solutions are certified too
     assert np.all(ok), np.unique(out["status"], return_counts=True)
@@ -51,6 +58,7 @@ def test_bench_batch_certificate_all_kernels(built, B):
     inp = bench.synth_batch(g, B, 12, seed=1234)
     out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
     assert np.all(out["status"] == 0), np.unique(out["status"], return_counts=True)
+    _no_retry(ctx, "bench batch B=%d" % B)
     _certify(par, out, inp, what="bench batch B=%d (%d wave(s) per QP)" % (B, ctx.solver_waves(B)))
     if B == 256:                                         # and the oracle's optimum on a sample of the exact bench inputs
         from tests.test_gpu_configs import oracle_step
@@ -80,9 +88,10 @@ def test_other_horizons_certificate(built, N, B):
                uOld=uP[tb].copy(), zt=xP[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
     out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
     _certify(par, out, inp, what="N=%d B=%d (%d wave(s) per QP)" % (N, B, ctx.solver_waves(B)))
+    _no_retry(ctx, "N=%d B=%d" % (N, B))
     if N == 40:
-        # iteration statistics are part of the contract: 10.98 on average / 18 at most on this batch.  (A cross-lane primitive that fed zeros into a
-        # reduction under a partial EXEC mask passed every certificate -- the iteration still converged -- at 12.4 iterations and a third of the speed.)
+        # iteration statistics are part of the contract: 10.98 on average / 18 at most on this batch, the NumPy model of the kernel 10.66 / 18
+        # (profiles/r5_n40_model.json).  12.4 on average is the signature of a first pass that failed everywhere and was rescued by the retry kernel.
         it = np.asarray(out["iters"])
         assert it.mean() < 11.3 and it.max() <= 19, (it.mean(), it.max())
     ctx.close()
@@ -108,6 +117,7 @@ def test_batch4096_30_laps_certificate(built):
                uOld=uq[tb].copy(), zt=xq[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
     out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
     assert np.all(out["status"] == 0)
+    _no_retry(ctx, "B=4096 / 30 laps")
     _certify(par, out, inp, what="B=4096 / 30 laps")
     ctx.close()
 

@@ -316,9 +316,13 @@ def test_fused_step_matches_two_kernel_step(built):
 
 def _compare_with_oracle(out, res, N, what):
     """K1 / K2 of every oracle record in `res` (tests/oracle_pool.oracle_batch), K3 of those that carry the certified optimum: A, B, C to TOL_ABC relative,
-    SS_sel / Qfun_sel identical, |xPred, uPred - z*| < TOL_XU, objective to 1e-7 relative, zt / zt_u (feasibleStateInput) from the oracle's successor rows
-    and lambda* to TOL_ZT where lambda* is unique enough to say (see common.zt_tolerance)."""
-    worst_abc = worst_xu = worst_zt = 0.0; n_opt = 0
+    SS_sel / Qfun_sel identical, |xPred, uPred - z*| < TOL_XU, objective to 1e-8 relative.  zt / zt_u (feasibleStateInput, :382-384):
+      * always: ztNext = Succ lambda_gpu and ztuNext = SuccU lambda_gpu to rounding, with the ORACLE's successor rows and the kernel's own lambda -- and that
+        lambda is optimal (objective of the kernel's full primal vector = the certified optimum's, feasibility: feasibility_properties / certificates);
+      * against Succ lambda* to TOL_ZT (1 + |zt|) wherever lambda* is determined by the QP: the oracle's two methods (active-set polished ADMM, dense interior
+        point) agree on Succ lambda* to 1e-7.  Where they do not, the QP has a face of optimal lambda (x, u unique, lambda not: SURVEY 8(c)-3), the reference
+        itself returns whichever point its solver lands on, and the count is printed."""
+    worst_abc = worst_xu = worst_zt = worst_id = worst_obj = worst_zt_free = 0.0; n_opt = n_det = 0
     nxu = 6 * (N + 1) + 2 * N
     for r in res:
         b = r["b"]
@@ -327,15 +331,26 @@ def _compare_with_oracle(out, res, N, what):
         assert np.array_equal(out["ssSel"][b], r["SSsel"].T) and np.array_equal(out["qSel"][b], r["Qsel"]), (what, b)
         if "opt" in r:
             n_opt += 1
-            assert r["cert"] < 1e-7, (what, b, r["cert"])
+            assert r["cert"] < 1e-7 and r["cert2"] < 1e-8, (what, b, r["cert"], r["cert2"])
             w = np.concatenate([out["xPred"][b].ravel(), out["uPred"][b].ravel()])
-            worst_xu = max(worst_xu, np.abs(w - r["opt"][:nxu]).max())
+            worst_xu = max(worst_xu, min(np.abs(w - r["opt"][:nxu]).max(), np.abs(w - r["opt2"][:nxu]).max()))
             S = r["Qsel"].shape[0]
-            lam = r["opt"][nxu + 2 * N:nxu + 2 * N + S]
-            worst_zt = max(worst_zt, np.abs(out["ztNext"][b] - r["Succ"] @ lam).max(), np.abs(out["ztuNext"][b] - r["SuccU"] @ lam).max())
-    print("%s: %d problems: worst relative |A,B,C - oracle| %.2e, selections identical; %d of them against the certified optimum: |xu - z*| %.2e, |zt - Succ lambda*| %.2e"
-          % (what, len(res), worst_abc, n_opt, worst_xu, worst_zt))
-    assert worst_abc < common.TOL_ABC and worst_xu < common.TOL_XU and worst_zt < common.TOL_ZT, what
+            sl = slice(nxu + 2 * N, nxu + 2 * N + S)
+            worst_id = max(worst_id, common.zt_err(out["ztNext"][b], out["ztuNext"][b], r["Succ"], r["SuccU"], out["lambd"][b]))
+            full = np.concatenate([w, out["slack"][b], out["lambd"][b], out["sTerm"][b]])
+            # objective of the kernel's primal vector on the ORACLE-assembled QP = the certified optimum's (0.5 z'Pz + q'z, P and q rebuilt from the records)
+            worst_obj = max(worst_obj, abs(r["objf"](full) - r["obj"]) / (1 + abs(r["obj"])))
+            determinate = common.zt_err(r["Succ"] @ r["opt"][sl], r["SuccU"] @ r["opt"][sl], r["Succ"], r["SuccU"], r["opt2"][sl]) < 1e-7
+            e = min(common.zt_err(out["ztNext"][b], out["ztuNext"][b], r["Succ"], r["SuccU"], o[sl]) for o in (r["opt"], r["opt2"]))
+            if determinate:
+                n_det += 1; worst_zt = max(worst_zt, e)
+            else:
+                worst_zt_free = max(worst_zt_free, e)
+    print("%s: %d problems: worst relative |A,B,C - oracle| %.2e, selections identical; %d against the certified optimum: |xu - z*| %.2e, objective %.1e relative, "
+          "|zt - Succ lambda_gpu| %.1e; lambda* determined on %d of them: |zt - Succ lambda*| / (1 + |zt|) %.2e (on the others: %.2e)"
+          % (what, len(res), worst_abc, n_opt, worst_xu, worst_obj, worst_id, n_det, worst_zt, worst_zt_free))
+    assert worst_abc < common.TOL_ABC and worst_xu < common.TOL_XU and worst_zt < common.TOL_ZT and worst_id < 1e-10 and worst_obj < 1e-8, what
+    assert n_opt == 0 or n_det >= n_opt // 2, (what, n_det, n_opt)
 
 
 def test_k1_k2_k3_match_oracle_on_every_bench_problem(built):
@@ -398,11 +413,15 @@ def test_n40_every_problem_against_oracle(built):
     for _ in range(4):
         ctx.model_add_trajectory(*pid); ctx.ss_add_trajectory(*pid)
     out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
-    assert np.all(out["status"] == 0) and ctx.solver_waves(B) == 1
+    assert np.all(out["status"] == 0) and ctx.solver_waves(B) == 1 and int(ctx.stats().n_retry) == 0
     _compare_with_oracle(out, res, N, "N = 40, batch 1024 (one wave per QP)")
+    sub5 = {k: v[:512] for k, v in inp.items()}          # 512 problems: one wave per QP with [A_k | B_k] in LDS (the other long-horizon kernel)
+    out5 = ctx.step_batch(sub5["x0"], sub5["xLin"], sub5["uLin"], sub5["uOld"], zt=sub5["zt"], timeStep=sub5["timeStep"])
+    assert np.all(out5["status"] == 0) and ctx.solver_waves(512) == 1 and int(ctx.stats().n_retry) == 0
+    _compare_with_oracle(out5, res[:512], N, "N = 40, batch 512 (one wave per QP, matrices in LDS)")
     sub = {k: v[:256] for k, v in inp.items()}
     out4 = ctx.step_batch(sub["x0"], sub["xLin"], sub["uLin"], sub["uOld"], zt=sub["zt"], timeStep=sub["timeStep"])
-    assert np.all(out4["status"] == 0) and ctx.solver_waves(256) == 4
+    assert np.all(out4["status"] == 0) and ctx.solver_waves(256) == 4 and int(ctx.stats().n_retry) == 0
     _compare_with_oracle(out4, res[:256], N, "N = 40, batch 256 (four waves per QP)")
     ctx.close()
 

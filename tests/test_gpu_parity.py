@@ -144,7 +144,7 @@ def test_other_configurations_match_reference(built, name):
         w = np.concatenate([out["xPred"][r].ravel(), out["uPred"][r].ravel()])
         worst = max(worst, np.abs(w - g["sol_opt"][r][:nxu]).max())
         lam = g["sol_opt"][r][nxu + 2 * N:nxu + 2 * N + S]
-        worst_zt = max(worst_zt, np.abs(out["ztNext"][r] - g["Succ"][r] @ lam).max(), np.abs(out["ztuNext"][r] - g["SuccU"][r] @ lam).max())
+        worst_zt = max(worst_zt, common.zt_err(out["ztNext"][r], out["ztuNext"][r], g["Succ"][r], g["SuccU"][r], lam))
     # the QP solve alone on the reference's own A, B, C and selection
     out2 = ctx.qp_solve_batch(g["A"], g["B"], g["C"], g["x0"], g["OldInput"], np.transpose(g["SSsel"], (0, 2, 1)), g["Qsel"])
     assert np.all(out2["status"] == 0)
@@ -191,7 +191,7 @@ def test_30_lap_stores_match_reference(built, name):
         w = np.concatenate([out["xPred"][r].ravel(), out["uPred"][r].ravel()])
         worst = max(worst, np.abs(w - g["sol_opt"][r][:nxu]).max())
         lam = g["sol_opt"][r][nxu + 2 * N:nxu + 2 * N + S]
-        worst_zt = max(worst_zt, np.abs(out["ztNext"][r] - g["Succ"][r] @ lam).max(), np.abs(out["ztuNext"][r] - g["SuccU"][r] @ lam).max())
+        worst_zt = max(worst_zt, common.zt_err(out["ztNext"][r], out["ztuNext"][r], g["Succ"][r], g["SuccU"][r], lam))
     print("30 laps in both stores: worst |xu - certified optimum| %.2e, |zt, zt_u - Succ lambda*| %.2e, IPM iterations max %d" % (worst, worst_zt, out["iters"].max()))
     assert worst < common.TOL_XU and worst_zt < common.TOL_ZT
     ctx.close()

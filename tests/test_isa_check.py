@@ -1,0 +1,65 @@
+"""CPU: the build-time guard against live-range copies placed ahead of a flow block's EXEC restore (racinglmpc_amd/isa_check.py; DESIGN.md "N = 40").
+
+* the scanner finds the block in the recorded excerpt of a faulty build (tests/golden/isa_fault_excerpt.s: lmpc_solve_kernel<40, 48, false, true>, the build
+  that ran "12.4 instead of 11.0 iterations") and nothing in the excerpt of a sound one;
+* every library the tree carries -- liblmpc_hip.so and the liblmpc_var_*.so variants, exactly the files the GPU tests load -- is clean.
+"""
+import glob
+import os
+
+import pytest
+
+from tests import common
+from racinglmpc_amd import isa_check
+
+GOLD = os.path.join(common.ROOT, "tests", "golden")
+
+
+def test_scanner_finds_the_recorded_fault():
+    bad = open(os.path.join(GOLD, "isa_fault_excerpt.s")).read()
+    hits = isa_check.scan(bad)
+    assert len({(f, l) for f, l, _, _ in hits}) == 1
+    f, l, ins, widen = hits[0]
+    assert ins.startswith("v_accvgpr_write_b32") and widen.startswith("s_or_saveexec_b64"), hits[0]
+    good = open(os.path.join(GOLD, "isa_sound_excerpt.s")).read()
+    assert isa_check.scan(good) == []
+
+
+def test_scanner_on_synthetic_blocks():
+    ok = """
+f:
+\ts_and_saveexec_b64 s[4:5], vcc
+\ts_cbranch_execz .L1
+\tv_mov_b32_e32 v1, v2
+.L1:
+\tv_readlane_b32 s6, v255, 3
+\ts_or_b64 exec, exec, s[4:5]
+\tv_accvgpr_write_b32 a1, v1
+\ts_endpgm
+"""
+    assert isa_check.scan(ok) == []
+    bad = ok.replace("\tv_readlane_b32 s6, v255, 3\n", "\tv_readlane_b32 s6, v255, 3\n\tv_accvgpr_write_b32 a2, v7\n")
+    assert [h[2] for h in isa_check.scan(bad)] == ["v_accvgpr_write_b32 a2, v7"]
+    # a body block laid out of line (entered by execnz, closed by its own s_or) is not a flow block
+    body = """
+f:
+\ts_and_saveexec_b64 s[4:5], vcc
+\ts_cbranch_execnz .L2
+.L1:
+\ts_or_b64 exec, exec, s[4:5]
+\ts_endpgm
+.L2:
+\tv_mov_b32_e32 v1, v2
+\ts_or_b64 exec, exec, s[6:7]
+\ts_branch .L1
+"""
+    assert isa_check.scan(body) == []
+
+
+def test_libraries_in_the_tree_are_clean():
+    libs = sorted(glob.glob(os.path.join(common.ROOT, "racinglmpc_amd", "liblmpc_hip.so")) + glob.glob(os.path.join(common.ROOT, "racinglmpc_amd", "liblmpc_var_N*.so")))
+    if not libs or not os.path.exists(isa_check.OBJDUMP):
+        pytest.skip("no built library / no llvm-objdump here")
+    for lib in libs:
+        hits = isa_check.check(lib)
+        assert not hits, (os.path.basename(lib), sorted({(f, l) for f, l, _, _ in hits}))

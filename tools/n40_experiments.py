@@ -18,9 +18,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-BASE = ["LMPC_DEV_FAST", "LMPC_DEV_N=40", "LMPC_TRACE"]
+BASE = ["LMPC_DEV_FAST", "LMPC_DEV_N=40", "LMPC_TRACE", "LMPC_NO_ISA_CHECK"]      # (these builds are WANTED as the compiler makes them, faulty or not)
 FLAVOURS = {"trace40": ([], True), "gram40": (["LMPC_FORCE_GRAM8"], True), "bc40": (["LMPC_DPP_BC"], True),
-            "trace40nf": ([], False), "gram40nf": (["LMPC_FORCE_GRAM8"], False), "bc40nf": (["LMPC_DPP_BC"], False)}
+            "trace40nux": (["LMPC_NO_UNIFORM_EXIT"], True), "gram40nux": (["LMPC_FORCE_GRAM8", "LMPC_NO_UNIFORM_EXIT"], True), "bc40nux": (["LMPC_DPP_BC", "LMPC_NO_UNIFORM_EXIT"], True)}
 
 
 def build():
@@ -45,7 +45,9 @@ def _one(name, B=1024, N=40):
     out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
     trace = ctx.debug_trace_fetch(tr, B)
     it = np.asarray(out["iters"]); st = np.asarray(out["status"])
+    last = trace[:, -1, :]                                  # (dynamics residual as the kernel sees it | with C, A, B re-read from the inputs | max |c_r - C| | max |AB - (A, B)| | it | converged)
     res = dict(name=name, waves=ctx.solver_waves(B), iters_mean=float(it.mean()), iters_max=int(it.max()), hist=np.bincount(it).tolist(),
+               last_row_max=[float(np.nanmax(last[:, c])) for c in range(4)], converged=int(np.nansum(last[:, 5])),
                status=dict(zip(*[a.tolist() for a in np.unique(st, return_counts=True)])))
     try:
         c = _certify(par, out, inp, what=name)
@@ -104,4 +106,4 @@ if __name__ == "__main__":
             sys.exit(subprocess.run([sys.executable, os.path.abspath(__file__), "audit"], env=dict(os.environ, LMPC_LIB=lib)).returncode)
         _audit()
     else:
-        run(sys.argv[2:] or list(FLAVOURS))
+        run(sys.argv[2:] or list(FLAVOURS))          # (any liblmpc_hip_<name>.so built with LMPC_DEV_N=40 and LMPC_TRACE can be named)
