@@ -951,7 +951,7 @@ int lmpc_plant_step_batch(lmpc_ctx *c, int B, const double *x, const double *xg,
     int *ds = (int *)(d + (size_t)B * 29);
     double *dx = d, *dg = d + (size_t)B * 6, *du = d + (size_t)B * 12, *dn = d + (size_t)B * 14, *dxn = d + (size_t)B * 17, *dgn = d + (size_t)B * 23;
     H2D(dx, x, (size_t)B * 6); H2D(dg, xg, (size_t)B * 6); H2D(du, u, (size_t)B * 2); H2D(dn, noise, (size_t)B * 3);
-    hipLaunchKernelGGL(lmpc_plant_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, c->stream, c->dp, B, dx, dg, du, dn, dxn, dgn, ds);
+    hipLaunchKernelGGL(lmpc_plant_kernel, dim3((B + PLANT_CARS - 1) / PLANT_CARS), dim3(PLANT_NT), 0, c->stream, c->dp, B, dx, dg, du, dn, dxn, dgn, ds);
     HIPCHK(hipGetLastError());
     D2H(xn, dxn, (size_t)B * 6); D2H(xgn, dgn, (size_t)B * 6); D2H(status, ds, B);
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1060,7 +1060,7 @@ int lmpc_rollout_run(lmpc_ctx *c, int max_steps, int *steps_total, int *n_done) 
         rc = launch_solve(c, B, io, true); if (rc) return rc;      // (the plant consumes uPred without a host round trip: unconditional retry pass)
         HIPCHK(hipEventRecord(r->e_solved, c->stream));
         HIPCHK(hipStreamWaitEvent(r->pstream, r->e_solved, 0));
-        hipLaunchKernelGGL(lmpc_rollout_plant_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, r->pstream, c->dp, B, r->t, st);
+        hipLaunchKernelGGL(lmpc_rollout_plant_kernel, dim3((B + PLANT_CARS - 1) / PLANT_CARS), dim3(PLANT_NT), 0, r->pstream, c->dp, B, r->t, st);
         HIPCHK(hipEventRecord(r->e_plant, r->pstream));
         hipLaunchKernelGGL(lmpc_rollout_shift_kernel, dim3((B * LMPC_SHIFT_TPR((int)N) + 255) / 256), dim3(256), 0, c->stream, c->dp, B, r->t, st);   // then the next step's regression
         HIPCHK(hipGetLastError());
