@@ -145,9 +145,12 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
     # ---- strictly interior start
     x = np.zeros((N + 1, 6)); u = np.zeros((N, 2)); x[0] = qp.x0
     start = start or {}
-    if start.get("u") == "uold":                                             # (experiment: the previous input held over the horizon, pulled inside the box)
+    if isinstance(start.get("u"), str) and start.get("u") == "uold":         # (experiment: the previous input held over the horizon, pulled inside the box)
         ub = np.array([bu[0], bu[2]]) * start.get("shrink", 0.9)
         u[:] = np.clip(qp.uOld, -ub, ub)
+    elif start.get("u") is not None:                                         # (round 5, warm start: the shifted input sequence of the previous closed-loop step, pulled inside the box)
+        ub = np.array([bu[0], bu[2]]) * start.get("shrink", 0.98)
+        u[:] = np.clip(np.asarray(start["u"], float), -ub, ub)
     for k in range(N):
         x[k + 1] = A[k] @ x[k] + B[k] @ u[k] + C[k]
     viol = x[:N] @ Fx.T - bx
@@ -159,7 +162,17 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         return bx - (fl - s), bu - u @ Fu.T, s.copy(), lam.copy()
     t_lane, t_u, t_s, t_l = slacks()
     mu0 = max(1.0, 0.01 * (np.max(np.abs(qp.Qsel)) if qp.term else 1.0)) * start.get("mu_scale", 1.0)
+    if start.get("slack") == "tight":                                        # (warm start: lane slacks at their violation plus a margin instead of one unit inside)
+        s = np.where(viol > 0, viol + start.get("s_margin", 0.05), start.get("s_margin", 0.05))
+    if start.get("lam") is not None:
+        lam = np.maximum(np.asarray(start["lam"], float), start.get("lam_floor", 1e-3)); lam = lam / lam.sum()
     m_lane, m_u, m_s, m_l = mu0 / t_lane, mu0 / t_u, mu0 / t_s, (mu0 / t_l if qp.term else np.zeros(0))
+    if start.get("mu") is not None:
+        # (warm start, dual part: the previous step's multipliers of the lane / input / slack rows, shifted by one stage, floored so that every complementarity
+        #  product is at least mu0 -- and capped at cap * mu0 / t, so that a row that was active and is not any more does not start far off the central path)
+        pm_lane, pm_u, pm_s = start["mu"]
+        cap = start.get("mu_cap", 100.0)
+        m_lane = np.clip(pm_lane, mu0 / t_lane, cap * mu0 / t_lane); m_u = np.clip(pm_u, mu0 / t_u, cap * mu0 / t_u); m_s = np.clip(pm_s, mu0 / t_s, cap * mu0 / t_s)
     mtot = 8 * N + S
     info = {}
     sep = False; gap_prev = None          # separate primal/dual steps only after an iteration with poor progress
@@ -444,6 +457,12 @@ def ipm_solve_cd(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=
     t_lane, t_u, t_s, t_l = bx - (x[:N] @ Fx.T - s), bu - u @ Fu.T, s.copy(), lam.copy()
     mu0 = max(1.0, 0.01 * (np.max(np.abs(qp.Qsel)) if qp.term else 1.0))
     m_lane, m_u, m_s, m_l = mu0 / t_lane, mu0 / t_u, mu0 / t_s, (mu0 / t_l if qp.term else np.zeros(0))
+    if start.get("mu") is not None:
+        # (warm start, dual part: the previous step's multipliers of the lane / input / slack rows, shifted by one stage, floored so that every complementarity
+        #  product is at least mu0 -- and capped at cap * mu0 / t, so that a row that was active and is not any more does not start far off the central path)
+        pm_lane, pm_u, pm_s = start["mu"]
+        cap = start.get("mu_cap", 100.0)
+        m_lane = np.clip(pm_lane, mu0 / t_lane, cap * mu0 / t_lane); m_u = np.clip(pm_u, mu0 / t_u, cap * mu0 / t_u); m_s = np.clip(pm_s, mu0 / t_s, cap * mu0 / t_s)
     mtot = 8 * N + S
     sep = False; gap_prev = None
     qscale = max(1.0, float(np.max(np.abs(qp.Qsel)))) if qp.term else 1.0
