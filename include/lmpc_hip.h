@@ -224,6 +224,9 @@ int lmpc_reset_stats(lmpc_ctx *);
 int lmpc_debug_set_trace(lmpc_ctx *, double *dev_rows /* max_batch x 48 x 6 doubles of device memory, or NULL */);
         /* -DLMPC_TRACE: every later solve launch records, per problem and interior-point iteration, (gap, r_d, r_e | sigma, alpha_p, alpha_d) --
          * the columns of tests/ipm_model.py's trace, for a differential comparison of kernel and model (tools/n40_model.py) */
+int lmpc_debug_rollout_peek(lmpc_ctx *, double *xLin /*B x (N+1) x 6*/, double *uLin /*B x N x 2*/, int *status /*B*/, int *rstatus /*B x N*/);
+        /* (every build) the rollout session's current linearisation trajectories -- the queries of the NEXT step's regression -- and the status words of the step
+         * just taken; any pointer may be NULL.  tools/robustness_sweep.py captures the inputs of a flagged closed-loop regression with it */
 int lmpc_debug_exec_audit(lmpc_ctx *, unsigned long long *out16, int reset);
         /* -DLMPC_EXEC_AUDIT: out16[site] = calls of a cross-lane primitive (DPP / permlane / bpermute reductions, MFMA stages) of the built-in
          * kernels that found an incomplete EXEC mask, out16[8 + site] = calls; sites are listed in csrc/lmpc_kernels.hip.h */

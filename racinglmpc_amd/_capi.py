@@ -52,7 +52,7 @@ EXPORTS = [
     "lmpc_lti_regression", "lmpc_comm_unique_id", "lmpc_comm_init", "lmpc_comm_destroy", "lmpc_comm_info", "lmpc_comm_allgather_dev", "lmpc_comm_allgather",
     "lmpc_comm_allreduce_max", "lmpc_comm_barrier", "lmpc_rollout_exchange",
     "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_solver_waves", "lmpc_plant_step_batch", "lmpc_global_position_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap", "lmpc_ss_truncate_lap",
-    "lmpc_debug_set_trace", "lmpc_debug_exec_audit",
+    "lmpc_debug_set_trace", "lmpc_debug_exec_audit", "lmpc_debug_rollout_peek",
 ]
 
 _lib = None
@@ -466,6 +466,13 @@ class Context:
         self.sync(); self.dev_download(p, out)
         _chk(self.lib.lmpc_debug_set_trace(self._h, None)); self.dev_free(p)
         return out
+
+    def debug_rollout_peek(self, B):
+        """(xLin (B, N+1, 6), uLin (B, N, 2), status (B,), rstatus (B, N)) of the running rollout session, see lmpc_debug_rollout_peek."""
+        N = self.N
+        xl = np.zeros((B, N + 1, 6)); ul = np.zeros((B, N, 2)); st = np.zeros(B, np.int32); rs = np.zeros((B, N), np.int32)
+        _chk(self.lib.lmpc_debug_rollout_peek(self._h, _d(xl), _d(ul), _d(st), _d(rs)))
+        return xl, ul, st, rs
 
     def debug_exec_audit(self, reset=True):
         """(partial[8], calls[8]) of the cross-lane primitives since the last reset (sites: csrc/lmpc_kernels.hip.h)."""

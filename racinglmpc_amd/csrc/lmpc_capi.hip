@@ -1088,6 +1088,18 @@ int lmpc_rollout_fetch(lmpc_ctx *c, int t0, int t1, double *X, double *U, double
     return LMPC_OK;
 }
 
+int lmpc_debug_rollout_peek(lmpc_ctx *c, double *xLin, double *uLin, int *status, int *rstatus) {
+    // developer entry point: the rollout session's current linearisation trajectories (B x (N+1) x 6, B x N x 2 -- what the NEXT step's regression will be asked) and the
+    // status words of the step just taken (per rollout: B; per horizon point of its regression: B x N).  tools/robustness_sweep.py steps a generation one step at a
+    // time with it to capture the inputs of a flagged regression.  Any pointer may be NULL.
+    ARGCHK(c && c->ro && c->ro->active);
+    lmpc_rollout_session *r = c->ro; const size_t Bz = r->B, N = c->cfg.N;
+    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(r->pstream)); HIPCHK(hipStreamSynchronize(c->stream));
+    D2H(xLin, r->d_xLin, Bz * (N + 1) * 6); D2H(uLin, r->d_uLin, Bz * N * 2); D2H(status, r->d_status, Bz); D2H(rstatus, r->d_rst, Bz * N);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LMPC_OK;
+}
+
 int lmpc_rollout_end(lmpc_ctx *c) {
     ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
     if (c->ro) {

@@ -468,3 +468,36 @@ def test_the_two_scan_builds_of_the_regression_kernel_agree(built):
         for a, b in zip(outs[(False, B)], outs[(True, B)]):
             assert np.array_equal(a, b)
         assert np.all(outs[(False, B)][3] == 0)
+
+
+def test_closed_loop_singular_regressions_match_the_oracle(built):
+    """The regressions a 768-rollout closed loop flagged LMPC_ST_REG_SINGULAR (tests/golden/reg_singular_capture.npz, captured on the device by
+    tools/capture_reg_singular.py; the oracle side alone: tests/test_oracle_golden.py): replayed through lmpc_regress_batch, the flag is set on exactly the horizon
+    points on which the oracle raises (no stored row inside the bandwidth: the reference's cvxopt.qp fails there, PredictiveModel.py:170-178), and every other point
+    agrees with the oracle to TOL_ABC."""
+    import os
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    d = np.load(os.path.join(common.GOLDEN, "reg_singular_capture.npz"))
+    g = common.load_lmpc_golden()
+    N = int(d["N"]); R = d["xLin"].shape[0]
+    cfg, _ = common.lmpc_config(g, N, max_batch=R, max_lap_len=512)
+    ctx = _capi.Context(cfg)
+    xs, us = [d["lapx%d" % j] for j in range(4)], [d["lapu%d" % j] for j in range(4)]
+    for x, u in zip(xs, us):
+        ctx.model_add_trajectory(x, u)
+    A, Bm, C, st = ctx.regress_batch(d["xLin"], d["uLin"])
+    assert np.array_equal((st & _capi.ST_REG_SINGULAR) != 0, (d["rst"] & 2) != 0)            # what the closed loop saw is what the replay sees
+    worst = 0.0
+    for c in range(R):
+        for i in range(N):
+            if st[c, i] & _capi.ST_REG_SINGULAR:
+                with pytest.raises(np.linalg.LinAlgError):
+                    orc.regression_and_linearization(xs, us, [0, 1, 2, 3], np.array(d["track"]), d["xLin"][c][i], d["uLin"][c][i])
+                continue
+            Ai, Bi, Ci = orc.regression_and_linearization(xs, us, [0, 1, 2, 3], np.array(d["track"]), d["xLin"][c][i], d["uLin"][c][i])
+            for got, ref in ((A[c, i], Ai), (Bm[c, i], Bi), (C[c, i], Ci)):
+                worst = max(worst, (np.abs(got - ref) / (1 + np.abs(ref))).max())
+    print("captured closed-loop regressions: flags identical, worst relative |A,B,C - oracle| on the others %.2e" % worst)
+    assert worst < common.TOL_ABC
+    ctx.close()

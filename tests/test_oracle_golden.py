@@ -241,3 +241,30 @@ def test_oracle_flow_reproduces_the_executed_reference_closed_loop():
     live = closed_loop.run_laps(closed_loop.OracleFlow(g, 14, solver="osqp"), g, 3, seed=5, noise="legacy")     # ~15 s
     assert [r["steps"] for r in live] == d["laps40"]["5"][:3] == d["oracle_laps40"]["5"][:3]
     assert [r["lap_time"] for r in live] == d["qfun40"]["5"][:3]
+
+
+def test_captured_closed_loop_singular_regressions_raise_in_the_oracle():
+    """tests/golden/reg_singular_capture.npz (tools/capture_reg_singular.py on the GPU box: 768 rollouts, generation 2): the horizon points whose regression the
+    HIP path flagged LMPC_ST_REG_SINGULAR in closed loop.  The oracle -- and the reference's cvxopt.qp (PredictiveModel.py:170-178) -- raises on exactly those
+    points: no stored row lies inside the bandwidth h of the query (the predicted state has left the data: |wz| > 2, a ~ 4), the normal matrix is the zero matrix."""
+    from oracle import lmpc_oracle as orc
+    import os
+    d = np.load(os.path.join(common.GOLDEN, "reg_singular_capture.npz"))
+    N = int(d["N"]); laps = [(d["lapx%d" % j], d["lapu%d" % j]) for j in range(4)]
+    xs, us = [l[0] for l in laps], [l[1] for l in laps]
+    n_flag = 0
+    for c in range(d["xLin"].shape[0]):
+        for i in range(N):
+            x, u = d["xLin"][c][i], d["uLin"][c][i]
+            npts = sum(len(orc.compute_indices(xs[it], us[it], np.hstack((x[0:3], u)))[0]) for it in range(4))
+            flagged = bool(d["rst"][c][i] & 2)
+            if flagged:
+                n_flag += 1
+                assert npts == 0
+                with pytest.raises(np.linalg.LinAlgError):
+                    orc.regression_and_linearization(xs, us, [0, 1, 2, 3], d["track"], x, u)
+            else:
+                assert npts >= 5
+                A, B, C = orc.regression_and_linearization(xs, us, [0, 1, 2, 3], d["track"], x, u)
+                assert np.all(np.isfinite(A)) and np.all(np.isfinite(B)) and np.all(np.isfinite(C))
+    assert n_flag == 6
