@@ -92,6 +92,41 @@ def pid_laps(ctx, g, n_laps, max_steps=600):
 
 
 ROLLOUT_WATCHDOG_S = 240   # multi-rank closed-loop leg: seconds before the watchdog gives it up (it takes about one second)
+HEADLINE_WATCHDOG_S = 300  # multi-rank headline (communicator set-up, timed region, its closing barrier, the gathers behind it): seconds before the watchdog gives it up
+PROGRESS = {}              # what the headline has reached, for the watchdog's line: t0 (timed region entered), t_sync (this rank's device drained after the K steps)
+
+
+class Watchdog:
+    """A collective that one rank never enters would hang the job with nothing on stdout.  While armed, a timer thread waits beside the main thread (which may sit in a
+    C call, GIL released); when it fires, rank 0 prints ONE JSON line in the shape of the headline -- this rank's own rate if the timed steps had finished, else null --
+    with "rccl_error" saying which phase did not return, and every rank leaves with exit status 3 (a launcher then reports the job as failed, not as rc 0)."""
+
+    def __init__(self, rank, world, make_line):
+        self.rank, self.world, self.make_line, self.timer, self.phase = rank, world, make_line, None, ""
+
+    def arm(self, seconds, phase):
+        import threading
+        self.disarm(); self.phase = phase
+        if self.world <= 1 and not os.environ.get("LMPC_BENCH_FORCE_WATCHDOG"):
+            return
+        self.timer = threading.Timer(seconds, self._fire, args=(seconds,)); self.timer.daemon = True; self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel(); self.timer = None
+
+    def _fire(self, seconds):
+        fail(self.rank, self.make_line, "%s did not return within %d s on rank %d (watchdog)" % (self.phase, seconds, self.rank))
+
+
+def fail(rank, make_line, message, code=3):
+    """The headline cannot be completed (a collective hung, the communicator could not be built): rank 0 prints the line it has with "rccl_error", all leave non-zero."""
+    try:
+        if rank == 0:
+            sys.stdout.flush()
+            print(json.dumps(make_line(message)), flush=True)
+    finally:
+        os._exit(code)
 PROFILE_EVERY = 5      # HIP events around every 5th launch of each kernel inside the timed region (an event record costs ~4 us of stream time)
 
 
@@ -101,7 +136,7 @@ def time_steps(ctx, B, a, steps, warmup, sync=None):
         ctx.step_batch_dev(B, a)
     (sync or ctx.sync)()
     ctx.reset_stats(); ctx.set_profiling(PROFILE_EVERY)
-    t0 = time.perf_counter()
+    t0 = time.perf_counter(); PROGRESS["t0"] = t0; PROGRESS.pop("t_sync", None)
     for _ in range(steps):
         ctx.step_batch_dev(B, a)
     (sync or ctx.sync)()
@@ -268,6 +303,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the sweep / extra configurations / rollout leg")
     ap.add_argument("--rollouts-per-gpu", type=int, default=1024)
     ap.add_argument("--dry-run", action="store_true", help="start the ranks and the rendezvous only (no GPU needed): proves the N-rank launch path")
+    ap.add_argument("--dry-run-rccl", action="store_true", help="communicator set-up, one barrier and one gather only -- on a box with fewer GPUs than ranks the ranks share "
+                    "device 0 and RCCL refuses: the failure path of lmpc_comm_init with world > 1 (one JSON line with rccl_error, exit status 3)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -299,9 +336,36 @@ def main():
     ge.build()                                       # no-op when the library is current (file-locked against concurrent ranks)
     g = load_seed()
     N, B = args.horizon, args.batch
-    ctx = make_ctx(g, N, max(B, 1 if args.no_extras else args.rollouts_per_gpu), local)
+    def minimal_line(message):                       # what the watchdog / a failed communicator set-up prints: the headline's keys, this rank's own rate if it got that far
+        local_dt = PROGRESS["t_sync"] - PROGRESS["t0"] if "t_sync" in PROGRESS and "t0" in PROGRESS else None
+        return {"metric": "QP solves/sec (N=%d, nx=6, nu=2)" % N, "value": B * args.steps / local_dt if local_dt else None, "unit": "solves/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": local_dt / args.steps * 1e3 if local_dt else None, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "batch=%d LMPC QPs per GPU, N=%d" % (B, N), "ranks": world},
+                "rccl_error": message, "note": "value, if any, is rank 0's own rate over its K steps (no cross-rank barrier closed the region)"}
+    wd = Watchdog(rank, world, minimal_line)
+    try:
+        ctx = make_ctx(g, N, max(B, 1 if args.no_extras else args.rollouts_per_gpu), local)
+    except Exception:                                # noqa: BLE001
+        if not args.dry_run_rccl or local == 0:
+            raise
+        ctx = make_ctx(g, N, B, 0)                   # (--dry-run-rccl on a box with fewer GPUs than ranks: share device 0, RCCL will refuse)
     S = ctx.S
-    comm = parallel.comm_from_env(ctx, force_rccl=os.environ.get("LMPC_BENCH_FORCE_DIST") == "1")
+    wd.arm(60 if args.dry_run_rccl else HEADLINE_WATCHDOG_S, "communicator set-up (rendezvous, ncclCommInitRank)")
+    try:
+        comm = parallel.comm_from_env(ctx, force_rccl=os.environ.get("LMPC_BENCH_FORCE_DIST") == "1" or args.dry_run_rccl)
+        if args.dry_run_rccl:
+            wd.arm(60, "first barrier / gather of the communicator")
+            comm.barrier()
+            ranks = comm.allgather(np.array([rank], dtype=np.int64)).reshape(-1)
+            wd.disarm()
+            if rank == 0:
+                print(json.dumps({"dry_run_rccl": True, "n_gpus": world, "rccl_ranks": ctx.comm_info()[1], "gathered_ranks": ranks.tolist()}), flush=True)
+            comm.close(); ctx.close()
+            return
+    except Exception as e:                           # noqa: BLE001  (lmpc_comm_init failed: RCCL's own message is in the exception)
+        wd.disarm()
+        fail(rank, minimal_line, "%s: %s" % (type(e).__name__, str(e)[:400]))
+    wd.arm(HEADLINE_WATCHDOG_S, "the timed region or its closing barrier (one all-reduce per rank)")
     if rank == 0 and world > 1:                       # a left-over "extras done" event of a killed launch (same parent, same port) must not release the other ranks early
         try:
             os.remove(parallel._rdzv_file(port) + ".extras")
@@ -312,6 +376,7 @@ def main():
 
     def sync_all():                                  # device drained on this rank, then on every rank
         ctx.sync()
+        PROGRESS["t_sync"] = time.perf_counter()
         comm.barrier()
 
     dt, st = time_steps(ctx, B, a, args.steps, args.warmup, sync=sync_all)
@@ -326,6 +391,7 @@ def main():
     ctx.dev_download(a.status, status); ctx.dev_download(a.iters, iters)
     n_ok = int(comm.allgather(np.array([np.sum(status == 0)], dtype=np.int64)).sum())
     comm_info = ctx.comm_info()
+    wd.disarm()                                      # the headline is complete: every collective it needs has returned
 
     out = None
     if rank == 0:
@@ -409,12 +475,13 @@ def main():
         if world > 1:
             import threading
 
-            def _bail():
+            def _bail():                              # (the headline itself is complete here: the line is printed in full, but the job still ends non-zero)
                 if rank == 0:
                     out["config_rollouts"] = {"error": "multi-rank rollout leg did not return within %d s (watchdog)" % ROLLOUT_WATCHDOG_S}
+                    out["rccl_error"] = out["config_rollouts"]["error"]
                     sys.stdout.flush()
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(3)
             watchdog = threading.Timer(ROLLOUT_WATCHDOG_S, _bail); watchdog.daemon = True; watchdog.start()
         try:                                         # (deterministic failures -- e.g. too few valid laps -- occur on every rank alike)
             leg = rollout_leg(g, comm, ctx, args.rollouts_per_gpu)

@@ -78,15 +78,17 @@ def host_signal(tag, port):
     """Same-node host-side event (a file next to the rendezvous file): ranks that have nothing to do on their GPU while another rank works
     alone wait for it in host_wait -- sleeping -- instead of spinning inside a collective for seconds."""
     path = _rdzv_file(port) + "." + "".join(ch for ch in tag if ch.isalnum())
-    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+    tmp = path + ".tmp%d" % os.getpid()                            # written aside and renamed into place: a waiter sees the whole payload or the old file
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
     with os.fdopen(fd, "wb") as f:
         f.write(int(os.getpid()).to_bytes(8, "little"))
+    os.replace(tmp, path)
     return path
 
 
 def host_wait(tag, port, timeout=3600.0, poll=0.05, writer_pid=None):
     """Sleep until host_signal(tag, port) has been called by a LIVE process of this launch.  The event file carries its writer's pid: a file
-    whose writer is gone -- left behind by a killed launch with the same parent, port and nonce -- is ignored (and removed), so it cannot release
+    whose writer is gone -- left behind by a killed launch with the same parent, port and nonce -- is ignored, so it cannot release
     the waiters early; writer_pid (the signalling rank's pid, if the caller knows it) turns a dead signaller into an error instead of a sleep
     until the timeout."""
     path = _rdzv_file(port) + "." + "".join(ch for ch in tag if ch.isalnum())
@@ -97,11 +99,8 @@ def host_wait(tag, port, timeout=3600.0, poll=0.05, writer_pid=None):
                 buf = f.read()
             if len(buf) == 8 and _alive(int.from_bytes(buf, "little")):
                 return path
-            if len(buf) == 8:                                        # stale: its writer is dead
-                try:
-                    os.remove(path)
-                except OSError:
-                    pass
+            # (a file whose writer is dead is stale: ignored, NOT removed -- a waiter that unlinked it could delete the fresh signal the live writer has
+            #  just renamed into place; the signaller of a launch removes left-overs itself before it starts, bench.py)
         except OSError:
             pass
         if writer_pid is not None and not _alive(int(writer_pid)):

@@ -56,3 +56,22 @@ def test_k1_slack_case_construction(monkeypatch):
     idx, K = orc.compute_indices(case["x"], case["u"], np.hstack([case["xq"][:3], case["uq"]]))
     assert sorted(idx) == sorted(case["decoys"][:6] + [case["victim"]])
     assert sorted(idx) == sorted(emu["exact_top"])
+
+
+def test_bench_watchdog_prints_one_line_and_exits_non_zero():
+    """bench.py's headline watchdog (a collective that never returns must not leave the job hanging, nor end it with rc 0): while the main thread sits in a call
+    that does not come back, rank 0 prints one JSON line with `rccl_error` naming the phase, and the process ends with status 3."""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; "
+            "wd = bench.Watchdog(0, 2, lambda m: {'metric': 'QP solves/sec (N=12, nx=6, nu=2)', 'value': None, 'rccl_error': m}); "
+            "wd.arm(0.3, 'closing barrier'); time.sleep(30)") % common.ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=60)
+    assert r.returncode == 3, (r.returncode, r.stderr[-300:])
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["value"] is None and "closing barrier did not return within 0 s on rank 0" in line["rccl_error"]
+    # a single rank arms nothing (no collective to hang in)
+    code1 = code.replace("bench.Watchdog(0, 2,", "bench.Watchdog(0, 1,").replace("time.sleep(30)", "time.sleep(0.6); print('alive')")
+    r1 = subprocess.run([sys.executable, "-c", code1], capture_output=True, timeout=60)
+    assert r1.returncode == 0 and r1.stdout.decode().strip() == "alive"

@@ -168,7 +168,7 @@ def test_host_wait_ignores_a_dead_writers_event(tmp_path, monkeypatch):
         f.write(int(dead.pid).to_bytes(8, "little"))
     with pytest.raises(TimeoutError):
         parallel.host_wait("extras", port, timeout=0.5)
-    assert not os.path.exists(path)                                  # the stale event was removed
+    assert os.path.exists(path)                                      # ignored, not removed: a waiter that unlinked it could delete the live writer's fresh signal (host_signal renames it into place)
     with pytest.raises(RuntimeError):
         parallel.host_wait("extras", port, timeout=30.0, writer_pid=dead.pid)
     threading.Timer(0.3, lambda: parallel.host_signal("extras", port)).start()
