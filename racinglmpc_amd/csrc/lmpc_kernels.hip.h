@@ -234,16 +234,17 @@ __device__ __forceinline__ double frcp(double x) {
 //  * separate primal / dual step lengths after an iteration whose gap shrank by less than 1 / LMPC_SEP_THRESHOLD.
 #define LMPC_SEP_THRESHOLD 0.1
 //  * termination (round 5): on a QP without strict complementarity the distance to the optimum goes like sqrt(gap), not like gap -- the gap test alone let 1 of
-//    256 sampled problems of the 30-lap batch stop 2.4e-6 from its optimum (x_N) and 1 of 286 fast-lap QPs 7e-6 -- and those are the problems whose gap
-//    contracts LINEARLY at the end.  A problem whose last step was not superlinear (gap ratio above 1e-2) therefore needs a ten times smaller gap
-//    (0.1 tol_gap) to end: two scalar comparisons on values the iteration has anyway.  NumPy model (tests/ipm_model.py: acc_rule) -- bench batch: histogram
-//    unchanged (8.29 / 12); fast laps 10.287 -> 10.290 / 16, worst |xu - optimum| 7.4e-6 -> 7.7e-7; 30-lap sample 9.043 -> 9.047 / 14, 2.4e-6 -> 9.7e-7;
-//    N = 40 10.77 -> 10.78 / 18.  (A form that also looked at the length of the last step -- one more wave reduction per iteration -- bought nothing over
-//    this one in the model and cost the kernels 3 % at batch 256 and 20 % at N = 40 through register allocation alone: profiles/r5i_bench.json.)
-#define LMPC_ACC_RATIO 1e-2
-#define LMPC_ACC_FLOOR 0.1
-__device__ __forceinline__ bool accuracy_ok(double gap, double gap_prev, double tol_gap) {
-    return gap_prev < 0.0 || gap <= LMPC_ACC_RATIO * gap_prev || gap < LMPC_ACC_FLOOR * tol_gap;
+//    256 sampled problems of the 30-lap batch stop 2.4e-6 from its optimum (x_N), 1 of 286 fast-lap QPs 7e-6 and 1 of 128 N = 40 problems 5e-6 -- and those
+//    are the problems whose gap contracts LINEARLY at the end.  A problem whose last step was not superlinear (gap ratio above 1e-3) therefore needs a smaller
+//    gap to end: 0.1 tol_gap, and 0.03 tol_gap at horizons beyond 24 (the error constant grows with the number of coupled stages): scalar comparisons on
+//    values the iteration has anyway.  NumPy model (tests/ipm_model.py: acc_rule; tools/ipm_acc_sets.py) -- bench batch 8.28 -> 8.30 / 12 unchanged
+//    maximum, worst |xu - optimum| 2.0e-7; fast laps 10.29 / 16, 7.4e-6 -> 7.7e-7; 30-lap sample 9.04 -> 9.05 / 14, 2.4e-6 -> 9.7e-7; N = 40 10.81 -> 10.83 / 18,
+//    4.9e-6 -> 1.6e-7.  (A form that also looked at the length of the last step -- one more wave reduction per iteration -- bought nothing over this one in the
+//    model and cost the kernels 3 % at batch 256 and 20 % at N = 40 through register allocation alone: profiles/r5i_bench.json.)
+#define LMPC_ACC_RATIO 1e-3
+template <int N> constexpr double LMPC_ACC_FLOOR = N > 24 ? 0.03 : 0.1;
+template <int N> __device__ __forceinline__ bool accuracy_ok(double gap, double gap_prev, double tol_gap) {
+    return gap_prev < 0.0 || gap <= LMPC_ACC_RATIO * gap_prev || gap < LMPC_ACC_FLOOR<N> * tol_gap;
 }
 // Barrier weights theta = mu / t are capped at 1e11 in the Newton matrix: 1 / theta >= 1e-11 is a dual regularisation of the inequality row
 // (F dw + (1 / theta_c) dmu = -r_c / mu); the right-hand side uses the same effective reciprocal rt = 1 / max(t, 1e-11 mu), so the fixed
@@ -987,6 +988,103 @@ template <int CH> __device__ __forceinline__ void gram8_mfma(const double *Mt, d
     Wl[(4 * (b >> 1) + (lane >> 4)) * 8 + 4 * (b & 1) + (lane & 3)] = (acc0 + acc1) + (acc2 + acc3);
 }
 
+// Explicit, re-orthogonalised Q of the terminal factor (round 5).  The terminal block needs the orthogonal projector onto the row space of M = [E D^-1/2 | T^-1/2]
+// (7 x (S + 6); the Newton step's lambda part is v = -c~ + Q z, Q = M' R^-1 with R'R = M M').  R comes from a Cholesky factorisation of the Gram matrix, whose
+// condition number is the SQUARE of M's -- and D spans 1e-6 .. 1e11 once the active set settles: the computed Q = M' R^-1 is then orthonormal to 1e-2 only,
+// the Newton directions of the last iterations carry that error, the dual residual stalls near 1e-9 and the iteration takes one more step.  That -- not the
+// step rules -- was the whole difference between the kernels and their NumPy model (which orthogonalises by Gram-Schmidt): 8.69 / 13 against 8.29 / 12 iterations on
+// the bench batch, 11.18 / 19 against 10.74 / 17 at N = 40 (tests/ipm_model.py: TERM_FACTOR = "gram" reproduces the kernels' counts).  Remedy (Cholesky-QR2 with a
+// first-order second pass): every lane forms its row q of Q1 = M' R1^-1 (28 multiply-adds on its own column of M), the Gram matrix of Q1 -- I + E, |E| <= 2e-2 --
+// comes from the same 16 matrix-core instructions as the first, and I + E = (I + U)'(I + U) + O(E^2) with U = triu(E, 1) + diag(E) / 2 corrects both factors:
+// q <- q (I - U) per lane, R^-1 <- R1^-1 (I - U) (column j in lane j).  What matters is that q is kept EXPLICITLY (the lanes' mcol registers) where it multiplies z;
+// R^-1 alone, however accurate, brings nothing (modelled: "cholqr2" with Q = M' R^-1: 8.63 / 13).  Model with this scheme: 8.34 / 12, 10.76 / 17.
+#define LMPC_QX_GAP 1e-4
+// mcol: this lane's columns of M on entry, of Q on exit.  Ri: R1^-1 on entry (7 x 7 row-major, zeros below the diagonal), R^-1 on exit.  Qt: 8 x 64 CH doubles of
+// LDS in gram8_mfma's operand layout (may be the tile M was multiplied from), Wl: 64 doubles.  One wave; WG: work-group barrier (one-wave kernel) or waitcnt only;
+// CORR = false: no LDS tile to spare for the second Gram matrix -- the routine is a no-op and the solves keep the form of rounds 1-4.
+template <bool WG> __device__ __forceinline__ void term_sync() {
+    if constexpr (WG) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+template <int CH, bool WG, bool CORR = true> __device__ __forceinline__ void term_reorth(double (&mcol)[CH][7], double *Ri, double *Qt, double *Wl, int lane, bool late) {
+    // The second pass costs ~2.7 k cycles of the critical wave (+7 % per Newton iteration) and only the last iterations need it -- the loss of orthogonality grows with
+    // the spread of the barrier weights.  `late` (wave-uniform; the callers pass gap < LMPC_QX_GAP) switches it on; before that the routine does nothing and the
+    // Newton solves run in the form of rounds 1-4 (mcol = columns of M, v = -c~ + M' (R^-1 z7): term_omega).  Always on, it took the bench batch from 8.62 / 13 to
+    // 8.30 / 12 iterations and cost the same time again (profiles/r5n_ab.txt); late only, the model counts the same 8.28 / 12.
+    if (!CORR || !late) return;
+    // (the 7 x 7 factors are read from LDS column by column where they are used -- uniform addresses, broadcast reads -- and fenced, so that at most seven of
+    //  their entries are live at a time: held in registers whole, 2 x 28 doubles, the one-wave kernel spilled 47 vector registers to scratch)
+#pragma unroll
+    for (int j = 6; j >= 0; j--) {                                                 // q[j] = sum_{i <= j} R1^-1[i][j] m[i]  (descending j: in place)
+        double rc[7];
+#pragma unroll
+        for (int i = 0; i <= j; i++) rc[i] = Ri[i * 7 + j];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) {
+            double v = rc[j] * mcol[ch][j];
+#pragma unroll
+            for (int i = 0; i < j; i++) v = fma(rc[i], mcol[ch][i], v);
+            mcol[ch][j] = v;
+        }
+    }
+
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) Qt[(lane + WAVE * ch) * 8 + j] = mcol[ch][j];
+        Qt[(lane + WAVE * ch) * 8 + 7] = 0.0;
+    }
+    term_sync<WG>();
+    gram8_mfma<CH>(Qt, Wl, lane);                                                  // Q1' Q1 = I + E
+    term_sync<WG>();
+    {
+        const int lj = lane < 7 ? lane : 0;
+        double xk[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) xk[k] = Wl[k * 8 + lj];                        // column `lane` of I + E (lanes < 7)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 7; k++) xk[k] = k < lj ? -xk[k] : (k == lj ? 1.5 - 0.5 * xk[k] : 0.0);  // column `lane` of I - U,  U = triu(E, 1) + diag(E) / 2
+        double rt[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) {                                              // column `lane` of R1^-1 (I - U): row i of R1^-1 against it
+            double rr[7];
+#pragma unroll
+            for (int k = i; k < 7; k++) rr[k] = Ri[i * 7 + k];
+            asm volatile("" ::: "memory");
+            double v = 0.0;
+#pragma unroll
+            for (int k = i; k < 7; k++) v = fma(rr[k], xk[k], v);
+            rt[i] = v;
+        }
+        if (lane < 7) {                                                            // (every read of R1^-1 above was issued before these stores: one wave, LDS in order)
+#pragma unroll
+            for (int i = 0; i < 7; i++) Ri[i * 7 + lane] = rt[i];
+        }
+    }
+    // q <- q (I - U), column j of U at a time; q1 comes back from its tile (not carried in registers across the Gram matrix: the 256-register kernels spilled)
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++)
+#pragma unroll
+        for (int j = 0; j < 7; j++) mcol[ch][j] = Qt[(lane + WAVE * ch) * 8 + j];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 6; j >= 0; j--) {
+        double uc[7];
+#pragma unroll
+        for (int i = 0; i <= j; i++) uc[i] = Wl[i * 8 + j];
+        asm volatile("" ::: "memory");
+        const double ud = 0.5 * (uc[j] - 1.0);
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) {
+            double v = fma(-mcol[ch][j], ud, mcol[ch][j]);
+#pragma unroll
+            for (int i = 0; i < j; i++) v = fma(-mcol[ch][i], uc[i], v);
+            mcol[ch][j] = v;
+        }
+    }
+}
+
 template <int N, int S> struct solve_lds {
     static constexpr int M = 8 * N + S;
     static constexpr int CH = (S + 6 + WAVE - 1) / WAVE, CW = CH * WAVE;       // terminal-block columns per lane of the wave that owns them
@@ -1173,20 +1271,38 @@ template <int N> __device__ __forceinline__ void rollout_start(const double *AB,
     }
 }
 
-// Terminal part of a Newton solve without LDS round trips: omega' = Ri (Ri' d7 + y7), d7 = (dx_N ; -re_sum).  The forward sweep ends (for
+// Terminal part of a Newton solve without LDS round trips: omega' = Ri (Ri' d7 + y7), d7 = (dx_N ; -re_sum) -- or, late in the iteration, z7 = Ri' d7 + y7 itself.  The forward sweep ends (for
 // even N: its last stage sums over the groups) with every lane (lg, lc) holding xi_N[lc], which is d7[lc] for lc < 6: the product with
 // Ri' is formed from that register, z7 reaches lane (lg, lc) as element lc through the LDS crossbar (ds_bpermute from the first lane of
 // group lc), and the seven results leave as wave-uniform values (v_readlane).  Same products and the same summation order as the
 // ri_t_times / ri_times pair on LDS copies, hence bit-identical; ~0.7 k cycles less per solve on the critical wave.
-__device__ __forceinline__ void term_omega(const double *Ri, double yv /* y7[lg] */, double xiN, double re_sum, int lg, int lc, double (&w)[7]) {
+__device__ __forceinline__ void term_omega(const double *Ri, double yv /* y7[lg] */, double xiN, double re_sum, int lg, int lc, double (&w)[7], bool late) {
     const double b_ = lc < 6 ? xiN : (lc == 6 ? -re_sum : 0.0);
     const bool on1 = lg < 7 && lc <= lg;
     const double r1 = Ri[(on1 ? lc : 0) * 7 + (on1 ? lg : 0)];
     const double zv = sum_over_c(on1 ? r1 * b_ : 0.0) + yv;                       // z7[lg], in every lane of group lg
-    const double zt = lane_gather(zv, 32 * lc);                                   // z7[lc]
+    double ov = zv;
+    if (!late) {                                                                  // (wave-uniform) omega' = Ri z7, for v = -c~ + M' omega'
+        const double zt = lane_gather(zv, 32 * lc);                               // z7[lc]
+        const bool on2 = lg < 7 && lc >= lg && lc < 7;
+        const double r2 = Ri[(on2 ? lg : 0) * 7 + (on2 ? lc : 0)];
+        ov = sum_over_c(on2 ? r2 * zt : 0.0);
+    }
+    // late: z7 itself leaves -- the lanes hold their rows of Q = M' R^-1 explicitly by then (term_reorth) and form v = -c~ + Q z7
+#pragma unroll
+    for (int j = 0; j < 7; j++) w[j] = rdlane(ov, 8 * j);
+}
+
+// (the condensed kernel, lmpc_solve_cd.hip.h, keeps the rounds 1-4 form: omega' = Ri z7 for v = -c~ + M' omega')
+__device__ __forceinline__ void term_omega_w(const double *Ri, double yv, double xiN, double re_sum, int lg, int lc, double (&w)[7]) {
+    const double b_ = lc < 6 ? xiN : (lc == 6 ? -re_sum : 0.0);
+    const bool on1 = lg < 7 && lc <= lg;
+    const double r1 = Ri[(on1 ? lc : 0) * 7 + (on1 ? lg : 0)];
+    const double zv = sum_over_c(on1 ? r1 * b_ : 0.0) + yv;
+    const double zt = lane_gather(zv, 32 * lc);
     const bool on2 = lg < 7 && lc >= lg && lc < 7;
     const double r2 = Ri[(on2 ? lg : 0) * 7 + (on2 ? lc : 0)];
-    const double wv = sum_over_c(on2 ? r2 * zt : 0.0);                            // omega'[lg], in every lane of group lg
+    const double wv = sum_over_c(on2 ? r2 * zt : 0.0);
 #pragma unroll
     for (int j = 0; j < 7; j++) w[j] = rdlane(wv, 8 * j);
 }
@@ -1454,8 +1570,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
         if (r < M) { const double tt = rowb(r) - rowF(r, x, u, s, lam); t_r[j] = tt; m[r] = mu0 / tt; }
     }
     double ph[N];                                          // Phi_k entry this lane multiplies with in the register sweeps
-    double mcol[CH][7];                                    // this lane's columns of M = [E D^-1/2 | T7^-1/2] (column lane + 64 ch); row 6 of a
-                                                           // lambda column is its scaling D^-1/2 itself
+    double mcol[CH][7];                                    // this lane's columns of M = [E D^-1/2 | T7^-1/2] (column lane + 64 ch) while the terminal block is factorised,
+                                                           // then this lane's rows of Q = M' R^-1 (term_reorth)
+    double rsl[CH];                                        // D^-1/2 of this lane's lambda columns (0 for the slack columns)
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
 #pragma unroll
@@ -1465,6 +1582,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
     for (int k = 0; k < N; k++) ph[k] = 0.0;
     __syncthreads();
 
+    bool qx_late = false;                                  // the terminal factor of this iteration carries the explicit, re-orthogonalised Q (term_reorth)
     // one Newton-system solve for the right-hand side currently in (rx,ru,rs,rl,h); result in dx,du,ds,dl
     auto kkt_solve = [&](double re_sum) {
         FOR_LANES_T(i, t, 2 * N) {                              // slack elimination, per lane row (k,j)
@@ -1484,8 +1602,8 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             for (int ch = 0; ch < CH; ch++) {
                 const int col = lane + WAVE * ch;
                 c_t[ch] = 0.0;
-                if (col < S) c_t[ch] = (rl_r[ch] + h[8 * N + col]) * mcol[ch][6];
-                ct[col] = col < S ? c_t[ch] * mcol[ch][6] : 0.0;  // D^-1/2 c~ (the slack columns of M meet zeros of c~)
+                if (col < S) c_t[ch] = (rl_r[ch] + h[8 * N + col]) * rsl[ch];
+                ct[col] = col < S ? c_t[ch] * rsl[ch] : 0.0;      // D^-1/2 c~ (the slack columns of M meet zeros of c~)
             }
         }
         __syncthreads();
@@ -1601,7 +1719,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
         }
         if constexpr (term) {
             double wq[7];
-            if constexpr ((N - 1) & 1) term_omega(Ri, y7v, xiN, re_sum, lg, lc, wq);         // (even N: every lane ends the sweep with xi_N[lc])
+            if constexpr ((N - 1) & 1) term_omega(Ri, y7v, xiN, re_sum, lg, lc, wq, qx_late);         // (even N: every lane ends the sweep with xi_N[lc])
             else {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
                 if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;               // d7 (w7 is free until omega' is written)
                 __syncthreads();
@@ -1609,19 +1727,22 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
                 __syncthreads();
                 if (lc == 0 && lg < 7) z7[lg] = zv;
                 __syncthreads();
-                const double wv = ri_times(Ri, z7, lg, lc);
-                if (lc == 0 && lg < 7) w7[lg] = wv;
-                __syncthreads();
+                if (!qx_late) {
+                    const double wv = ri_times(Ri, z7, lg, lc);
+                    __syncthreads();
+                    if (lc == 0 && lg < 7) z7[lg] = wv;
+                    __syncthreads();
+                }
 #pragma unroll
-                for (int j = 0; j < 7; j++) wq[j] = w7[j];
+                for (int j = 0; j < 7; j++) wq[j] = z7[j];
             }
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
                 const int col = lane + WAVE * ch;
-                double v = -c_t[ch];                            // v = -c~ + M' omega'
+                double v = -c_t[ch];                            // v = -c~ + M' omega'  (late: -c~ + Q z7, Q explicit: term_reorth)
 #pragma unroll
                 for (int j = 0; j < 7; j++) v = fma(mcol[ch][j], wq[j], v);
-                if (col < S) dl[col] = v * mcol[ch][6];
+                if (col < S) dl[col] = v * rsl[ch];
             }
         }
         __syncthreads();
@@ -1726,7 +1847,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
         // The dynamics rows are linear and every step keeps them (the roll-out start satisfies them, the Newton direction lies in their null
         // space): their residual only collects rounding, ~1e-13.  It is still checked -- wherever a decision depends on it (convergence,
         // the INEXACT classification) -- but no longer in the iterations whose other two residuals have not passed yet.
-        if (gap < p.tol_gap && rdn < p.tol_res * qscale && accuracy_ok(gap, gap_prev, p.tol_gap)) {
+        if (gap < p.tol_gap && rdn < p.tol_res * qscale && accuracy_ok<N>(gap, gap_prev, p.tol_gap)) {
             ren = LMPC_UX(fmax(dyn_residual(), fabs(re_sum)));
             if (ren < p.tol_res) { converged = 1; break; }
         }
@@ -1760,7 +1881,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
                 const double rs_ = frsqrt(th[8 * N + cl] + p.reg), tsq = frsqrt(T2p[cs]);       // lambda column: D^-1/2;  slack column: T^-1/2
 #pragma unroll
                 for (int j = 0; j < 6; j++) mcol[ch][j] = islam ? SS[j * S + cl] * rs_ : ((isslk && cs == j) ? tsq : 0.0);
-                mcol[ch][6] = islam ? rs_ : 0.0;
+                mcol[ch][6] = islam ? rs_ : 0.0; rsl[ch] = mcol[ch][6];
             }
             double Rr[7][7], rinv[7];
             // Gram matrix W = M M' (7 x 7, K = 64 CH columns) on the matrix cores (gram8_mfma)
@@ -1809,6 +1930,9 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
                     for (int i = 0; i < 7; i++) Ri[i * 7 + lane] = col[i];
                 }
             }
+            __syncthreads();
+            qx_late = gap < LMPC_QX_GAP;
+            term_reorth<CH, true>(mcol, Ri, Mt, Wl, lane, qx_late);       // (late iterations) rows of Q explicit and re-orthogonalised; Ri <- R^-1 of the corrected factor (M's tile is free: Q1 goes there)
             __syncthreads();
             if (lane < 36) {                                     // Pi_term = (Ri Ri')[0:6,0:6]
                 const int i = lane / 6, j = lane % 6; double v = 0.0;

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(WAVE, 2) void lmpc_solve_kernel_cd(lmpc_dev_params 
         TSTAMP(34);
         if constexpr (term) {
             double wq[7];
-            term_omega(Ri, y7v, xiN, re_sum, lg, lc, wq);
+            term_omega_w(Ri, y7v, xiN, re_sum, lg, lc, wq);
             double v = -c_t;
 #pragma unroll
             for (int j = 0; j < 7; j++) v = fma(mcol[j], wq[j], v);
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(WAVE, 2) void lmpc_solve_kernel_cd(lmpc_dev_params 
         rdn = wmax(rmax);
         const double re_sum = term ? wave_uniform(wsum(lsum) - 1.0) : 0.0;
         ren = fabs(re_sum);
-        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res) { converged = 1; break; }
+        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res && accuracy_ok<N>(gap, gap_prev, p.tol_gap)) { converged = 1; break; }
         if (gap_prev >= 0.0) sep = !EQ && gap > LMPC_SEP_THRESHOLD * gap_prev;
         gap_prev = gap;
         if (it == p.max_iter) break;

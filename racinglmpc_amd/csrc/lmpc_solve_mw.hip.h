@@ -185,6 +185,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     const ricc_consts rc = ricc_setup(lane, Q2, Fx, R2, dR2, Fu);
     double ph[N];
     constexpr int CH = LL::CH;                               // terminal-block columns per lane of wave 0 (column = lane + 64 ch; 1 up to 58 safe-set points)
+    constexpr bool QX = 8 * LL::CW <= 64 * N;                // second pass of the terminal factor's orthogonalisation: needs the Phi tiles' LDS as its Gram tile
     double mcol[CH][7], tsq_lane[CH];                        // columns of M = [E D^-1/2 | T7^-1/2]; T^-1/2 entry of a slack column (loop invariant)
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             Mt[col * 8 + 7] = 0.0;
         }
     };
+    bool qx_late = false;                                    // second orthogonalisation pass of the terminal factor on (term_reorth): set per iteration, wave-uniform
     auto term_partB = [&](int &numeric_bad) {
         double Rr[7][7], rinv[7];
         WSYNC();
@@ -284,6 +286,10 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                 for (int i = 0; i < 7; i++) Ri[i * 7 + lane] = col[i];
             }
         }
+        WSYNC();
+        // late iterations: rows of Q = M' R^-1 explicit in mcol, re-orthogonalised -- where an LDS tile for the second Gram matrix is free (term_reorth, lmpc_kernels.hip.h): the Phi_k
+        // tiles are dead between the step phase and the stage recursion -- 64 N doubles against the 8 x 64 CH the tile needs
+        term_reorth<CH, false, QX>(mcol, Ri, Phi, Wl, lane, qx_late);
         WSYNC();
         if (lane < 36) {                                 // Pi_term = (Ri Ri')[0:6,0:6]  (Ri is zero below the diagonal: all seven terms, same sum)
             const int i = lane / 6, j = lane % 6; double v = 0.0;
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         if constexpr (term) {
             if (w0) {
                 double wq[7];
-                if constexpr ((N - 1) & 1) term_omega(Ri, y7v, xiN, re_sum, lg, lc, wq);     // (even N: every lane ends the sweep with xi_N[lc])
+                if constexpr ((N - 1) & 1) term_omega(Ri, y7v, xiN, re_sum, lg, lc, wq, qx_late);     // (even N: every lane ends the sweep with xi_N[lc])
                 else {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
                     if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;           // d7 (w7 is free until omega' is written)
                     WSYNC();
@@ -443,16 +449,19 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                     WSYNC();
                     if (lc == 0 && lg < 7) z7[lg] = zv;
                     WSYNC();
-                    const double wv = ri_times(Ri, z7, lg, lc);
-                    if (lc == 0 && lg < 7) w7[lg] = wv;
-                    WSYNC();
+                    if (!qx_late) {                                  // omega' = Ri z7 (late iterations: z7 itself, the lanes' mcol holds Q = M' R^-1 then, see term_omega)
+                        const double wv = ri_times(Ri, z7, lg, lc);
+                        WSYNC();
+                        if (lc == 0 && lg < 7) z7[lg] = wv;
+                        WSYNC();
+                    }
 #pragma unroll
-                    for (int j = 0; j < 7; j++) wq[j] = w7[j];
+                    for (int j = 0; j < 7; j++) wq[j] = z7[j];
                 }
 #pragma unroll
                 for (int ch = 0; ch < CH; ch++) {
                     const int col = lane + WAVE * ch;
-                    double v = -c_t[ch];                        // v = -c~ + M' omega'
+                    double v = -c_t[ch];                        // v = -c~ + Q z7
                     const double rq = rsq[col];
                     LDS_GROUP();
 #pragma unroll
@@ -477,6 +486,8 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         if (w0) {
             if constexpr (term) {
                 if (!TEARLY || it == 0) term_partA();
+                // (this iterate's gap is being summed by the helper waves right now: the decision uses the previous iterate's, one decade earlier)
+                qx_late = QX && it > 0 && gap < 10.0 * LMPC_QX_GAP;
                 term_partB(numeric_bad);
             }
             WSYNC();
@@ -550,7 +561,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         const double re_sum = term ? lsum_all - 1.0 : 0.0;
         ren = fmax(ren, fabs(re_sum));
         TRACE3(tid == 0, 0, gap, rdn, ren);
-        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res && accuracy_ok(gap, gap_prev, p.tol_gap)) { converged = 1; break; }
+        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res && accuracy_ok<N>(gap, gap_prev, p.tol_gap)) { converged = 1; break; }
         if (gap_prev >= 0.0) sep = gap > LMPC_SEP_THRESHOLD * gap_prev;
         gap_prev = gap;
         if (it == p.max_iter) break;
@@ -684,7 +695,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         if constexpr (term) {
             if (w0) {
                 double wq[7];
-                if constexpr ((N - 1) & 1) term_omega(Ri, y7[lg < 7 ? lg : 0], xiN, re_sum, lg, lc, wq);   // (y7: wave 1's, from step 0 of the pipeline)
+                if constexpr ((N - 1) & 1) term_omega(Ri, y7[lg < 7 ? lg : 0], xiN, re_sum, lg, lc, wq, qx_late);   // (y7: wave 1's, from step 0 of the pipeline)
                 else {   // z7 = Ri' d7 + y7, d7 = (dx_N ; -re_sum);  omega' = Ri z7
                     if (lane < 7) w7[lane] = lane < 6 ? dx[N * 6 + lane] : -re_sum;           // d7 (w7 is free until omega' is written)
                     WSYNC();
@@ -692,16 +703,19 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
                     WSYNC();
                     if (lc == 0 && lg < 7) z7[lg] = zv;
                     WSYNC();
-                    const double wv = ri_times(Ri, z7, lg, lc);
-                    if (lc == 0 && lg < 7) w7[lg] = wv;
-                    WSYNC();
+                    if (!qx_late) {                                  // omega' = Ri z7 (late iterations: z7 itself, the lanes' mcol holds Q = M' R^-1 then, see term_omega)
+                        const double wv = ri_times(Ri, z7, lg, lc);
+                        WSYNC();
+                        if (lc == 0 && lg < 7) z7[lg] = wv;
+                        WSYNC();
+                    }
 #pragma unroll
-                    for (int j = 0; j < 7; j++) wq[j] = w7[j];
+                    for (int j = 0; j < 7; j++) wq[j] = z7[j];
                 }
 #pragma unroll
                 for (int ch = 0; ch < CH; ch++) {
                     const int col = lane + WAVE * ch;
-                    double v = -ct[col];                        // v = -c~ + M' omega'
+                    double v = -ct[col];                        // v = -c~ + Q z7
                     const double rq = rsq[col];
                     LDS_GROUP();
 #pragma unroll

@@ -52,6 +52,11 @@ def tri_inv_upper(R):
     return X
 
 
+TERM_LATE_GAP = 1e-4
+TERM_LATE = False          # set by ipm_solve per iteration: the iterate is in its final phase (gap below 1e-4)
+TERM_FACTOR = "cholqr2_fo_late"        # (round 5: what the kernels do)   how kkt_factor factorises the terminal block: "mgs" (two passes of modified Gram-Schmidt on M'), "gram" (Cholesky of M M', the kernels' way), "gram_scaled"
+
+
 class Factor:
     pass
 
@@ -69,7 +74,29 @@ def kkt_factor(qp, th_lane, th_u, th_s, th_l, reg_l=0.0):
         f.D = th_l + reg_l
         E = np.vstack([qp.SS, np.ones(qp.S)])
         Mt = np.vstack([(E / np.sqrt(f.D)).T, np.diag(np.concatenate([1 / np.sqrt(T), [0]]))[:6]])
-        f.Qm, R = mgs_QR(Mt)
+        if TERM_FACTOR == "mgs":
+            f.Qm, R = mgs_QR(Mt)
+        else:
+            # what the kernels do: Gram matrix W = M M' (on the matrix cores), Cholesky R'R = W; "gram_scaled": rows of M equilibrated first (unit diagonal of W)
+            Mm = Mt.T                                             # 7 x (S + 6)
+            dsc = 1.0 / np.sqrt(np.sum(Mm * Mm, axis=1)) if TERM_FACTOR == "gram_scaled" else np.ones(7)
+            W = (Mm * dsc[:, None]) @ (Mm * dsc[:, None]).T
+            R = np.linalg.cholesky(W).T / dsc[None, :]            # R'R = M M'
+            if TERM_FACTOR.startswith("cholqr2") and (not TERM_FACTOR.endswith("_late") or TERM_LATE):
+                # second pass (Cholesky-QR2): M1 = R^-T M has a Gram matrix close to the identity; its Cholesky factor corrects R
+                M1 = tri_inv_upper(R).T @ Mm
+                W2 = M1 @ M1.T
+                if "fo" in TERM_FACTOR:                           # first-order factor of a Gram matrix next to the identity: I + E = (I + U)'(I + U) + O(E^2), U = triu(E, 1) + diag(E) / 2
+                    E_ = W2 - np.eye(7); Rb = np.eye(7) + np.triu(E_, 1) + np.diag(np.diag(E_)) / 2
+                    globals()["FO_EMAX"] = max(globals().get("FO_EMAX", 0.0), float(np.abs(E_).max()))
+                else:
+                    Rb = np.linalg.cholesky(W2).T
+                R = Rb @ R
+                f.Qm = M1.T @ tri_inv_upper(Rb)                   # Q kept explicitly, column by column of M: Q = (M' R1^-1) R2^-1, never M' (R2 R1)^-1
+                if "yimpl" in TERM_FACTOR:                        # (experiment: y7 = R^-T (M c~), the explicit Q only where it multiplies z7)
+                    f.Qm_y = Mt @ tri_inv_upper(R)
+            else:
+                f.Qm = Mt @ tri_inv_upper(R)
         f.Ri = tri_inv_upper(R); f.W7i = f.Ri @ f.Ri.T; f.E = E; f.T = T; f.sqD = np.sqrt(f.D)
         Pi[:6, :6] += f.W7i[:6, :6]
     f.Kx = np.zeros((N, 2, 6)); f.Ku = np.zeros((N, 2, 2)); f.Mi = np.zeros((N, 2, 2)); f.Hx = np.zeros((N, 6, 6))
@@ -104,7 +131,7 @@ def kkt_solve(qp, f, th_lane, th_s, gx, gu, gs, h_lane, h_u, h_s, gl, re_dyn, re
     pv = np.zeros(8); pv[:6] = gx[N]
     if qp.term:
         ct = np.concatenate([gl / f.sqD, np.zeros(6)])
-        y7 = f.Qm.T @ ct
+        y7 = (f.Qm_y if hasattr(f, "Qm_y") else f.Qm).T @ ct
         d0 = np.concatenate([np.zeros(6), [-re_sum]])
         pv[:6] += (f.Ri @ (f.Ri.T @ d0 + y7))[:6]
     k0 = np.zeros((N, 2))
@@ -264,7 +291,7 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         # below `ratio`) ends the iteration as before.
         acc_ok = True
         if acc_rule == "kernel":
-            acc_rule = dict(ratio=1e-2, step=0.0, floor=0.1 * tol_gap)   # LMPC_ACC_RATIO / LMPC_ACC_FLOOR of the kernels (lmpc_kernels.hip.h: accuracy_ok); no step term there
+            acc_rule = dict(ratio=1e-3, step=0.0, floor=(0.03 if N > 24 else 0.1) * tol_gap)   # LMPC_ACC_RATIO / LMPC_ACC_FLOOR<N> of the kernels (lmpc_kernels.hip.h: accuracy_ok); no step term there
         if acc_rule is not None and gp_before is not None:
             acc_ok = gap <= acc_rule["ratio"] * gp_before or info.get("step_prev", 0.0) <= acc_rule["step"] or gap < acc_rule["floor"]
         if acc_ok and gap < tol_gap and rd < tol_res * qscale and re < tol_res and (degen_tol is None or max(
@@ -321,6 +348,7 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         cap = (lambda t, m: np.maximum(t, m / th_max)) if th_max is not None else (lambda t, m: t)
         rts = [1.0 / cap(t, m) if t.size else t for t, m in zip(ts, ms)]
         th_lane, th_u, th_s, th_l = ths = [m * rt for m, rt in zip(ms, rts)]
+        globals()["TERM_LATE"] = gap < TERM_LATE_GAP
         f = kkt_factor(qp, th_lane, th_u, th_s, th_l, reg_l); nfact += 1
         # terminal slack eliminated: its Hessian T enters W7 through T^-1 (kept in factor)
         def solve(h_lane, h_u, h_s, h_l):
