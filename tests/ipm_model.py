@@ -159,7 +159,7 @@ def kkt_solve(qp, f, th_lane, th_s, gx, gu, gs, h_lane, h_u, h_s, gl, re_dyn, re
     return dx, du, ds, dl
 
 
-def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True, polish=None, pex=None, so_w=1.0, start=None, trace=None, degen_tol=None, acc_rule="kernel"):
+def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True, polish=None, pex=None, so_w=1.0, start=None, trace=None, degen_tol=None, acc_rule="kernel"):
     """Returns dict(x,u,s,lam,sT, mu (ineq duals in reference row order), iters, gap, rd, re).
     exact_nu (round 3): the multipliers of the dynamics rows are not iterates of their own; every iteration takes them from the adjoint recursion
     nu_{k-1} = A_k' nu_k - w_k (w_k: gradient of the state rows' other terms), so the x rows of the dual residual vanish identically and the
@@ -397,6 +397,16 @@ def ipm_solve(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=Fal
         dx, du, ds, dl = solve(*hs)
         dt = ineq_steps(dx, du, ds, dl)
         dm = [-h_ - th * d for h_, th, d in zip(hs, ths, dt)]
+        if ncorr is not None and gap < ncorr.get("gap", 1e-4):
+            # (round 5 experiment, negative -- profiles/r5_ncorr_model.txt) iterated corrector: the second-order term of the right-hand side taken from the combined
+            # direction just computed instead of the affine one, same factorisation, one more pair of sweeps per repetition
+            for _ in range(ncorr.get("n", 1)):
+                rc = [t * m - tgt + d * dm_ for t, m, d, dm_ in zip(ts, ms, dt, dm)]
+                hs = [r * rt for r, rt in zip(rc, rts)]
+                dx, du, ds, dl = solve(*hs)
+                dt = ineq_steps(dx, du, ds, dl)
+                dm = [-h_ - th * d for h_, th, d in zip(hs, ths, dt)]
+                info["ncorr"] = info.get("ncorr", 0) + 1
         frac = max(0.995, 1.0 - 10.0 * gap) if sig < 1e-3 else 0.995      # longer steps in the final phase only (step_fraction in the kernel)
         al = min(1.0, frac * maxstep(ts, dt)); ald = min(1.0, frac * maxstep(ms, dm))
         if not sep:
