@@ -435,7 +435,8 @@ def main():
                              "valu_utilisation": counters.get("valu_utilisation"), "lds_bank_conflict_rate": counters.get("lds_bank_conflict_rate"),
                              "mfma_busy_cycles_per_launch": counters.get("SQ_VALU_MFMA_BUSY_CYCLES")},
                          "note": "dependent-issue-latency bound path (one Newton recursion per QP); compulsory HBM traffic is 2.46 KB per solve (SURVEY 8(d)); "
-                                 "measured traffic also counts the L2-resident lap-store scans and the mu/ssSel outputs; see DESIGN.md"},
+                                 "the dominant extra in the measured traffic is the A, B, C hand-over from the regression kernel (5.2 KB per solve at N = 12, written "
+                                 "by one kernel and read by the other), then the 288 KB lap store missing once per XCD L2 and the ssSel output; see DESIGN.md"},
         }
     for p in keep:
         ctx.dev_free(p)

@@ -906,7 +906,7 @@ int lmpc_debug_timing(lmpc_ctx *c, const double *A, const double *Bm, const doub
     lmpc_solve_io io; memset(&io, 0, sizeof(io));
     io.mode = 2; io.A = c->w_A; io.Bm = c->w_B; io.C = c->w_C; io.x0 = c->w_x0; io.uOld = c->w_uOld; io.ssSelIn = c->w_ssSel; io.qSelIn = c->w_qSel;
     io.xPred = c->w_xPred; io.uPred = c->w_uPred; io.slack = c->w_slack; io.lambda = c->w_lam; io.sTerm = c->w_sT; io.mu = c->w_mu; io.resid = c->w_resid;
-    io.status = c->w_status; io.iters = c->w_iters; io.tbuf = dt;
+    io.status = c->w_status; io.iters = c->w_iters; io.tbuf = dt; io.abPack = c->ab_pack;      // (long horizons: the route a large batch takes, [A_k | B_k] in global memory; LMPC_NO_ABG=1 for the other)
     int rc = launch_solve(c, 1, io); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(tbuf_host, dt, sizeof(long long) * nt, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream)); hipFree(dt);

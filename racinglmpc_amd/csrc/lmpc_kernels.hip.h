@@ -244,6 +244,9 @@ __device__ __forceinline__ double frcp(double x) {
 #define LMPC_ACC_RATIO 1e-3
 template <int N> constexpr double LMPC_ACC_FLOOR = N > 24 ? 0.03 : 0.1;
 template <int N> __device__ __forceinline__ bool accuracy_ok(double gap, double gap_prev, double tol_gap) {
+#ifdef LMPC_AB_NOACC                    // (developer A / B: the gap test alone, rounds 1-4)
+    return true;
+#endif
     return gap_prev < 0.0 || gap <= LMPC_ACC_RATIO * gap_prev || gap < LMPC_ACC_FLOOR<N> * tol_gap;
 }
 // Barrier weights theta = mu / t are capped at 1e11 in the Newton matrix: 1 / theta >= 1e-11 is a dual regularisation of the inequality row
@@ -1666,8 +1669,17 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
         FOR_LANES(i, 2 * N) {                                   // k0_k = Mi_k (gu' + B' p_x + p_u)
             const int k = i >> 1, c = i & 1;
             double w0 = gup[2 * k] + pst[(k + 1) * 8 + 6], w1 = gup[2 * k + 1] + pst[(k + 1) * 8 + 7];
+            if constexpr (ABG) {            // (global loads: all six pairs in flight before the first multiply-add -- see the adjoint recursion)
+                double b6[6], b7[6];
 #pragma unroll
-            for (int j = 0; j < 6; j++) { w0 = fma(AB[k * 48 + j * 8 + 6], pst[(k + 1) * 8 + j], w0); w1 = fma(AB[k * 48 + j * 8 + 7], pst[(k + 1) * 8 + j], w1); }
+                for (int j = 0; j < 6; j++) { b6[j] = AB[k * 48 + j * 8 + 6]; b7[j] = AB[k * 48 + j * 8 + 7]; }
+                asm volatile("" : "+v"(b6[0]), "+v"(b6[1]), "+v"(b6[2]), "+v"(b6[3]), "+v"(b6[4]), "+v"(b6[5]), "+v"(b7[0]), "+v"(b7[1]), "+v"(b7[2]), "+v"(b7[3]), "+v"(b7[4]), "+v"(b7[5]));
+#pragma unroll
+                for (int j = 0; j < 6; j++) { w0 = fma(b6[j], pst[(k + 1) * 8 + j], w0); w1 = fma(b7[j], pst[(k + 1) * 8 + j], w1); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; j++) { w0 = fma(AB[k * 48 + j * 8 + 6], pst[(k + 1) * 8 + j], w0); w1 = fma(AB[k * 48 + j * 8 + 7], pst[(k + 1) * 8 + j], w1); }
+            }
             k0[i] = Mi[k * 4 + c * 2] * w0 + Mi[k * 4 + c * 2 + 1] * w1;
         }
         __syncthreads();
@@ -1795,8 +1807,33 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             const int c = lane < 6 ? lane : 0;
             double nc = -rx[N * 6 + c];                                          // nu_{N-1}[c]
             if (lane < 6) nu[(N - 1) * 6 + lane] = nc;
-            if constexpr (ABG || N > 20) {
-                // long horizons: a rolled loop (unrolled, the 6 N loads -- global ones with ABG -- were hoisted together: 281 spilled VGPRs at N = 40)
+            if constexpr (ABG) {
+                // [A_k | B_k] in global memory: the six loads of a stage are issued TOGETHER, one stage ahead of the multiply-adds that use them (two register sets,
+                // two stages per trip).  Left to the compiler the loop came out in one of two forms depending on unrelated code -- six loads into one register
+                // pair, each waited for (234 exposed cache round trips per iteration: 1.27 ms per launch at batch 1024), or the six in flight together (1.04 ms).
+                auto ld6 = [&](int k, double (&d)[6]) {
+                    const double *Ak = AB + k * 48 + c;
+#pragma unroll
+                    for (int r = 0; r < 6; r++) d[r] = Ak[r * 8];
+                };
+                auto st1 = [&](int k, const double (&a)[6]) {
+                    double v = -rx[k * 6 + c];
+#pragma unroll
+                    for (int r = 0; r < 6; r++) v = fma(a[r], rdlane(nc, r), v);
+                    nc = v;
+                    if (lane < 6) nu[(k - 1) * 6 + lane] = v;
+                };
+                double a0[6], a1[6];
+                ld6(N - 1, a0);
+                int k = N - 1;
+#pragma unroll 1
+                for (; k >= 2; k -= 2) {
+                    ld6(k - 1, a1); st1(k, a0);
+                    ld6(k > 2 ? k - 2 : 1, a0); st1(k - 1, a1);
+                }
+                if (k == 1) st1(1, a0);
+            } else if constexpr (N > 20) {
+                // long horizons: a rolled loop (unrolled, the 6 N loads were hoisted together: 281 spilled VGPRs at N = 40)
 #pragma unroll 1
                 for (int k = N - 1; k >= 1; k--) {
                     double v = -rx[k * 6 + c];

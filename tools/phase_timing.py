@@ -18,8 +18,18 @@ _capi.LIB_PATH = so
 from tests import common
 g = common.load_lmpc_golden()
 r = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-cfg, par = common.lmpc_config(g, 12, max_batch=4)
+PN = int(os.environ.get("PT_N", "12"))          # PT_N=40: problem r of BASELINE configs[4]'s batch (A, B, C and the selection taken from a full step of this library)
+cfg, par = common.lmpc_config(g, PN, max_batch=4)
 ctx = _capi.Context(cfg)
+if PN != 12:
+    from tools.n40_model import inputs
+    for _ in range(4):
+        ctx.model_add_trajectory(g["xPID"], g["uPID"]); ctx.ss_add_trajectory(g["xPID"], g["uPID"])
+    inp = {k: v[r:r + 1] for k, v in inputs(g, PN, 1024).items()}
+    o = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    print("N = %d, problem %d: %d iterations in the full step" % (PN, r, int(o["iters"][0])))
+    g = dict(g); g.update(rec_A={r: o["A"][0]}, rec_B={r: o["B"][0]}, rec_C={r: o["C"][0]}, rec_x0={r: inp["x0"][0]}, rec_OldInput={r: inp["uOld"][0]},
+             rec_SSsel={r: np.ascontiguousarray(o["ssSel"][0]).T}, rec_Qsel={r: o["qSel"][0]})
 NT = 32000          # 4 waves x 4000 (id, cycle) pairs (the multi-wave kernel stamps per wave)
 tb = np.zeros(NT, np.int64)
 f = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data_as(C.c_void_p)
