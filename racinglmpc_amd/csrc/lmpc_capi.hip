@@ -81,6 +81,7 @@ struct lmpc_ctx {
     void *var_dl;                            // dlopen handle when that instantiation lives in its own shared object (lmpc_variant.hip)
     int mw_max_batch, mw2_max_batch, n_cu;   // largest batch served by the four-wave / the two-wave solve kernel
     bool k1_force16;                         // regression kernel: never the 8-rows-per-lane scan (launch_k1)
+    int k1_qg_force;                         // (experiments, LMPC_K1_QG at lmpc_create: queries per work-group of the regression kernel; 0 = the rule of k1_grid)
     int fuse_k1;                             // fused step for one-wave batches (LMPC_FUSE=0 turns it off)
     double *ab_pack;                         // global scratch of the one-wave kernel's long-horizon variant ([A_k | B_k] per problem), max_batch x 48 N doubles
     int cd_ok, cd_hasq, cd_mode;             // condensed one-wave kernel (opt-in: libraries built with -DLMPC_WITH_CD only): usable for this configuration / state cost present / LMPC_CD=1 in the environment selects it, at every batch size
@@ -196,6 +197,7 @@ static int create_body(lmpc_ctx *c) {
     HIPCHK(hipSetDevice(cfg->device));
     // an unsupported (N, numSS_points) pair is an ordinary user error: find that out before anything is allocated
     c->k1_force16 = getenv("LMPC_K1_RPL16") != nullptr;
+    { const char *e = getenv("LMPC_K1_QG"); c->k1_qg_force = e ? atoi(e) : 0; }
     { const int rc = pick_solver(c); if (rc) return rc; }
     {   // batches that leave SIMDs idle (B <= number of CUs) run the 4-waves-per-QP kernel
         const char *e = getenv("LMPC_MW_MAX_BATCH"); hipDeviceProp_t prop; int cus = 256;
@@ -565,7 +567,8 @@ static void k1_grid(lmpc_ctx *c, int B, int *qg, int *nblk) {
     int q = 1, np = N;
     for (int k = 0; k < 6; k++) {
         q = k1_queries_per_block(cands[k], c->cfg.trToUse, c->cfg.maxNumPoint); np = (N + q - 1) / q;
-        if ((long long)B * np >= (long long)c->n_cu) break;      // (two or more groups per CU measured no faster: 26-35 us against 27 us at batch 256)
+        if (c->k1_qg_force > 0) { if (cands[k] <= c->k1_qg_force) break; else continue; }
+        if ((long long)B * np >= (long long)c->n_cu) break;      // (two or more groups per CU measured no faster: round 2 26-35 us against 27 us at batch 256; round 5, LMPC_K1_QG = 6 / 4 / 3 / 2: 20 / 27 / 29 / 39 us against 22)
     }
     *qg = q; *nblk = B * np;
 }
