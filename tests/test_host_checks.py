@@ -75,3 +75,21 @@ def test_bench_watchdog_prints_one_line_and_exits_non_zero():
     code1 = code.replace("bench.Watchdog(0, 2,", "bench.Watchdog(0, 1,").replace("time.sleep(30)", "time.sleep(0.6); print('alive')")
     r1 = subprocess.run([sys.executable, "-c", code1], capture_output=True, timeout=60)
     assert r1.returncode == 0 and r1.stdout.decode().strip() == "alive"
+
+
+def test_noise_prefetch_keeps_the_draw_order():
+    """BatchedRollouts.prefetch_noise / the per-lap prefetch of the plant noise: the generator is consumed in exactly the order it would be without them,
+    a prefetched array of another shape is discarded together with its draws."""
+    from racinglmpc_amd import rollout
+
+    def mk():
+        r = rollout.BatchedRollouts.__new__(rollout.BatchedRollouts)
+        r.rng = np.random.default_rng(5); r._pre = None; r.global_noise = False; r.noise_shard = None
+        return r
+    ref = np.random.default_rng(5)
+    want = [ref.standard_normal((10, 4, 3)), ref.standard_normal((10, 4, 3)), ref.standard_normal((7, 4, 3))]
+    a = mk(); got = [a._draw_noise(10, 4), a._draw_noise(10, 4), a._draw_noise(7, 4)]
+    assert all(np.array_equal(x, y) for x, y in zip(want, got))
+    b = mk(); b.prefetch_noise(10, 4, wait=True); got = [b._draw_noise(10, 4), b._draw_noise(10, 4), b._draw_noise(7, 4)]
+    assert all(np.array_equal(x, y) for x, y in zip(want, got))
+    c = mk(); c.prefetch_noise(9, 4); assert np.array_equal(c._draw_noise(10, 4), want[0])          # wrong shape prefetched: discarded, state restored
