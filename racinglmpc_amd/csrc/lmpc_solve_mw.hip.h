@@ -624,7 +624,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             STEP_BARRIER();                                  // step 0
 #pragma unroll
             for (int k = N - 1; k >= 0; k--) {               // step N - k: stage k was factorised during the previous step
-                if (wave == FB_WAVE) {
+                if (NW > 2 && wave == FB_WAVE) {          // (two waves: wave 1 runs the sweep only -- with both followers it, not the recursion, set the pace of the pipeline; phi in bulk below)
                     // phi_k = [-B k0 ; -k0],  k0_k = M_uu^-1 (gu' + [B; I]' p_{k+1}): lane c of every group of 8 holds row c of [B_k; I] and p_{k+1}[c]
                     // (per-lane loads, no chain of broadcast reads), the two 8-term sums are DPP reductions inside the group
                     const double bq0 = lc < 6 ? AB[k * 48 + lc * 8 + 6] : (lc == 6 ? 1.0 : 0.0), bq1 = lc < 6 ? AB[k * 48 + lc * 8 + 7] : (lc == 7 ? 1.0 : 0.0);
@@ -650,6 +650,23 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             }
         }
         // (the last step's barrier is the hand-over to the forward sweep: LDS writes of a wave that precede its barrier are in place)
+        if constexpr (NW == 2) {
+            // Two waves per QP: the feed-forward terms phi_k of ALL stages now, eight stages per pass (group lg takes stage lg of the pass, lane lc row lc of [B_k; I]),
+            // the passes dealt to the two waves in turn.  As a follower inside the pipeline phi cost wave 1 ~450 cycles per stage on top of its sweep step, and wave 0
+            // waited for it at every stage barrier (1 200 instead of 950 cycles per stage, profiles/r5zz_phase_timing_mw2.txt); in bulk it is one pass per wave.
+#pragma unroll
+            for (int k0_ = 0; k0_ < N; k0_ += 16) {
+                const int k = k0_ + 8 * wave + lg; const bool on = k < N; const int kk = on ? k : 0;
+                const double bq0 = lc < 6 ? AB[kk * 48 + lc * 8 + 6] : (lc == 6 ? 1.0 : 0.0), bq1 = lc < 6 ? AB[kk * 48 + lc * 8 + 7] : (lc == 7 ? 1.0 : 0.0);
+                const double pq = pst[(kk + 1) * 8 + lc], gq = lc >= 6 ? gup[2 * kk + lc - 6] : 0.0;
+                const double m00 = Mi[kk * 4], m01 = Mi[kk * 4 + 1], m10 = Mi[kk * 4 + 2], m11 = Mi[kk * 4 + 3];
+                LDS_GROUP();
+                const double w0_ = sum_over_c<BCF>(fma(bq0, pq, lc == 6 ? gq : 0.0)), w1_ = sum_over_c<BCF>(fma(bq1, pq, lc == 7 ? gq : 0.0));
+                const double k00 = m00 * w0_ + m01 * w1_, k01 = m10 * w0_ + m11 * w1_;
+                if (on) phi[k * 8 + lc] = -(bq0 * k00 + bq1 * k01);
+            }
+            STEP_BARRIER();
+        }
         if (bad_sh) { if (tid == 0) atomicOr(&st_sh, (gap < 1e-9 && rdn < 1e-5 * qscale && ren < 1e-7) ? LMPC_ST_INEXACT : LMPC_ST_NUMERIC); break; }   // see lmpc_solve_kernel
         TSMW(13);
         // ---- predictor (affine scaling) direction, rest: forward sweep on wave 0, then the slack and terminal steps ----------------
