@@ -239,15 +239,17 @@ __device__ __forceinline__ double frcp(double x) {
 //    gap to end: 0.1 tol_gap, and 0.03 tol_gap at horizons beyond 24 (the error constant grows with the number of coupled stages): scalar comparisons on
 //    values the iteration has anyway.  NumPy model (tests/ipm_model.py: acc_rule; tools/ipm_acc_sets.py) -- bench batch 8.28 -> 8.30 / 12 unchanged
 //    maximum, worst |xu - optimum| 2.0e-7; fast laps 10.29 / 16, 7.4e-6 -> 7.7e-7; 30-lap sample 9.04 -> 9.05 / 14, 2.4e-6 -> 9.7e-7; N = 40 10.81 -> 10.83 / 18,
-//    4.9e-6 -> 1.6e-7.  (A form that also looked at the length of the last step -- one more wave reduction per iteration -- bought nothing over this one in the
-//    model and cost the kernels 3 % at batch 256 and 20 % at N = 40 through register allocation alone: profiles/r5i_bench.json.)
-#define LMPC_ACC_RATIO 1e-3
+//    4.9e-6 -> 1.6e-7.  At horizons beyond 24 "superlinear" means a ratio below 1e-4: one of 256 sampled N = 40 problems ended its eighth iteration at gap 2.8e-12
+//    after a 1e-3 contraction with lambda 4e-7 off (|zt - Succ lambda*| = 1.24e-6 (1 + |zt|), tools/n40_zt_probe.py); with 1e-4 the model's worst lambda error
+//    over every 4th N = 40 problem goes from 4.0e-7 to 8.3e-8 for +0.03 iterations.  (A form that also looked at the length of the last step -- one more wave
+//    reduction per iteration -- bought nothing over this one in the model; the time it seemed to cost at N = 40 was that kernel's exposed global loads, see ABG.)
+template <int N> constexpr double LMPC_ACC_RATIO = N > 24 ? 1e-4 : 1e-3;
 template <int N> constexpr double LMPC_ACC_FLOOR = N > 24 ? 0.03 : 0.1;
 template <int N> __device__ __forceinline__ bool accuracy_ok(double gap, double gap_prev, double tol_gap) {
 #ifdef LMPC_AB_NOACC                    // (developer A / B: the gap test alone, rounds 1-4)
     return true;
 #endif
-    return gap_prev < 0.0 || gap <= LMPC_ACC_RATIO * gap_prev || gap < LMPC_ACC_FLOOR<N> * tol_gap;
+    return gap_prev < 0.0 || gap <= LMPC_ACC_RATIO<N> * gap_prev || gap < LMPC_ACC_FLOOR<N> * tol_gap;
 }
 // Barrier weights theta = mu / t are capped at 1e11 in the Newton matrix: 1 / theta >= 1e-11 is a dual regularisation of the inequality row
 // (F dw + (1 / theta_c) dmu = -r_c / mu); the right-hand side uses the same effective reciprocal rt = 1 / max(t, 1e-11 mu), so the fixed

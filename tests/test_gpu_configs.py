@@ -397,7 +397,7 @@ def test_k1_k2_k3_match_oracle_on_every_bench_problem(built):
 
 def test_n40_every_problem_against_oracle(built):
     """BASELINE configs[4] (N = 40, batch 1024) as a first-class configuration: K1 and K2 against the oracle on ALL 1024 problems, K3 against the oracle's
-    certified optimum on 64 evenly spaced ones -- through the kernel the batch size selects (one wave per QP, [A_k | B_k] in global memory) and, for the
+    certified optimum on 256 evenly spaced ones -- through the kernel the batch size selects (one wave per QP, [A_k | B_k] in global memory) and, for the
     first 256 problems, through the four-wave kernel as well."""
     from oracle import lmpc_oracle as orc
     from racinglmpc_amd import _capi
@@ -408,7 +408,7 @@ def test_n40_every_problem_against_oracle(built):
     par = orc.QPParams.lmpc_default(N)
     pid = (np.array(g["xPID"]), np.array(g["uPID"]))
     inp = inputs(g, N, B)
-    res = oracle_pool.oracle_batch(par, pt, TL, [pid] * 4, N, inp, range(B), solve_idx=range(0, B, 16))
+    res = oracle_pool.oracle_batch(par, pt, TL, [pid] * 4, N, inp, range(B), solve_idx=range(0, B, 4))
     cfg, _ = common.lmpc_config(g, N, max_batch=B)
     ctx = _capi.Context(cfg)
     for _ in range(4):
