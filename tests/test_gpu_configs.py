@@ -1,5 +1,7 @@
 """-m gpu: the other BASELINE.json configurations as parity cases -- batch=4096 with a 30-lap safe set, long horizon
 N=40, reference default N=14 -- through sampled oracle comparisons and size-independent properties on the full batch."""
+import os
+
 import numpy as np
 import pytest
 
@@ -314,6 +316,9 @@ def test_fused_step_matches_two_kernel_step(built):
         assert np.array_equal(a[k], b[k]), k
 
 
+ORACLE_STRIDE = int(os.environ.get("LMPC_TEST_ORACLE_STRIDE", "4"))       # K3 against the oracle's optimum on every 4th problem of the big batches (smaller strides: the restated ADMM needs up to 20 s on some problems -- stride 1 did not finish in 16 minutes)
+
+
 def _compare_with_oracle(out, res, N, what):
     """K1 / K2 of every oracle record in `res` (tests/oracle_pool.oracle_batch), K3 of those that carry the certified optimum: A, B, C to TOL_ABC relative,
     SS_sel / Qfun_sel identical, |xPred, uPred - z*| < TOL_XU, objective to 1e-8 relative.  zt / zt_u (feasibleStateInput, :382-384):
@@ -374,7 +379,7 @@ def test_k1_k2_k3_match_oracle_on_every_bench_problem(built):
     inp_b = bench.synth_batch(g, 4096, N, seed=1234, lap=laps[29])
     # the oracle first (forked workers, before this process has a HIP context)
     res_a = oracle_pool.oracle_batch(par, pt, TL, [pid] * 4, N, inp_a, range(256), solve_idx=range(256))
-    res_b = oracle_pool.oracle_batch(par, pt, TL, laps4, N, inp_b, range(0, 4096, 16), solve_idx=range(0, 4096, 16))
+    res_b = oracle_pool.oracle_batch(par, pt, TL, laps4, N, inp_b, range(0, 4096, ORACLE_STRIDE), solve_idx=range(0, 4096, ORACLE_STRIDE))
     # (a) bench batch
     cfg, _ = common.lmpc_config(g, N, max_batch=256)
     ctx = _capi.Context(cfg)
@@ -384,14 +389,14 @@ def test_k1_k2_k3_match_oracle_on_every_bench_problem(built):
     assert np.all(out["status"] == 0)
     _compare_with_oracle(out, res_a, N, "bench batch (four waves per QP)")
     ctx.close()
-    # (b) 4096 problems / 30 laps, every 16th problem
+    # (b) 4096 problems / 30 laps, every 4th problem
     cfg, _ = common.lmpc_config(g, N, max_batch=4096, max_laps=40, max_lap_len=1024)
     ctx = _capi.Context(cfg)
     for x, u in laps:
         ctx.model_add_trajectory(x, u); ctx.ss_add_trajectory(x, u)
     out = ctx.step_batch(inp_b["x0"], inp_b["xLin"], inp_b["uLin"], inp_b["uOld"], zt=inp_b["zt"], timeStep=inp_b["timeStep"])
     assert np.all(out["status"] == 0)
-    _compare_with_oracle(out, res_b, N, "4096 / 30 laps (one wave per QP), every 16th problem")
+    _compare_with_oracle(out, res_b, N, "4096 / 30 laps (one wave per QP), every %s problem" % ("4th" if ORACLE_STRIDE == 4 else "%d-th" % ORACLE_STRIDE))
     ctx.close()
 
 
@@ -408,7 +413,7 @@ def test_n40_every_problem_against_oracle(built):
     par = orc.QPParams.lmpc_default(N)
     pid = (np.array(g["xPID"]), np.array(g["uPID"]))
     inp = inputs(g, N, B)
-    res = oracle_pool.oracle_batch(par, pt, TL, [pid] * 4, N, inp, range(B), solve_idx=range(0, B, 4))
+    res = oracle_pool.oracle_batch(par, pt, TL, [pid] * 4, N, inp, range(B), solve_idx=range(0, B, ORACLE_STRIDE))
     cfg, _ = common.lmpc_config(g, N, max_batch=B)
     ctx = _capi.Context(cfg)
     for _ in range(4):
