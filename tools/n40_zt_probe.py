@@ -1,5 +1,9 @@
-import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+"""Developer tool (GPU box): BASELINE configs[4] (N = 40, batch 1024) -- every 4th problem against the oracle's certified optimum, the eight with the largest
+|zt - Succ lambda*| / (1 + |zt|): how far the two oracle methods are apart on them (lambda* determinate?), error in (x, u), in lambda, iterations, final gap.
+    python tools/n40_zt_probe.py"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import lmpc_oracle as orc
 from racinglmpc_amd import _capi
 from tests import oracle_pool, common
