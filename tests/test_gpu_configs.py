@@ -432,6 +432,30 @@ def test_n40_every_problem_against_oracle(built):
     ctx.close()
 
 
+@pytest.mark.parametrize("N,B,stride", [(14, 256, 2), (20, 300, 3), (24, 400, 4)])
+def test_other_horizons_against_oracle(built, N, B, stride):
+    """K1 / K2 / K3 against the oracle at horizons between the bench's and configs[4]'s, every `stride`-th problem of a synthetic batch (round 5: this probe,
+    tools/oracle_probe.py, found (x, u) 1.09e-6 off on 1 of 100 N = 20 problems and set where the tight pair of the termination rule begins -- accuracy_ok)."""
+    import bench
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    from tests import oracle_pool
+    g = common.load_lmpc_golden()
+    pt = np.array(g["track"]); TL = float(g["trackLength"])
+    par = orc.QPParams.lmpc_default(N)
+    pid = (np.array(g["xPID"]), np.array(g["uPID"]))
+    inp = bench.synth_batch(g, B, N, seed=4321)
+    res = oracle_pool.oracle_batch(par, pt, TL, [pid] * 4, N, inp, range(0, B, stride), solve_idx=range(0, B, stride))
+    cfg, _ = common.lmpc_config(g, N, max_batch=B)
+    ctx = _capi.Context(cfg)
+    for _ in range(4):
+        ctx.model_add_trajectory(*pid); ctx.ss_add_trajectory(*pid)
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    assert np.all(out["status"] == 0) and int(ctx.stats().n_retry) == 0
+    _compare_with_oracle(out, res, N, "N = %d, batch %d (%d wave(s) per QP), every %d-th problem" % (N, B, ctx.solver_waves(B), stride))
+    ctx.close()
+
+
 def test_kernel_routes_of_the_bench_configuration(built):
     """Which solve kernel serves which batch size at N = 12 / 48 safe-set points (lmpc_solver_waves): four waves per QP up to one QP per CU, two
     waves up to FOUR QPs per CU, one wave beyond.  The two-wave range is capped by the occupancy the runtime reports for that kernel: round 4 added
