@@ -400,6 +400,32 @@ def test_k1_k2_k3_match_oracle_on_every_bench_problem(built):
     ctx.close()
 
 
+@pytest.mark.parametrize("L,B,stride", [(8, 1024, 8), (30, 256, 8)])
+def test_wide_safe_sets_against_oracle(built, L, B, stride):
+    """K1 / K2 / K3 against the oracle with more terminal-block columns than a wavefront has lanes: the L fastest of 30 stored laps in regression and safe
+    set, 12 L safe-set points (96: two columns per lane; 360 -- SURVEY 8(d)'s stress variant --: six), every `stride`-th problem of a synthetic batch."""
+    import bench
+    from oracle import lmpc_oracle as orc
+    from racinglmpc_amd import _capi
+    from tests import oracle_pool
+    g = common.load_lmpc_golden()
+    pt = np.array(g["track"]); TL = float(g["trackLength"]); N = 12
+    par = orc.QPParams.lmpc_default(N)
+    laps = pid_laps_batched(pt, 30)
+    order = sorted(range(30), key=lambda i: (laps[i][0].shape[0], i))
+    used = [laps[i] for i in order[:L]]
+    inp = bench.synth_batch(g, B, N, seed=1234, lap=laps[29])
+    res = oracle_pool.oracle_batch(par, pt, TL, used, N, inp, range(0, B, stride), solve_idx=range(0, B, stride))
+    cfg, _ = common.lmpc_config(g, N, max_batch=B, numSS_it=L, numSS_Points=12 * L, trToUse=L, max_laps=40, max_lap_len=1024)
+    ctx = _capi.Context(cfg)
+    for x, u in laps:
+        ctx.model_add_trajectory(x, u); ctx.ss_add_trajectory(x, u)
+    out = ctx.step_batch(inp["x0"], inp["xLin"], inp["uLin"], inp["uOld"], zt=inp["zt"], timeStep=inp["timeStep"])
+    assert np.all(out["status"] == 0)
+    _compare_with_oracle(out, res, N, "%d laps / %d safe-set points, batch %d (%d wave(s) per QP), every %d-th problem" % (L, 12 * L, B, ctx.solver_waves(B), stride))
+    ctx.close()
+
+
 def test_n40_every_problem_against_oracle(built):
     """BASELINE configs[4] (N = 40, batch 1024) as a first-class configuration: K1 and K2 against the oracle on ALL 1024 problems, K3 against the oracle's
     certified optimum on 256 evenly spaced ones -- through the kernel the batch size selects (one wave per QP, [A_k | B_k] in global memory) and, for the
