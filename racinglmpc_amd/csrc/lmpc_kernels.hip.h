@@ -236,18 +236,19 @@ __device__ __forceinline__ double frcp(double x) {
 //  * termination (round 5): on a QP without strict complementarity the distance to the optimum goes like sqrt(gap), not like gap -- the gap test alone let 1 of
 //    256 sampled problems of the 30-lap batch stop 2.4e-6 from its optimum (x_N), 1 of 286 fast-lap QPs 7e-6 and 1 of 128 N = 40 problems 5e-6 -- and those
 //    are the problems whose gap contracts LINEARLY at the end.  A problem whose last step was not superlinear (gap ratio above 1e-3) therefore needs a smaller
-//    gap to end: 0.1 tol_gap, and 0.03 tol_gap at horizons beyond 14 (the error constant grows with the number of coupled stages): scalar comparisons on
+//    gap to end: 0.1 tol_gap, and 0.03 tol_gap at horizons beyond 12 (the error constant grows with the number of coupled stages): scalar comparisons on
 //    values the iteration has anyway.  NumPy model (tests/ipm_model.py: acc_rule; tools/ipm_acc_sets.py) -- bench batch 8.28 -> 8.30 / 12 unchanged
 //    maximum, worst |xu - optimum| 2.0e-7; fast laps 10.29 / 16, 7.4e-6 -> 7.7e-7; 30-lap sample 9.04 -> 9.05 / 14, 2.4e-6 -> 9.7e-7; N = 40 10.81 -> 10.83 / 18,
-//    4.9e-6 -> 1.6e-7.  At horizons beyond 14 "superlinear" means a ratio below 1e-4: one of 256 sampled N = 40 problems ended its eighth iteration at gap 2.8e-12
+//    4.9e-6 -> 1.6e-7.  At horizons beyond 12 "superlinear" means a ratio below 1e-4: one of 256 sampled N = 40 problems ended its eighth iteration at gap 2.8e-12
 //    after a 1e-3 contraction with lambda 4e-7 off (|zt - Succ lambda*| = 1.24e-6 (1 + |zt|), tools/n40_zt_probe.py); with 1e-4 the model's worst lambda error
 //    over every 4th N = 40 problem goes from 4.0e-7 to 8.3e-8 for +0.03 iterations.  (A form that also looked at the length of the last step -- one more wave
 //    reduction per iteration -- bought nothing over this one in the model; the time it seemed to cost at N = 40 was that kernel's exposed global loads, see ABG.)
 //    Where "long" begins was set by probing other horizons against the oracle (tools/oracle_probe.py, every 3rd / 4th problem): N = 14 holds 2.3e-7 with the loose pair,
 //    N = 20 missed (x, u) by 1.09e-6 on 1 of 100 problems (final gap 8.9e-13: the floor) and N = 24 sat at 7.9e-7 (a 9e-4 contraction counted as superlinear) -- the
-//    tight pair applies beyond N = 14.
-template <int N> constexpr double LMPC_ACC_RATIO = N > 14 ? 1e-4 : 1e-3;
-template <int N> constexpr double LMPC_ACC_FLOOR = N > 14 ? 0.03 : 0.1;
+//    tight pair applies beyond N = 12: at N = 14 (main.py's horizon) the model's fast-lap set -- real LMPC laps in the safe set -- holds 7.7e-7 with the loose pair and 2.6e-7
+//    with the tight one for +1 % iterations; N = 12 keeps the loose pair (1 536 bench / 30-lap problems against the oracle: 3e-7).
+template <int N> constexpr double LMPC_ACC_RATIO = N > 12 ? 1e-4 : 1e-3;
+template <int N> constexpr double LMPC_ACC_FLOOR = N > 12 ? 0.03 : 0.1;
 template <int N> __device__ __forceinline__ bool accuracy_ok(double gap, double gap_prev, double tol_gap) {
 #ifdef LMPC_AB_NOACC                    // (developer A / B: the gap test alone, rounds 1-4)
     return true;
