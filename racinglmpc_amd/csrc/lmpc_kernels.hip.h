@@ -255,6 +255,18 @@ template <int N> __device__ __forceinline__ bool accuracy_ok(double gap, double 
 #endif
     return gap_prev < 0.0 || gap <= LMPC_ACC_RATIO<N> * gap_prev || gap < LMPC_ACC_FLOOR<N> * tol_gap;
 }
+// A-posteriori estimate of the distance to the optimum, horizons beyond 12 (round 5, from probing the closed loop against the oracle: tools/closed_loop_oracle_probe.py).
+// One of ~1 000 sampled closed-loop QPs of the 40-lap experiment at N = 14 met every test above 2.8e-6 from its optimum: a FLAT problem, error = 660 x dual residual,
+// with r_d = 4e-9 far inside its tolerance.  The last Newton step was ~ H^-1 r_prev, so |H^-1| ~ |step| / r_d,prev and the error left is ~ r_d |step| / r_d,prev (4.6e-6 there):
+// wave-uniform scalars, one more wave maximum per iteration in the step phase.  A problem whose estimate exceeds LMPC_ACC_EST iterates once more.  Model, LMPC_ACC_EST = 1e-6:
+// that QP 2.9e-6 -> 1.7e-7; fast laps 10.35 -> 10.38 iterations / 16, worst error 1.5e-7 -> 2.4e-8; N = 40 10.84 -> 10.91 / 18.  The N <= 12 kernels do not carry it: the
+// bench batch would pay 8.30 -> 8.40 iterations and its maximum 12 -> 13 for no change of its worst error (1.4e-7; 1 536 problems at N = 12 against the oracle: <= 3e-7).
+#define LMPC_ACC_EST 1e-6
+template <int N> constexpr bool LMPC_ACC_HAS_EST = N > 12;
+template <int N> __device__ __forceinline__ bool estimate_ok(double rd, double rd_prev, double step_prev) {
+    if constexpr (!LMPC_ACC_HAS_EST<N>) return true;
+    return rd_prev <= 0.0 || step_prev * rd <= LMPC_ACC_EST * rd_prev;
+}
 // Barrier weights theta = mu / t are capped at 1e11 in the Newton matrix: 1 / theta >= 1e-11 is a dual regularisation of the inequality row
 // (F dw + (1 / theta_c) dmu = -r_c / mu); the right-hand side uses the same effective reciprocal rt = 1 / max(t, 1e-11 mu), so the fixed
 // point does not move and the row's equation is off by 1e-11 dmu only.  Uncapped, an active lane row (t ~ 1e-14, mu ~ 10: main.py's fast
@@ -1779,6 +1791,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
     };
     int it = 0, converged = 0, sep = 0;                   // sep: separate primal/dual step lengths after a poor-progress iteration
     double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0;
+    double rd_prev = -1.0, step_prev = 0.0;                  // (horizons beyond 12: estimate_ok)
 
     const double qscale = wave_uniform(fmax(1.0, qmax));                // dual residual tolerance is relative to the cost scale
 #pragma unroll 1
@@ -1890,12 +1903,12 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
         // The dynamics rows are linear and every step keeps them (the roll-out start satisfies them, the Newton direction lies in their null
         // space): their residual only collects rounding, ~1e-13.  It is still checked -- wherever a decision depends on it (convergence,
         // the INEXACT classification) -- but no longer in the iterations whose other two residuals have not passed yet.
-        if (gap < p.tol_gap && rdn < p.tol_res * qscale && accuracy_ok<N>(gap, gap_prev, p.tol_gap)) {
+        if (gap < p.tol_gap && rdn < p.tol_res * qscale && accuracy_ok<N>(gap, gap_prev, p.tol_gap) && estimate_ok<N>(rdn, rd_prev, step_prev)) {
             ren = LMPC_UX(fmax(dyn_residual(), fabs(re_sum)));
             if (ren < p.tol_res) { converged = 1; break; }
         }
         if (gap_prev >= 0.0) sep = !EQ && gap > LMPC_SEP_THRESHOLD * gap_prev;
-        gap_prev = gap;
+        gap_prev = gap; rd_prev = rdn;
         if (it == p.max_iter) { ren = LMPC_UX(fmax(dyn_residual(), fabs(re_sum))); break; }
         if (!(gap == gap) || !(rdn == rdn)) { if (lane == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
 
@@ -2090,8 +2103,15 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
                 for (int j = 0; j < 6; j++) v -= SS[j * S + c] * T2p[j] * w7[j]; }
             deta = SWEEP_BF<N> ? wsum(v) * (1.0 / (double)S) : wsum(v) / (double)S;
         }
-        FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
-        FOR_LANES(i, 2 * N) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
+        if constexpr (LMPC_ACC_HAS_EST<N>) {                   // (the same step, and the length of its (x, u) part for estimate_ok)
+            double smax = 0.0;
+            FOR_LANES(i, 6 * (N + 1)) { smax = fmax(smax, fabs(al * dx[i])); x[i] = fma(al, dx[i], x[i]); }
+            FOR_LANES(i, 2 * N) { smax = fmax(smax, fabs(al * du[i])); u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
+            step_prev = LMPC_UX(wmax(smax));
+        } else {
+            FOR_LANES(i, 6 * (N + 1)) x[i] = fma(al, dx[i], x[i]);
+            FOR_LANES(i, 2 * N) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
+        }
         if constexpr (term) { FOR_LANES(c, S) lam[c] = fma(al, dl[c], lam[c]); }
 #pragma unroll
         for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) { m[r] = fma(ald, dm[r], m[r]); t_r[j] = fma(al, dt_r[j], t_r[j]); } }

@@ -299,6 +299,10 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
             acc_rule = dict(ratio=(1e-4 if N > 12 else 1e-3), step=0.0, floor=(0.03 if N > 12 else 0.1) * tol_gap)   # LMPC_ACC_RATIO<N> / LMPC_ACC_FLOOR<N> of the kernels (lmpc_kernels.hip.h: accuracy_ok); no step term there
         if acc_rule is not None and gp_before is not None:
             acc_ok = gap <= acc_rule["ratio"] * gp_before or info.get("step_prev", 0.0) <= acc_rule["step"] or gap < acc_rule["floor"]
+            if acc_rule.get("est") is not None and info.get("rd_prev", 0.0) > 0.0:
+                # (round 5) a-posteriori estimate of the distance to the optimum from wave-uniform scalars: the last Newton step was ~ H^-1 r_prev, so |H^-1| ~ step_prev / rd_prev
+                # and the error left is ~ |H^-1| rd.  A flat QP (1 of ~1 000 sampled closed-loop QPs: error = 660 x dual residual) fails this and iterates once more.
+                acc_ok = acc_ok and info.get("step_prev", 0.0) * rd <= acc_rule["est"] * info["rd_prev"]
         if acc_ok and gap < tol_gap and rd < tol_res * qscale and re < tol_res and (degen_tol is None or max(
                 [np.minimum(t, m / qscale).max() for t, m in zip((t_lane, t_u, t_s, t_l), (m_lane, m_u, m_s, m_l)) if t.size]) < degen_tol):
             break
@@ -436,6 +440,7 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
         if trace is not None:
             trace[-1][3:] = [sig, al, ald]
         info["step_prev"] = al * max(np.abs(dx).max(), np.abs(du).max())
+        info["rd_prev"] = rd
         x += al * dx; u += al * du; s += al * ds
         if carry_t:
             t_lane, t_u, t_s, t_l = [t + al * d for t, d in zip(ts, dt)]
