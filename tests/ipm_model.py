@@ -296,7 +296,7 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
         # below `ratio`) ends the iteration as before.
         acc_ok = True
         if acc_rule == "kernel":
-            acc_rule = dict(ratio=(1e-4 if N > 12 else 1e-3), step=0.0, floor=(0.03 if N > 12 else 0.1) * tol_gap)   # LMPC_ACC_RATIO<N> / LMPC_ACC_FLOOR<N> of the kernels (lmpc_kernels.hip.h: accuracy_ok); no step term there
+            acc_rule = dict(ratio=(1e-4 if N > 12 else 1e-3), step=0.0, floor=(0.03 if N > 12 else 0.1) * tol_gap, est=(1e-6 if N > 12 else None))   # LMPC_ACC_RATIO<N> / LMPC_ACC_FLOOR<N> / LMPC_ACC_EST of the kernels (lmpc_kernels.hip.h: accuracy_ok); no step term there
         if acc_rule is not None and gp_before is not None:
             acc_ok = gap <= acc_rule["ratio"] * gp_before or info.get("step_prev", 0.0) <= acc_rule["step"] or gap < acc_rule["floor"]
             if acc_rule.get("est") is not None and info.get("rd_prev", 0.0) > 0.0:
