@@ -33,12 +33,16 @@ def compile_checked(cmd, out, verbose=False, salts=None):
     log = []
     for salt in (SALTS if salts is None else salts):
         subprocess.check_call(cmd + salt + ["-o", tmp])
-        hits = isa_check.check(tmp)
+        try:
+            hits, images = isa_check.check_report(tmp)      # raises when nothing could be parsed: an unread library is not a clean one
+        except Exception:
+            os.remove(tmp)
+            raise
         log.append({"options": salt, "blocks": sorted({"%s %s" % (f, l) for f, l, _, _ in hits})})
         if not hits:
             os.replace(tmp, out)
             with open(out + ".isa.json", "w") as f:
-                json.dump({"accepted_with": salt, "attempts": log}, f)
+                json.dump({"accepted_with": salt, "attempts": log, "parsed": images}, f)
             if verbose or salt:
                 print("isa_check: %s accepted with options %s (%d attempt(s))" % (os.path.basename(out), salt or "none", len(log)))
             return out

@@ -26,7 +26,7 @@ import subprocess
 import sys
 import tempfile
 
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+OBJDUMP = os.environ.get("OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")       # (override next to HIPCC)
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 WIDEN = re.compile(r"^\s*(s_or_b64\s+exec,\s*exec,|s_or_saveexec_b64\s|s_xor_b64\s+exec,\s*exec,|s_mov_b64\s+exec,\s*s)")
 LANE_FREE = re.compile(r"^\s*(s_|v_readlane_b32|v_writelane_b32|v_readfirstlane_b32|;|$)")
@@ -132,17 +132,50 @@ def to_labelled(text):
     return "\n".join(out)
 
 
-def check(path):
+class IsaCheckError(RuntimeError):
+    """The check could not look at the code (no code object, nothing parsed): NOT a clean result."""
+
+
+def stats(text):
+    """(instructions, s_cbranch_execz branches with a resolved label) of a labelled listing: what a scan of it can have seen."""
+    n_ins = 0; n_skip = 0
+    for raw in text.splitlines():
+        st = raw.split("//")[0].split(";")[0].strip()
+        if not st or st.endswith(":") or st.startswith("."):
+            continue
+        n_ins += 1
+        if SKIP.match(st):
+            n_skip += 1
+    return n_ins, n_skip
+
+
+def check_report(path):
+    """(hits, report).  FAILS CLOSED (round 6): raises IsaCheckError unless every input yields at least one gfx9 code object, a non-zero number of parsed
+    instructions and at least one `s_cbranch_execz` with a resolved target per image -- a compressed offload bundle, a change of llvm-objdump's output format or a
+    missing tool must not read as "clean" (every solve kernel here has exec-mask regions, so an image without one was not parsed)."""
     texts = []
     if path.endswith(".s"):
-        texts.append(open(path).read())
+        texts.append(("listing", open(path).read()))
     else:
-        for triple, img in code_objects(path):
-            texts.append(to_labelled(disassemble(img)))
-    hits = []
-    for t in texts:
+        if not os.path.exists(OBJDUMP):
+            raise IsaCheckError("isa_check: %s not found (set OBJDUMP)" % OBJDUMP)
+        objs = code_objects(path)
+        if not objs:
+            raise IsaCheckError("isa_check: no amdgcn code object found in %s (compressed or unknown offload bundle?)" % path)
+        for triple, img in objs:
+            texts.append((triple, to_labelled(disassemble(img))))
+    hits = []; images = []
+    for triple, t in texts:
+        n_ins, n_skip = stats(t)
+        if n_ins == 0 or n_skip == 0:
+            raise IsaCheckError("isa_check: %s / %s: %d instructions and %d s_cbranch_execz parsed -- the disassembly was not understood" % (path, triple, n_ins, n_skip))
+        images.append({"image": triple, "instructions": n_ins, "execz_branches": n_skip})
         hits += scan(t)
-    return hits
+    return hits, images
+
+
+def check(path):
+    return check_report(path)[0]
 
 
 if __name__ == "__main__":

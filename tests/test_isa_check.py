@@ -65,6 +65,29 @@ def test_libraries_in_the_tree_are_clean():
         assert not hits, (os.path.basename(lib), sorted({(f, l) for f, l, _, _ in hits}))
 
 
+def test_check_fails_closed(tmp_path):
+    """a library the scanner cannot read is an error, never a clean result."""
+    empty = tmp_path / "no_bundle.so"
+    empty.write_bytes(b"\x7fELF" + b"\0" * 256)                              # no offload bundle inside
+    if os.path.exists(isa_check.OBJDUMP):
+        with pytest.raises(isa_check.IsaCheckError, match="no amdgcn code object"):
+            isa_check.check(str(empty))
+    blank = tmp_path / "blank.s"
+    blank.write_text("f:\n")                                                # a listing with no instruction
+    with pytest.raises(isa_check.IsaCheckError, match="not understood"):
+        isa_check.check(str(blank))
+    noexecz = tmp_path / "noexecz.s"
+    noexecz.write_text("f:\n\tv_mov_b32_e32 v1, v2\n\ts_endpgm\n")           # instructions, but not one exec-mask region: not one of these kernels
+    with pytest.raises(isa_check.IsaCheckError, match="not understood"):
+        isa_check.check(str(noexecz))
+    hits, images = isa_check.check_report(os.path.join(GOLD, "isa_sound_excerpt.s"))
+    assert hits == [] and images[0]["instructions"] > 0 and images[0]["execz_branches"] > 0
+    libs = sorted(glob.glob(os.path.join(common.ROOT, "racinglmpc_amd", "liblmpc_hip.so")))
+    if libs and os.path.exists(isa_check.OBJDUMP):
+        hits, images = isa_check.check_report(libs[0])
+        assert hits == [] and images and all(i["instructions"] > 10000 and i["execz_branches"] > 10 for i in images), images
+
+
 def test_pre_fix_sources_reproduce_the_fault():
     """tools/isa_fault_repro.py: the sources of the last commit before the round-5 change, compiled with the one define rounds 3-4 could not explain at N = 40
     (the 4x4x4 Gram matrix in the one-wave kernel), are flagged by the scanner -- v_accvgpr_write copies ahead of an s_or_saveexec_b64; HEAD's libraries are
