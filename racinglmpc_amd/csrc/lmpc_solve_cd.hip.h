@@ -348,7 +348,7 @@ __global__ __launch_bounds__(WAVE, 2) void lmpc_solve_kernel_cd(lmpc_dev_params 
     };
 
     int it = 0, converged = 0, sep = 0;
-    double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0;
+    double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0, step_prev = INFINITY, step_pp = INFINITY;
     const double qscale = wave_uniform(fmax(1.0, qmax));
 #pragma unroll 1
     for (it = 0; it <= p.max_iter; it++) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(WAVE, 2) void lmpc_solve_kernel_cd(lmpc_dev_params 
         rdn = wmax(rmax);
         const double re_sum = term ? wave_uniform(wsum(lsum) - 1.0) : 0.0;
         ren = fabs(re_sum);
-        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res && accuracy_ok<N>(gap, gap_prev, p.tol_gap)) { converged = 1; break; }
+        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res && step_bound_ok(step_prev, step_pp)) { converged = 1; break; }
         if (gap_prev >= 0.0) sep = !EQ && gap > LMPC_SEP_THRESHOLD * gap_prev;
         gap_prev = gap;
         if (it == p.max_iter) break;
@@ -619,6 +619,10 @@ __global__ __launch_bounds__(WAVE, 2) void lmpc_solve_kernel_cd(lmpc_dev_params 
         __syncthreads();
         TSTAMP(18);
         // ---- step, then the roll-out of the new inputs ---------------------------------------------------------------------------------
+        double xo0 = 0.0, xo1 = 0.0;                           // the states before the step (step_bound_ok measures the (x, u) step actually taken; 6 (N + 1) <= 102 entries)
+        if (lane < 6 * (N + 1)) xo0 = x[lane];
+        if (lane + WAVE < 6 * (N + 1)) xo1 = x[lane + WAVE];
+        double smax = lane < NV ? fabs(al * du[lane]) : 0.0;
         if (lane < NV) { u[lane] = fma(al, du[lane], u[lane]); s[lane] = fma(al, ds[lane], s[lane]); }
         if constexpr (term) { if (lane < S) lam[lane] = fma(al, dl[lane], lam[lane]); }
 #pragma unroll
@@ -629,6 +633,9 @@ __global__ __launch_bounds__(WAVE, 2) void lmpc_solve_kernel_cd(lmpc_dev_params 
         __syncthreads();
         rollout();
         __syncthreads();
+        if (lane < 6 * (N + 1)) smax = fmax(smax, fabs(x[lane] - xo0));
+        if (lane + WAVE < 6 * (N + 1)) smax = fmax(smax, fabs(x[lane + WAVE] - xo1));
+        step_pp = step_prev; step_prev = wave_uniform(wmax(smax));
     }
     TSTAMP(20);
     if (!converged && lane == 0 && !(st_sh & (LMPC_ST_NUMERIC | LMPC_ST_INEXACT)))

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     };
 
     int it = 0, converged = 0, sep = 0;
-    double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0, lsum_all = 0.0, rd_prev = -1.0;
+    double gap = 0.0, rdn = 0.0, ren = 0.0, gap_prev = -1.0, lsum_all = 0.0, step_pp = INFINITY;      // step_pp: the (x, u) step before the last one (the last one is in reduction slot 6)
     const double qscale = fmax(1.0, qmax);
     constexpr int FB_WAVE = NW > 2 ? 2 : 1;                  // wave that runs the feed-forward follower (its own wave when there are three helpers)
 #pragma unroll 1
@@ -561,9 +561,10 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         const double re_sum = term ? lsum_all - 1.0 : 0.0;
         ren = fmax(ren, fabs(re_sum));
         TRACE3(tid == 0, 0, gap, rdn, ren);
-        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res && accuracy_ok<N>(gap, gap_prev, p.tol_gap) && estimate_ok<N>(rdn, rd_prev, LMPC_ACC_HAS_EST<N> ? red_max(6) : 0.0)) { converged = 1; break; }
+        const double step_last = it > 0 ? red_max(6) : INFINITY;         // (written in the step phase, two barriers ago)
+        if (gap < p.tol_gap && rdn < p.tol_res * qscale && ren < p.tol_res && step_bound_ok(step_last, step_pp)) { converged = 1; break; }
         if (gap_prev >= 0.0) sep = gap > LMPC_SEP_THRESHOLD * gap_prev;
-        gap_prev = gap; rd_prev = rdn;
+        gap_prev = gap; step_pp = step_last;
         if (it == p.max_iter) break;
         if (!(gap == gap) || !(rdn == rdn)) { if (tid == 0) atomicOr(&st_sh, LMPC_ST_NUMERIC); break; }
         TSMW(12);
@@ -827,14 +828,11 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             for (int j = 0; j < 6; j++) deta -= T2p[j] * w7[j] * ss_rowsum[j];
             if constexpr (SWEEP_BF<N>) deta *= 1.0 / (double)S; else deta /= (double)S;
         }
-        if constexpr (LMPC_ACC_HAS_EST<N>) {                   // (the same step, and the length of its (x, u) part for estimate_ok: slot 6 is free from the predictor's
+        {                                                      // (the step, and the length of its (x, u) part for step_bound_ok: slot 6 is free from the predictor's
             double smax = 0.0;                                 //  sigma to the next iteration's, and is read at the top of that iteration, behind this phase's barrier)
             FOR_WAVE2(i, 6 * (N + 1), 1, 2) { smax = fmax(smax, fabs(al * dx[i])); x[i] = fma(al, dx[i], x[i]); }
             FOR_WAVE(i, 2 * N, 2) { smax = fmax(smax, fabs(al * du[i])); u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
             red_put(6, wmax<BCF>(smax));
-        } else {
-            FOR_WAVE2(i, 6 * (N + 1), 1, 2) x[i] = fma(al, dx[i], x[i]);
-            FOR_WAVE(i, 2 * N, 2) { u[i] = fma(al, du[i], u[i]); s[i] = fma(al, ds[i], s[i]); }
         }
         if constexpr (term) { FOR_WAVE(c, S, 2) lam[c] = fma(al, dl[c], lam[c]); }
         gsum_c = 0.0;

@@ -160,7 +160,7 @@ def kkt_solve(qp, f, th_lane, th_s, gx, gu, gs, h_lane, h_u, h_s, gl, re_dyn, re
     return dx, du, ds, dl
 
 
-def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True, polish=None, pex=None, so_w=1.0, start=None, trace=None, degen_tol=None, acc_rule="kernel"):
+def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True, polish=None, pex=None, so_w=1.0, start=None, trace=None, degen_tol=None, acc_rule="kernel", snaps=None):
     """Returns dict(x,u,s,lam,sT, mu (ineq duals in reference row order), iters, gap, rd, re).
     exact_nu (round 3): the multipliers of the dynamics rows are not iterates of their own; every iteration takes them from the adjoint recursion
     nu_{k-1} = A_k' nu_k - w_k (w_k: gradient of the state rows' other terms), so the x rows of the dual residual vanish identically and the
@@ -266,6 +266,8 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
         info.update(iters=it, gap=gap, rd=rd, re=re)
         if trace is not None:
             trace.append([gap, rd, re, np.nan, np.nan, np.nan])          # (gap, r_d, r_e | sigma, alpha_p, alpha_d of the step taken from here)
+        if snaps is not None:                                             # (tools/term_rule_model.py: the iterate every termination rule is evaluated on, and the scalars the kernels have at this point)
+            snaps.append(dict(x=x.copy(), u=u.copy(), lam=lam.copy(), gap=gap, rd=rd, re=re, step_prev=info.get("step_prev", 0.0), lstep_prev=info.get("lstep_prev", 0.0), rd_prev=info.get("rd_prev", 0.0), gap_prev=gp_before))
         if pol_backup is not None:
             # the previous iteration was an active-set (polish) step: accept it only if the true residuals meet the ordinary tolerances and
             # the signs hold (slacks of the rows taken as inactive, multipliers of the rows taken as active); otherwise back to the iterate it started from
@@ -296,8 +298,15 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
         # below `ratio`) ends the iteration as before.
         acc_ok = True
         if acc_rule == "kernel":
-            acc_rule = dict(ratio=(1e-4 if N > 12 else 1e-3), step=0.0, floor=(0.03 if N > 12 else 0.1) * tol_gap, est=(1e-6 if N > 12 else None))   # LMPC_ACC_RATIO<N> / LMPC_ACC_FLOOR<N> / LMPC_ACC_EST of the kernels (lmpc_kernels.hip.h: accuracy_ok); no step term there
-        if acc_rule is not None and gp_before is not None:
+            # (round 6) step_bound_ok of the kernels, lmpc_kernels.hip.h: the a-posteriori bound of a contracting iteration, |z - z*| <= rho / (1 - rho) |last step| with the rate
+            # measured on the last two (x, u) steps, below LMPC_ACC_TOL = 3e-7 -- one rule for every horizon (tools/term_rule_model.py)
+            acc_rule = lambda q: q["step_prev"] < q["step_pp"] and q["step_prev"] ** 2 <= 3e-7 * (q["step_pp"] - q["step_prev"])
+        elif acc_rule == "r5":
+            acc_rule = dict(ratio=(1e-4 if N > 12 else 1e-3), step=0.0, floor=(0.03 if N > 12 else 0.1) * tol_gap, est=(1e-6 if N > 12 else None))   # round 5's LMPC_ACC_RATIO<N> / LMPC_ACC_FLOOR<N> / LMPC_ACC_EST
+        if callable(acc_rule):                                            # (tools/term_rule_model.py: any rule on the scalars of this point)
+            acc_ok = bool(acc_rule(dict(gap=gap, gap_prev=gp_before, rd=rd, re=re, rd_prev=info.get("rd_prev", 0.0), step_prev=info.get("step_prev", np.inf), step_pp=info.get("step_pp", np.inf), lstep_prev=info.get("lstep_prev", 0.0),
+                                        base_ok=gap < tol_gap and rd < tol_res * qscale and re < tol_res, it=it)))
+        elif acc_rule is not None and gp_before is not None:
             acc_ok = gap <= acc_rule["ratio"] * gp_before or info.get("step_prev", 0.0) <= acc_rule["step"] or gap < acc_rule["floor"]
             if acc_rule.get("est") is not None and info.get("rd_prev", 0.0) > 0.0:
                 # (round 5) a-posteriori estimate of the distance to the optimum from wave-uniform scalars: the last Newton step was ~ H^-1 r_prev, so |H^-1| ~ step_prev / rd_prev
@@ -439,8 +448,10 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
         act_pred = [(t + d) < (m + d2) for t, d, m, d2 in zip(ts, dt, ms, dm)]      # full-step (Newton target) classification of the rows
         if trace is not None:
             trace[-1][3:] = [sig, al, ald]
+        info["step_pp"] = info.get("step_prev", np.inf)
         info["step_prev"] = al * max(np.abs(dx).max(), np.abs(du).max())
         info["rd_prev"] = rd
+        info["lstep_prev"] = al * np.abs(dl).max() if qp.term else 0.0
         x += al * dx; u += al * du; s += al * ds
         if carry_t:
             t_lane, t_u, t_s, t_l = [t + al * d for t, d in zip(ts, dt)]
