@@ -757,7 +757,39 @@ def pid_lap(pt, vt, seed, x0=None, multiLap=True, maxSimTime=100):
     return np.array(x_cl), np.array(u_cl), np.array(x_glob)
 
 
-def dense_ipm_solve(P, q, A, l, u, tol=1e-13, max_iter=80):
+def _active_set_finish(P, q, E, b, G, h, s, lam, scale, rounds=12, delta=1e-9, refine=8):
+    """See dense_ipm_solve.  Returns (z, y, lam) of the accepted active set or None."""
+    n, me, mi = P.shape[0], E.shape[0], G.shape[0]
+    act = lam > s
+    for _ in range(rounds):
+        Ga, ha = G[act], h[act]; ma = Ga.shape[0]
+        K = np.zeros((n + me + ma, n + me + ma))
+        K[:n, :n] = P; K[:n, n:n + me] = E.T; K[n:n + me, :n] = E; K[:n, n + me:] = Ga.T; K[n + me:, :n] = Ga
+        Kr = K.copy()
+        Kr[np.arange(n), np.arange(n)] += delta
+        Kr[np.arange(n, n + me + ma), np.arange(n, n + me + ma)] -= delta
+        rhs = np.concatenate([-q, b, ha])
+        try:
+            Ki = np.linalg.inv(Kr)
+        except np.linalg.LinAlgError:
+            return None
+        sol = Ki @ rhs
+        for _r in range(refine):
+            sol = sol + Ki @ (rhs - K @ sol)
+        z, y = sol[:n], sol[n:n + me]
+        lam2 = np.zeros(mi); lam2[act] = sol[n + me:]
+        bad_p = (~act) & (G @ z - h > 1e-11)
+        bad_d = act & (lam2 < -1e-11 * scale)
+        if not bad_p.any() and not bad_d.any():
+            lam2 = np.maximum(lam2, 0.0)
+            if np.abs(K @ sol - rhs).max() > 1e-9 * scale:       # (the refinement did not converge: a singular active set with an inconsistent right-hand side)
+                return None
+            return z, y, lam2
+        act = (act & ~bad_d) | bad_p
+    return None
+
+
+def dense_ipm_solve(P, q, A, l, u, tol=1e-13, max_iter=80, polish=True):
     """Second, independent way to the QP's optimum (test infrastructure; round 5): a textbook dense primal-dual interior-point iteration (Mehrotra) on the
     EXPLICIT reference-form matrices P, q, A, l, u (PredictiveControllers.py:259-283) -- dense LU of the reduced KKT matrix, no block structure, no
     Riccati recursion, nothing shared with the HIP kernels or with tests/ipm_model.py.  Used by osqp_solve_exact where the restated ADMM does not reach the
@@ -810,12 +842,24 @@ def dense_ipm_solve(P, q, A, l, u, tol=1e-13, max_iter=80):
         dz, dy, ds, dlam = solve(D, rd, rp, re, s * lam + ds * dlam - sig * mu)
         a = 0.99 * min(step(s, ds), step(lam, dlam)); a = min(a, 1.0)
         z = z + a * dz; y = y + a * dy; s = s + a * ds; lam = lam + a * dlam
+    interior = True
+    if polish:
+        # (round 6) active-set finish, the idea of the reference's own `polish=True` (PredictiveControllers.py:275): an interior iterate that meets the residual
+        # tolerances can still sit 1e-6..1e-5 from the optimum of a FLAT or degenerate QP (the closed-loop probes of round 6 found this function 7e-6 off where the HIP
+        # kernels agreed with a 1e-15 solve to 1e-8).  With the active set A = {rows with lam > s} the optimum solves the equality-constrained system
+        #     [P E' G_A'; E 0 0; G_A 0 0] (z, y, lam_A) = (-q, b, h_A)
+        # exactly (regularised LU + iterative refinement against the unregularised matrix); the point is accepted only if its signs hold -- inactive rows feasible,
+        # active multipliers non-negative -- else rows change sides (primal-dual active-set steps) and the system is solved again.  An accepted point lies ON its active
+        # set: its KKT residuals are rounding (1e-12), and so is its distance to the optimum along flat directions.
+        pol = _active_set_finish(P, q, E, b, G, h, s, lam, scale)
+        if pol is not None:
+            z, y, lam = pol; interior = False
     r = OSQPResult()
     yy = np.zeros(A.shape[0]); yy[eq] = y
     nu_ = int(up.sum())
     yy[up] += lam[:nu_]; yy[lo] -= lam[nu_:]
     r.x, r.y, r.z, r.status, r.iter = z, yy, A @ z, 1, it
-    r.interior = True
+    r.interior = interior
     r.status_polish = 0; r.obj_val = float(0.5 * z @ P @ z + q @ z); r.pri_res = 0.0; r.dua_res = 0.0; r.rho_updates = 0
     return r
 
