@@ -172,7 +172,10 @@ def rollout_leg(g, comm, ctx, rollouts_per_gpu, generations=2, K=4, T_max=400):
     ro = rollout.BatchedRollouts(ctx, g["track"], seed=100 + rank)
     x0 = np.tile(np.array([0.5, 0, 0, 0, 0, 0.0]), (total, 1)); x0[:, 5] = np.linspace(-0.1, 0.1, total); x0[:, 0] += np.linspace(0.0, 0.1, total)
     gen = rollout.LmpcGeneration(ro, total, K=K, T_max=T_max, ext=40, comm=comm)
-    gen.prepare()              # the synthetic plant noise of the first lap is input data: drawn before the timed region (later laps' draws overlap the device work)
+    # The synthetic plant noise of the first lap is input data: drawn BEFORE the timed region (later laps' draws overlap the device work on a worker thread).  The
+    # reference draws inside its simulation loop (SysModel.py:139-141), so generation 0's rate excludes this host time: the line says so (`noise_pregenerated`,
+    # `noise_host_ms_excluded`; rounds 1-4 drew inside the timed region -- their closed-loop numbers included it).
+    t_pre = time.perf_counter(); gen.prepare(); noise_ms = (time.perf_counter() - t_pre) * 1e3
     laps = []
     for it in range(generations):
         comm.barrier(); t0 = time.perf_counter()
@@ -182,8 +185,9 @@ def rollout_leg(g, comm, ctx, rollouts_per_gpu, generations=2, K=4, T_max=400):
         laps.append(dict(generation=it, seconds=dt, simulated_steps=steps, best_lap_steps=[b[4] for b in best], src_ranks=[int(b[3]) for b in best],
                          closed_loop_solves_per_s=total * steps / dt, allgather_bytes_per_rank=int(gen.last_exchange[0]),
                          exchange_seconds=float(comm.allreduce_max(gen.last_exchange[1])[0])))
+    ro.close()                 # (waits for the prefetched draw nobody will use, restores the generator, ends the worker thread)
     info = ctx.comm_info()
-    return dict(rollouts_total=total, rollouts_per_gpu=rollouts_per_gpu, K=K, collective="ncclAllGather (RCCL)" if info[2] else "none (single process)",
+    return dict(noise_pregenerated=True, noise_host_ms_excluded=round(noise_ms, 2), rollouts_total=total, rollouts_per_gpu=rollouts_per_gpu, K=K, collective="ncclAllGather (RCCL)" if info[2] else "none (single process)",
                 rccl_ranks=info[1] if info[2] else 1, generations=laps)
 
 

@@ -91,6 +91,9 @@ int lmpc_config_default(lmpc_config *cfg);                       /* reference de
 int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out);         /* MPC/LMPC.__init__, :63-107, :293-338 */
 int lmpc_destroy(lmpc_ctx *ctx);
 const char *lmpc_last_error(void);
+const char *lmpc_active_knobs(void);                             /* developer environment variables this process has acted on ("NAME=value;..."; "" = none): LMPC_K1_QG,
+                                                                    LMPC_K1_RPL16, LMPC_MW_MAX_BATCH, LMPC_MW2_MAX_BATCH, LMPC_FUSE, LMPC_CD, LMPC_NO_ABG -- route / grid choices
+                                                                    with identical results, each announced once on stderr; no reference counterpart */
 int lmpc_version(void);
 
 /* ---- lap stores -------------------------------------------------------------------------------
@@ -181,7 +184,10 @@ int lmpc_rollout_run(lmpc_ctx *, int max_steps, int *steps_total, int *n_done);
 int lmpc_rollout_fetch(lmpc_ctx *, int t0, int t1, double *X /*(t1-t0) x B x 6*/, double *U /*.. x B x 2*/, double *Xglob,
                        int *doneAt /*B*/, int *status /*B*/, double *finalX /*B x 6*/, double *finalXglob /*B x 6*/);
 int lmpc_rollout_end(lmpc_ctx *);
-        /* Simulator.sim with one LMPC controller per rollout, SysModel.py:22-54, state resident on the device */
+        /* Simulator.sim with one LMPC controller per rollout, SysModel.py:22-54, state resident on the device.  The session's device buffers are kept for the next
+         * lap of the same shape (a generation loop begins one per lap); lmpc_rollout_release or lmpc_destroy frees them */
+int lmpc_rollout_release(lmpc_ctx *);
+        /* give the kept session buffers back (55 MB at 1024 rollouts x 400 steps) without destroying the context; not valid between begin and end.  No reference counterpart */
 int lmpc_ss_extend_lap(lmpc_ctx *, int lap, const double *x /*n x 6*/, const double *u /*n x 2*/, int n);
 /* Undo extensions: keep the first T rows of stored lap `lap` (LapTime <= T <= current rows).  rollout.LmpcGeneration rolls a failed
  * generation back with it, so that a generation either completes or leaves the safe set as it found it.  No reference counterpart. */
@@ -227,6 +233,14 @@ int lmpc_debug_set_trace(lmpc_ctx *, double *dev_rows /* max_batch x 48 x 6 doub
 int lmpc_debug_rollout_peek(lmpc_ctx *, double *xLin /*B x (N+1) x 6*/, double *uLin /*B x N x 2*/, int *status /*B*/, int *rstatus /*B x N*/);
         /* (every build) the rollout session's current linearisation trajectories -- the queries of the NEXT step's regression -- and the status words of the step
          * just taken; any pointer may be NULL.  tools/robustness_sweep.py captures the inputs of a flagged closed-loop regression with it */
+int lmpc_debug_rollout_capture(lmpc_ctx *, int on);
+        /* (every build) sessions begun after this call also keep the selected safe-set points / Q-values of the step just taken (B x S x 6, B x S): off by default,
+         * the rollout step then does not write them */
+int lmpc_debug_rollout_qp(lmpc_ctx *, int b0, int n, double *A, double *B, double *C, double *xPred, double *uPred, double *ssSel, double *qSel, double *succ, double *succU,
+                          double *lambda, double *ztNext, double *ztuNext, int *iters, int *status);
+        /* (every build) the QP the LAST simulated step solved for rollouts b0 .. b0 + n - 1: the regression's A, B, C, the kernel's answer (xPred, uPred, lambda, zt / zt_u),
+         * and (capture on) the selection with its successor rows -- what tests/closed_loop_probe.py hands to the oracle; x0 / uOld are rows t - 1 / t - 2 of the
+         * session's logs.  Any pointer may be NULL */
 int lmpc_debug_exec_audit(lmpc_ctx *, unsigned long long *out16, int reset);
         /* -DLMPC_EXEC_AUDIT: out16[site] = calls of a cross-lane primitive (DPP / permlane / bpermute reductions, MFMA stages) of the built-in
          * kernels that found an incomplete EXEC mask, out16[8 + site] = calls; sites are listed in csrc/lmpc_kernels.hip.h */

@@ -44,15 +44,15 @@ class StepDevArgs(C.Structure):
 
 
 EXPORTS = [
-    "lmpc_config_default", "lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_version",
+    "lmpc_config_default", "lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_active_knobs", "lmpc_version",
     "lmpc_model_add_trajectory", "lmpc_model_num_laps", "lmpc_model_replace_lap",
     "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun", "lmpc_ss_get_laptime",
     "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
     "lmpc_lti_regression", "lmpc_comm_unique_id", "lmpc_comm_init", "lmpc_comm_destroy", "lmpc_comm_info", "lmpc_comm_allgather_dev", "lmpc_comm_allgather",
     "lmpc_comm_allreduce_max", "lmpc_comm_barrier", "lmpc_rollout_exchange",
-    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_solver_waves", "lmpc_plant_step_batch", "lmpc_global_position_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_ss_extend_lap", "lmpc_ss_truncate_lap",
-    "lmpc_debug_set_trace", "lmpc_debug_exec_audit", "lmpc_debug_rollout_peek",
+    "lmpc_set_profiling", "lmpc_get_stats", "lmpc_reset_stats", "lmpc_selftest", "lmpc_solver_waves", "lmpc_plant_step_batch", "lmpc_global_position_batch", "lmpc_rollout_begin", "lmpc_rollout_run", "lmpc_rollout_fetch", "lmpc_rollout_end", "lmpc_rollout_release", "lmpc_ss_extend_lap", "lmpc_ss_truncate_lap",
+    "lmpc_debug_set_trace", "lmpc_debug_exec_audit", "lmpc_debug_rollout_peek", "lmpc_debug_rollout_capture", "lmpc_debug_rollout_qp",
 ]
 
 _lib = None
@@ -73,10 +73,17 @@ def load():
         for name in EXPORTS:
             getattr(lib, name)          # raises AttributeError if a declared symbol is missing
         lib.lmpc_last_error.restype = C.c_char_p
+        lib.lmpc_active_knobs.restype = C.c_char_p
         # (declared argument types let the hot call take plain integers as addresses: no c_void_p object per array)
         lib.lmpc_step_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 24
         _lib = lib
     return _lib
+
+
+def active_knobs():
+    """Developer environment variables the library has acted on in this process ([] = none): route / grid choices, results identical."""
+    v = load().lmpc_active_knobs().decode()
+    return v.split(";") if v else []
 
 
 def comm_unique_id():
@@ -376,6 +383,27 @@ class Context:
 
     def rollout_end(self):
         _chk(self.lib.lmpc_rollout_end(self._h))
+
+    def rollout_release(self):
+        """Free the device buffers a finished session keeps for the next lap (lmpc_rollout_release)."""
+        _chk(self.lib.lmpc_rollout_release(self._h))
+
+    def debug_rollout_capture(self, on=True):
+        """Sessions begun after this call keep the selected safe-set points of every step (lmpc_debug_rollout_capture)."""
+        _chk(self.lib.lmpc_debug_rollout_capture(self._h, C.c_int(1 if on else 0)))
+
+    def debug_rollout_qp(self, b0, n, selection=True):
+        """The QP of the last simulated step for rollouts b0 .. b0 + n - 1: dict(A, B, C, xPred, uPred, lam, ztNext, ztuNext, iters, status[, ssSel (n, S, 6), qSel, succ (n, S, 6),
+        succU (n, S, 2)]) -- lmpc_debug_rollout_qp."""
+        N, S = self.N, self.cfg.numSS_points
+        o = dict(A=np.zeros((n, N, 6, 6)), B=np.zeros((n, N, 6, 2)), C=np.zeros((n, N, 6)), xPred=np.zeros((n, N + 1, 6)), uPred=np.zeros((n, N, 2)), lam=np.zeros((n, S)),
+                 ztNext=np.zeros((n, 6)), ztuNext=np.zeros((n, 2)), iters=np.zeros(n, np.int32), status=np.zeros(n, np.int32))
+        if selection:
+            o.update(ssSel=np.zeros((n, S, 6)), qSel=np.zeros((n, S)), succ=np.zeros((n, S, 6)), succU=np.zeros((n, S, 2)))
+        g = lambda k: _d(o[k]) if k in o else None
+        _chk(self.lib.lmpc_debug_rollout_qp(self._h, C.c_int(int(b0)), C.c_int(int(n)), g("A"), g("B"), g("C"), g("xPred"), g("uPred"), g("ssSel"), g("qSel"), g("succ"), g("succU"),
+                                            g("lam"), g("ztNext"), g("ztuNext"), g("iters"), g("status")))
+        return o
 
     def ss_extend_lap(self, lap, x, u):
         x = _f64(x); u = _f64(u)

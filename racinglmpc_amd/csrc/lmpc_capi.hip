@@ -10,11 +10,28 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
 static thread_local std::string g_err;
 static int set_err(int code, const char *what, const char *detail) { g_err = std::string(what) + ": " + (detail ? detail : ""); return code; }
+// Developer knobs read from the environment (round 6, ADVICE r5: a stray variable must not change behaviour silently).  Every knob that is SET is recorded
+// here, announced once on stderr and listed by lmpc_active_knobs(); knobs that change RESULTS (LMPC_NO_RETRY) exist in developer flavours only.
+static std::mutex g_knob_mu;
+static std::string g_knobs;
+static const char *dev_knob(const char *name) {
+    const char *e = getenv(name);
+    if (e) {
+        std::lock_guard<std::mutex> lk(g_knob_mu);
+        const std::string item = std::string(name) + "=" + e;
+        if ((";" + g_knobs + ";").find(";" + item + ";") == std::string::npos) {
+            g_knobs += (g_knobs.empty() ? "" : ";") + item;
+            fprintf(stderr, "liblmpc_hip: developer knob %s is active\n", item.c_str());
+        }
+    }
+    return e;
+}
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(LMPC_E_HIP, #call, hipGetErrorString(e_)); } while (0)
 #define ARGCHK(cond) do { if (!(cond)) return set_err(LMPC_E_ARG, "argument check failed", #cond); } while (0)
 
@@ -93,6 +110,7 @@ struct lmpc_ctx {
     int *w_selStart;                         // lmpc_select_batch: window starts, max_batch x numSS_it
     void *scr_dev; size_t scr_bytes;         // pooled scratch of the small host-buffer entry points (plant step, global position)
     std::vector<char *> gaps;                // guard builds: the 256-byte zones between the work-buffer ranges of the slabs
+    int dbg_capture;                         // lmpc_debug_rollout_capture: rollout sessions also keep the selected safe-set points of the last step (parity probes of the closed loop)
     double *dbg_trace;                       // developer builds (-DLMPC_TRACE): device buffer of the per-iteration side channel, see lmpc_debug_set_trace
     double tr_s[4]; long long tr_n;          // developer trace of lmpc_step_batch's one-QP path (lmpc_debug_step_trace): seconds spent staging / launching / waiting / unstaging
     struct lmpc_rollout_session *ro;
@@ -143,6 +161,7 @@ static int pick_solver(lmpc_ctx *c) {
 extern "C" {
 
 const char *lmpc_last_error(void) { return g_err.c_str(); }
+const char *lmpc_active_knobs(void) { std::lock_guard<std::mutex> lk(g_knob_mu); static thread_local std::string copy; copy = g_knobs; return copy.c_str(); }
 int lmpc_version(void) { return 100; }
 
 int lmpc_config_default(lmpc_config *c) {
@@ -196,18 +215,18 @@ static int create_body(lmpc_ctx *c) {
     const lmpc_config *cfg = &c->cfg;
     HIPCHK(hipSetDevice(cfg->device));
     // an unsupported (N, numSS_points) pair is an ordinary user error: find that out before anything is allocated
-    c->k1_force16 = getenv("LMPC_K1_RPL16") != nullptr;
-    { const char *e = getenv("LMPC_K1_QG"); c->k1_qg_force = e ? atoi(e) : 0; }
+    c->k1_force16 = dev_knob("LMPC_K1_RPL16") != nullptr;
+    { const char *e = dev_knob("LMPC_K1_QG"); c->k1_qg_force = e ? atoi(e) : 0; }
     { const int rc = pick_solver(c); if (rc) return rc; }
     {   // batches that leave SIMDs idle (B <= number of CUs) run the 4-waves-per-QP kernel
-        const char *e = getenv("LMPC_MW_MAX_BATCH"); hipDeviceProp_t prop; int cus = 256;
+        const char *e = dev_knob("LMPC_MW_MAX_BATCH"); hipDeviceProp_t prop; int cus = 256;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         c->mw_max_batch = e ? atoi(e) : cus; c->n_cu = cus;
     }
     // a variant whose one-wave LDS footprint leaves room for ONE QP per CU only would keep three SIMDs idle at any batch size and runs four waves
     // per QP throughout.  None of the built-in horizons is in that class any more: N = 40 fits two QPs per CU with [A_k | B_k] in LDS (53.5 KB)
     // and four with it in global memory (38.2 KB, lmpc_variant.hip.h: use_abg), so N = 40 follows the ordinary rule below (one wave from batch 257)
-    if (!getenv("LMPC_MW_MAX_BATCH") && 2 * (c->var.lds_1w_abg ? c->var.lds_1w_abg : c->var.lds_1w) > 160 * 1024) c->mw_max_batch = 1 << 30;
+    if (!dev_knob("LMPC_MW_MAX_BATCH") && 2 * (c->var.lds_1w_abg ? c->var.lds_1w_abg : c->var.lds_1w) > 160 * 1024) c->mw_max_batch = 1 << 30;
     // Two waves per QP between the four-wave and the one-wave regime: how far up depends on the horizon -- the longer the horizon, the
     // larger the share of the Newton step that is sequential (the helper wave only waits) and the fewer QPs of the multi-wave LDS layout fit a
     // CU.  Measured (solve kernel, ms; two waves | one wave): N=12 B=1024 0.30 | 0.40, B=2048 (two rounds | one round) 0.56 | 0.47;  N=14 B=512 0.33 | 0.42, B=1024 0.48 | 0.44;
@@ -221,12 +240,12 @@ static int create_body(lmpc_ctx *c) {
     // solve kernel: 0.425 ms in two rounds against 0.349 ms; round 4 found it out the hard way -- 512 bytes more static LDS, three QPs per CU instead of four)
     if (c->var.occ_mw2 > 0 && c->mw2_max_batch > c->var.occ_mw2 * c->n_cu) c->mw2_max_batch = c->var.occ_mw2 * c->n_cu;
     if (c->var.lds_mw == 0) { c->mw_max_batch = 0; c->mw2_max_batch = 0; }        // (a variant without multi-wave kernels)
-    if (const char *e = getenv("LMPC_MW2_MAX_BATCH")) c->mw2_max_batch = atoi(e);        // (experiments)
+    if (const char *e = dev_knob("LMPC_MW2_MAX_BATCH")) c->mw2_max_batch = atoi(e);        // (experiments)
     // Fused step (regression inside the one-wave solve kernel): bit-identical results, 42 MB less HBM traffic per step at batch 4096, but
     // MEASURED SLOWER -- 1.37 vs 1.01 + 0.23 ms at batch 4096, 2.48 vs 1.81 + 0.44 ms at batch 8192 with six QPs per CU; 1.92 vs 1.45 + 0.41 ms
     // at batch 8192 with eight: the regression's short dependent chains (DPP minima, 5 x 5 Cholesky, scattered L2 reads) want the four waves
     // per SIMD its own kernel gets, the solve kernel runs two.  Off unless LMPC_FUSE=1.
-    { const char *e = getenv("LMPC_FUSE"); c->fuse_k1 = e ? atoi(e) : 0; }
+    { const char *e = dev_knob("LMPC_FUSE"); c->fuse_k1 = e ? atoi(e) : 0; }
     if (c->fuse_k1 && (size_t)(54 * cfg->N + k1_fused_doubles(cfg->N, cfg->trToUse, cfg->maxNumPoint)) * sizeof(double) > (size_t)160 * 1024) c->fuse_k1 = 0;   // (many laps: the regression's work space does not fit beside the solve)
     {   // condensed kernel (lmpc_solve_cd.hip.h): built for 2N <= 32 and one terminal-block column per lane; it takes the state cost as diagonal Q, Qf
         bool diag = true; c->cd_hasq = 0;
@@ -236,10 +255,10 @@ static int create_body(lmpc_ctx *c) {
             if (i == j && (cfg->Q[i * 6 + j] < 0.0 || cfg->Qf[i * 6 + j] < 0.0)) diag = false;
         }
         c->cd_ok = c->var.lds_cd > 0 && diag;
-        const char *e = getenv("LMPC_CD"); c->cd_mode = e ? atoi(e) : 0;
+        const char *e = dev_knob("LMPC_CD"); c->cd_mode = e ? atoi(e) : 0;
     }
     HIPCHK(hipStreamCreate(&c->stream));
-    if (c->var.lds_1w_abg > 0 && !getenv("LMPC_NO_ABG")) { HIPCHK(g_malloc(&c->ab_pack, sizeof(double) * 48 * (size_t)cfg->N * (size_t)cfg->max_batch)); c->ab_pack_cap = (size_t)cfg->max_batch; }
+    if (c->var.lds_1w_abg > 0 && !dev_knob("LMPC_NO_ABG")) { HIPCHK(g_malloc(&c->ab_pack, sizeof(double) * 48 * (size_t)cfg->N * (size_t)cfg->max_batch)); c->ab_pack_cap = (size_t)cfg->max_batch; }
     HIPCHK(hipHostMalloc(&c->h_retry, sizeof(int) * LMPC_RETRY_RING, hipHostMallocMapped));
     memset(c->h_retry, 0, sizeof(int) * LMPC_RETRY_RING);
     HIPCHK(hipHostGetDevicePointer((void **)&c->d_retry, c->h_retry, 0));
@@ -606,7 +625,11 @@ static int resolve_retries(lmpc_ctx *c) {
     if (c->pending.empty()) return LMPC_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     int rc = LMPC_OK, launched = 0;
-    static const bool no_retry = getenv("LMPC_NO_RETRY") != nullptr;     // (developer probe: leave the first pass's output as it is, tools/n40_probe.py)
+#if defined(LMPC_DEV_FAST) || defined(LMPC_TRACE) || defined(LMPC_TIMING)
+    static const bool no_retry = dev_knob("LMPC_NO_RETRY") != nullptr;     // (developer probe, developer flavours only: leave the first pass's output as it is, tools/n40_probe.py)
+#else
+    const bool no_retry = false;
+#endif
     for (auto &pe : c->pending) {
         if (no_retry || c->h_retry[pe.epoch % LMPC_RETRY_RING] != pe.epoch) continue;
         pe.io.retry_flag = nullptr;
@@ -651,14 +674,14 @@ static int launch_solve(lmpc_ctx *c, int B, const lmpc_solve_io &io_in, bool imm
     // waves per QP: 4 up to one QP per CU, 2 up to mw2_max_batch (four QPs per CU at N <= 12, see create_body), beyond that the one-wave
     // kernel, whose slim LDS layout keeps eight QPs resident per CU at N = 12
 #ifdef LMPC_DEV_FAST
-    if (const char *f = getenv("LMPC_FORCE_NW")) {
+    if (const char *f = dev_knob("LMPC_FORCE_NW")) {
         const int nw = atoi(f);
         rc = nw == 4 ? c->var.launch_mw4(c->stream, c->dp, B, io) : nw == 2 ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     } else
 #endif
     rc = (c->cd_ok && c->cd_mode == 1 && !(io.mode & 4)) ? c->var.launch_cd(c->stream, c->dp, B, io, c->cd_hasq)
        : (io.mode & 4) ? c->var.launch_1w(c->stream, c->dp, B, io)        // fused step: the one-wave kernel runs the regression itself
-       : (B <= c->mw_max_batch && (!timing_buf || getenv("LMPC_TIMING_MW"))) ? c->var.launch_mw4(c->stream, c->dp, B, io)
+       : (B <= c->mw_max_batch && (!timing_buf || dev_knob("LMPC_TIMING_MW"))) ? c->var.launch_mw4(c->stream, c->dp, B, io)
        : (lmpc_solver_waves(c, B) == 2 && !timing_buf) ? c->var.launch_mw2(c->stream, c->dp, B, io) : c->var.launch_1w(c->stream, c->dp, B, io);
     ev_end(c);
     if (rc) return rc;
@@ -983,6 +1006,7 @@ struct lmpc_rollout_session {
     double *d_x, *d_xg, *d_xLin, *d_uLin, *d_uOld, *d_zt, *d_xPP, *d_xPred, *d_uPred, *d_slack, *d_lam, *d_sT, *d_ztN, *d_ztuN, *d_A, *d_B, *d_C, *d_resid;
     double *d_logX, *d_logU, *d_logG, *d_noise, *d_finX, *d_finG;
     int *d_hasPred, *d_tstep, *d_done, *d_nDone, *d_stAcc, *d_status, *d_iters, *d_rst;
+    double *d_ssSel, *d_qSel, *d_succ, *d_succU;                // only with lmpc_debug_rollout_capture on (else null: the step does not write them)
 };
 
 static void rollout_free(lmpc_ctx *c) {
@@ -1001,7 +1025,7 @@ int lmpc_rollout_begin(lmpc_ctx *c, int B, int T_max, const double *x0, const do
     // A generation loop begins a session of the same shape every lap: its ~35 device buffers (55 MB of logs at 1024 rollouts x 400 steps), the plant stream and
     // the two events are kept from one session to the next (round 5: allocating and freeing them was ~5 ms of every generation) and released by
     // lmpc_destroy or by a session of another shape.
-    if (c->ro && !c->ro->active && c->ro->B == B && c->ro->T_max == T_max) {
+    if (c->ro && !c->ro->active && c->ro->B == B && c->ro->T_max == T_max && (c->ro->d_ssSel != nullptr) == (c->dbg_capture != 0)) {
         lmpc_rollout_session *r = c->ro; r->t = 0; r->active = true;
         goto init_state;
     }
@@ -1017,6 +1041,8 @@ int lmpc_rollout_begin(lmpc_ctx *c, int B, int T_max, const double *x0, const do
     DA(double, d_xPred, Bz * (N + 1) * 6) DA(double, d_uPred, Bz * N * 2) DA(double, d_slack, Bz * N * 2) DA(double, d_lam, Bz * S) DA(double, d_sT, Bz * 6)
     DA(double, d_ztN, Bz * 6) DA(double, d_ztuN, Bz * 2) DA(double, d_A, Bz * N * 36) DA(double, d_B, Bz * N * 12) DA(double, d_C, Bz * N * 6)
     DA(double, d_resid, Bz * 3) DA(int, d_status, Bz) DA(int, d_iters, Bz) DA(int, d_rst, Bz * N) DA(double, d_finX, Bz * 6) DA(double, d_finG, Bz * 6)
+    r->d_ssSel = nullptr; r->d_qSel = nullptr; r->d_succ = nullptr; r->d_succU = nullptr;
+    if (c->dbg_capture) { DA(double, d_ssSel, Bz * S * 6) DA(double, d_qSel, Bz * S) DA(double, d_succ, Bz * S * 6) DA(double, d_succU, Bz * S * 2) }
     DA(double, d_logX, (size_t)T_max * Bz * 6) DA(double, d_logU, (size_t)T_max * Bz * 2) DA(double, d_logG, (size_t)T_max * Bz * 6) DA(double, d_noise, (size_t)T_max * Bz * 3)
 #undef DA
     if (!ok) { rollout_free(c); return set_err(LMPC_E_HIP, "hipMalloc", "rollout buffers"); }
@@ -1032,6 +1058,12 @@ init_state:
     HIPCHK(hipMemsetAsync(r->d_hasPred, 0, sizeof(int) * Bz, c->stream)); HIPCHK(hipMemsetAsync(r->d_tstep, 0, sizeof(int) * Bz, c->stream));
     HIPCHK(hipMemsetAsync(r->d_nDone, 0, sizeof(int), c->stream)); HIPCHK(hipMemsetAsync(r->d_stAcc, 0, sizeof(int) * Bz, c->stream));
     HIPCHK(hipMemsetAsync(r->d_finX, 0, sizeof(double) * Bz * 6, c->stream)); HIPCHK(hipMemsetAsync(r->d_finG, 0, sizeof(double) * Bz * 6, c->stream));
+    // a reused session is indistinguishable from a fresh one: what the previous lap left in the solver's outputs and status words goes too
+    HIPCHK(hipMemsetAsync(r->d_xPred, 0, sizeof(double) * Bz * (N + 1) * 6, c->stream)); HIPCHK(hipMemsetAsync(r->d_uPred, 0, sizeof(double) * Bz * N * 2, c->stream));
+    HIPCHK(hipMemsetAsync(r->d_lam, 0, sizeof(double) * Bz * S, c->stream)); HIPCHK(hipMemsetAsync(r->d_sT, 0, sizeof(double) * Bz * 6, c->stream));
+    HIPCHK(hipMemsetAsync(r->d_ztN, 0, sizeof(double) * Bz * 6, c->stream)); HIPCHK(hipMemsetAsync(r->d_ztuN, 0, sizeof(double) * Bz * 2, c->stream));
+    HIPCHK(hipMemsetAsync(r->d_status, 0, sizeof(int) * Bz, c->stream)); HIPCHK(hipMemsetAsync(r->d_iters, 0, sizeof(int) * Bz, c->stream));
+    HIPCHK(hipMemsetAsync(r->d_rst, 0, sizeof(int) * Bz * N, c->stream)); HIPCHK(hipMemsetAsync(r->d_resid, 0, sizeof(double) * Bz * 3, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return LMPC_OK;
 }
@@ -1059,6 +1091,7 @@ int lmpc_rollout_run(lmpc_ctx *c, int max_steps, int *steps_total, int *n_done) 
         io.mode = 3; io.A = r->d_A; io.Bm = r->d_B; io.C = r->d_C; io.x0 = r->d_x; io.uOld = r->d_uOld; io.zt = r->d_zt; io.xPredPrev = r->d_xPP; io.hasPred = r->d_hasPred;
         io.timeStep = r->d_tstep; io.xPred = r->d_xPred; io.uPred = r->d_uPred; io.slack = r->d_slack; io.lambda = r->d_lam; io.sTerm = r->d_sT; io.ztNext = r->d_ztN;
         io.ztuNext = r->d_ztuN; io.resid = r->d_resid; io.status = r->d_status; io.iters = r->d_iters; io.rstatus = r->d_rst;
+        io.ssSelOut = r->d_ssSel; io.qSelOut = r->d_qSel; io.succOut = r->d_succ; io.succUOut = r->d_succU;
         if (r->t > 0) HIPCHK(hipStreamWaitEvent(c->stream, r->e_plant, 0));          // the solve needs the plant's new state
         rc = launch_solve(c, B, io, true); if (rc) return rc;      // (the plant consumes uPred without a host round trip: unconditional retry pass)
         HIPCHK(hipEventRecord(r->e_solved, c->stream));
@@ -1103,6 +1136,32 @@ int lmpc_debug_rollout_peek(lmpc_ctx *c, double *xLin, double *uLin, int *status
     return LMPC_OK;
 }
 
+int lmpc_debug_rollout_capture(lmpc_ctx *c, int on) {
+    // developer entry point: rollout sessions begun after this call also write the selected safe-set points / Q-values of every step (B x S x 6, B x S) so that
+    // lmpc_debug_rollout_qp can hand a closed-loop QP to the oracle.  Off (the default) the step does not write them.
+    ARGCHK(c && !(c->ro && c->ro->active));
+    c->dbg_capture = on ? 1 : 0;
+    return LMPC_OK;
+}
+
+int lmpc_debug_rollout_qp(lmpc_ctx *c, int b0, int n, double *A, double *Bm, double *Cm, double *xPred, double *uPred, double *ssSel, double *qSel, double *succ, double *succU,
+                          double *lambda, double *ztNext, double *ztuNext, int *iters, int *status) {
+    // developer entry point: the QP the LAST simulated step solved for rollouts b0 .. b0 + n - 1 -- the regression's A, B, C (n x N x 36 / 12 / 6), the kernel's
+    // answer (n x (N+1) x 6, n x N x 2, n x S; zt / zt_u of feasibleStateInput: n x 6, n x 2), iterations and status, and (capture on) the selected safe-set points, their
+    // Q-values and successors (n x S x 6, n x S, n x S x 6, n x S x 2).  Its x0 / uOld are rows t - 1 / t - 2 of the session's logs (lmpc_rollout_fetch).  Meant to be
+    // called between lmpc_rollout_run(ctx, 1, ..) calls; any pointer may be NULL.
+    ARGCHK(c && c->ro && c->ro->active && c->ro->t >= 1 && b0 >= 0 && n >= 1 && b0 + n <= c->ro->B && ((!ssSel && !qSel && !succ && !succU) || c->ro->d_ssSel));
+    lmpc_rollout_session *r = c->ro; const size_t N = c->cfg.N, S = c->cfg.numSS_points, o = b0, nz = n;
+    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(r->pstream)); HIPCHK(hipStreamSynchronize(c->stream));
+    D2H(A, r->d_A + o * N * 36, nz * N * 36); D2H(Bm, r->d_B + o * N * 12, nz * N * 12); D2H(Cm, r->d_C + o * N * 6, nz * N * 6);
+    D2H(xPred, r->d_xPred + o * (N + 1) * 6, nz * (N + 1) * 6); D2H(uPred, r->d_uPred + o * N * 2, nz * N * 2); D2H(lambda, r->d_lam + o * S, nz * S);
+    D2H(ztNext, r->d_ztN + o * 6, nz * 6); D2H(ztuNext, r->d_ztuN + o * 2, nz * 2);
+    D2H(ssSel, r->d_ssSel + o * S * 6, nz * S * 6); D2H(qSel, r->d_qSel + o * S, nz * S); D2H(succ, r->d_succ + o * S * 6, nz * S * 6); D2H(succU, r->d_succU + o * S * 2, nz * S * 2);
+    D2H(iters, r->d_iters + o, nz); D2H(status, r->d_status + o, nz);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LMPC_OK;
+}
+
 int lmpc_rollout_end(lmpc_ctx *c) {
     ARGCHK(c); HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
     if (c->ro) {
@@ -1113,6 +1172,15 @@ int lmpc_rollout_end(lmpc_ctx *c) {
         c->ro->active = false;
 #endif
     }
+    return LMPC_OK;
+}
+
+int lmpc_rollout_release(lmpc_ctx *c) {
+    // lmpc_rollout_end keeps the session's device buffers (~35 allocations, 55 MB at 1024 rollouts x 400 steps), its stream and events for the next lap of the same
+    // shape; this gives them back without destroying the context.  Not valid inside a session.
+    ARGCHK(c && !(c->ro && c->ro->active));
+    HIPCHK(hipSetDevice(c->cfg.device)); HIPCHK(hipStreamSynchronize(c->stream));
+    rollout_free(c);
     return LMPC_OK;
 }
 

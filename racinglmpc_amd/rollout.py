@@ -65,6 +65,19 @@ class BatchedRollouts:
         self._pre = (key, self.rng.bit_generator.state, self._pool.submit(draw))
         return noise
 
+    def close(self):
+        """End of a generation loop: wait for the prefetched draw nobody will use, give its draws back (the generator state from before that draw is restored, so
+        `rng` is where a run without prefetching leaves it) and shut the worker thread down.  Between begin() calls `rng` belongs to the prefetcher: the worker
+        thread is drawing from it -- do not touch it from the caller's thread before close()."""
+        if self._pre is not None:
+            _, state, fut = self._pre
+            self._pre = None
+            fut.result()
+            self.rng.bit_generator.state = state
+        pool = self.__dict__.pop("_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=True)
+
     def prefetch_noise(self, max_steps, B, wait=False):
         """Draw the plant noise of the first lap ahead of time (worker thread; same draws, same order as without the call): the synthetic disturbance is input
         data of a closed-loop run, and 1.2 M normal draws are 15-20 ms of host time that would otherwise open the first lap."""
@@ -131,6 +144,24 @@ class LmpcGeneration:
         self.last_status = self.last_done = None
         self.skipped_extensions = []   # [(k, status bits)]: stored laps NOT extended in the last generation because the continuing rollout was flagged
         self.open_laps = set()         # stored laps that end at the finish line for good (their extension was skipped): kept out of the safe-set selection
+        self.step_hook = None          # developer / test hook: called as step_hook(t) after every simulated step (the lap is then advanced one step per call:
+                                       # tests/test_gpu_closed_loop.py samples the session's QPs through Context.debug_rollout_qp)
+
+    def _advance(self, n):
+        """ctx.rollout_run(n) -- or, with a step hook, n single steps with the hook in between (stops when every rollout has finished, as rollout_run does)."""
+        ctx = self.ro.ctx
+        if self.step_hook is None:
+            return ctx.rollout_run(n)
+        t_end = min(self.T_max, ctx._ro_t + n)
+        while True:
+            t, nd = ctx.rollout_run(1)
+            self.step_hook(t)
+            if nd >= self.hi - self.lo or t >= t_end:
+                return t, nd
+
+    def close(self):
+        """After the last run(): BatchedRollouts.close() (prefetched noise returned to the generator, worker thread ended)."""
+        self.ro.close()
 
     def prepare(self, wait=True):
         """Optional, before the first run(): the first lap's plant noise is drawn now (BatchedRollouts.prefetch_noise) instead of inside the lap."""
@@ -162,7 +193,7 @@ class LmpcGeneration:
                 # Each row is taken from the rank whose shard holds rollout k, together with that rollout's accumulated status bits: a row of a
                 # flagged rollout (anything but INEXACT) or a non-finite row never reaches a lap store -- decided from the gathered data, hence
                 # identically on every rank.
-                t, _ = ctx.rollout_run(ext)
+                t, _ = self._advance(ext)
                 X, U, G, done, st, fx, fg = ctx.rollout_fetch(0, t)
                 n = min(t, ext)
                 buf = np.zeros((K, ext, 9)); mask = np.zeros(K, dtype=np.int64)
@@ -188,7 +219,7 @@ class LmpcGeneration:
                 # decided from the gathered rows, hence identically on every rank.
                 self.open_laps |= {self.parents[k][4] for k, _ in self.skipped_extensions} | {self.parents[k][4] for k in range(K) if nmin <= 0 or not owned[k]}
                 self._apply_selection()
-            ctx.rollout_run(self.T_max)
+            self._advance(self.T_max)
             _, _, _, self.last_done, self.last_status, _, _ = ctx.rollout_fetch(0, 0)     # per-rollout finish step / accumulated status bits
             t0 = time.perf_counter()
             # The device-packed exchange needs the context's own RCCL communicator spanning the same world as `comm` (or a single process);

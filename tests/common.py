@@ -190,3 +190,14 @@ def run_golden_step_check(max_records=None, dev_every=0):
         ctx.close()
     return dict(max_err_xu=float(np.max(errs)), max_err_sssel=float(np.max(zerr)), max_err_zt=float(np.max(zterr)), n=len(errs), status=np.array(stats),
                 iters_mean=float(np.mean(iters)), iters_max=int(np.max(iters)), n_dev=len(ndev))
+
+
+def synthetic_inputs(g, N, B):
+    """The synthetic batch of BASELINE configs[4] and of the other-horizon tests (x0 around rows of the PID lap, linearisation = the rows that follow): what
+    tests/test_gpu_certificates.py::test_other_horizons_certificate, bench.py's config_N40 and tools/n40_model.py use.  (round 6: lived in tools/n40_model.py.)"""
+    xP, uP = np.array(g["xPID"]), np.array(g["uPID"])
+    tb = (37 * np.arange(B)) % 900
+    rng = np.random.default_rng(1234)
+    return dict(x0=xP[tb] + rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02]),
+                xLin=np.stack([xP[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uP[t + 1:t + N + 1] for t in tb]),
+                uOld=uP[tb].copy(), zt=xP[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))

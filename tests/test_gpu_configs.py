@@ -433,7 +433,7 @@ def test_n40_every_problem_against_oracle(built):
     from oracle import lmpc_oracle as orc
     from racinglmpc_amd import _capi
     from tests import oracle_pool
-    from tools.n40_model import inputs
+    inputs = common.synthetic_inputs
     g = common.load_lmpc_golden()
     pt = np.array(g["track"]); TL = float(g["trackLength"]); N, B = 40, 1024
     par = orc.QPParams.lmpc_default(N)

@@ -1,7 +1,8 @@
 """Developer tool (GPU box): the reference's 40-lap experiment on the drop-in classes; every `stride`-th closed-loop QP -- real LMPC laps in the safe set,
 lane slacks active in the fast laps -- is solved again by the oracle from the kernel's own A, B, C and selection (both restated on the explicit QP of the
 reference, oracle.assemble_lmpc_qp) to its certified optimum, and (x, u) compared.     python tools/closed_loop_oracle_probe.py [seed] [stride] [laps] [N]
-(tests/test_gpu_closed_loop.py runs probe() on the first laps.)"""
+       python tools/closed_loop_oracle_probe.py rollouts [seed] [N] [rollouts] [generations] [per_step]      # the batched-rollout route (two waves per QP at 257..1024 rollouts)
+(The probe itself is test infrastructure: tests/closed_loop_probe.py; tests/test_gpu_closed_loop.py runs it.)"""
 import os
 import sys
 
@@ -9,61 +10,20 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-
-
-def _work(args):
-    r, NH, fast = args
-    from oracle import lmpc_oracle as orc
-    par = orc.QPParams.lmpc_default(NH)
-    P, q, Ao, l, u = orc.assemble_lmpc_qp(par, r["A"], r["B"], r["C"], r["x0"], r["uOld"], r["SS"], r["Qsel"])
-    n = r["xu"].shape[0]
-    r2 = orc.dense_ipm_solve(P, q, Ao, l, u)                  # the oracle's dense interior-point solver on the explicit QP, certified by the solver-independent KKT check
-    c2 = max(orc.kkt_certificate(P, q, Ao, l, u, r2.x, r2.y).values())
-    opts = [r2.x]; cert = c2
-    if not fast:                                              # ... and the restated ADMM + polish (up to 20 s on the near-degenerate QPs of the first laps): on a flat QP --
-        ex, cert1 = orc.osqp_solve_exact(P, q, Ao, l, u, want=1e-8)      # error = 660 x residual on one of these -- either answer can itself be 1e-6 off; the kernel is compared
-        opts.append(ex.x); cert = max(cert, cert1)                     # with the nearer one, as in the tests
-    return min(float((np.abs(r["xu"] - o[:n]) / (1 + np.abs(o[:n]))).max()) for o in opts), float(cert)
-
-
-def probe(seed=5, stride=10, laps=40, NH=14, fast=False):
-    """Returns (records, err, cert, out): the sampled QPs (inputs, the kernel's (x, u), iterations, lap), their scaled distance to the nearer oracle optimum, the
-    oracle's certificates, the per-lap records of closed_loop.run_laps."""
-    from tests import closed_loop, common
-    g = common.load_lmpc_golden()
-    flow = closed_loop.DropinFlow(g, NH)
-    rec = []; cnt = [0]; state = dict(lap=0)
-    inner = flow.solve
-
-    def solve(x):
-        u, st, it = inner(x)
-        if cnt[0] % stride == 0:
-            o = flow.ctrl._out
-            rec.append(dict(A=o["A"][0].copy(), B=o["B"][0].copy(), C=o["C"][0].copy(), x0=np.array(x, float), uOld=flow._uOld_before.copy(), SS=np.ascontiguousarray(o["ssSel"][0].T),
-                            Qsel=o["qSel"][0].copy(), xu=np.concatenate([o["xPred"][0].ravel(), o["uPred"][0].ravel()]), it=it, lap=state["lap"], st=st))
-        cnt[0] += 1
-        return u, st, it
-    flow.solve = solve
-
-    def on_lap(r):
-        state["lap"] += 1
-    out = closed_loop.run_laps(flow, g, laps, seed=seed, on_lap=on_lap)
-    import multiprocessing as mp
-    try:
-        from threadpoolctl import threadpool_limits
-        lim = threadpool_limits(1)                     # (inherited by the forked children: one BLAS thread per process -- 64 processes x 256 BLAS threads each took minutes)
-    except Exception:                                 # noqa: BLE001
-        lim = None
-    try:
-        with mp.get_context("fork").Pool(max(1, min(64, (os.cpu_count() or 2) - 2, len(rec)))) as pool:          # (children never touch HIP: NumPy only)
-            res = pool.map(_work, [(r, NH, fast) for r in rec], chunksize=1)
-    finally:
-        if lim is not None and hasattr(lim, "restore_original_limits"):
-            lim.restore_original_limits()
-    return rec, np.array([a for a, _ in res]), np.array([c for _, c in res]), out, cnt[0]
+from tests.closed_loop_probe import probe, rollout_probe          # noqa: E402,F401
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rollouts":
+        a = [int(v) for v in sys.argv[2:]]
+        seed, NH, R, G, P = (a + [5, 12, 1024, 3, 4][len(a):])[:5]
+        rec, err, cert, waves, itmax, bits = rollout_probe(seed, NH, R, G, P)
+        lap = np.array([r["lap"] for r in rec]); w = int(np.argmax(err))
+        print("N = %d, seed %d, %d rollouts x %d generations (%d waves per QP): %d QPs sampled; iterations max %d (all QPs), status bits %#x" % (NH, seed, R, G, waves, len(rec), itmax, bits))
+        print("worst |xu - z*| / (1 + |z*|) %.2e (generation %d, step %d, %d iterations), oracle certificates <= %.1e; by generation: %s; n > 3e-7: %d" % (
+            err.max(), rec[w]["lap"], rec[w]["t"], rec[w]["it"], cert.max(), [float("%.2e" % err[lap == k].max()) for k in range(G) if (lap == k).any()], int((err > 3e-7).sum())))
+        ezt = np.array([r["ezt"] for r in rec]); print("worst |zt - Succ lambda*| / (1 + |zt|) where lambda* is determinate %.2e (%d QPs with more than one optimal lambda)" % (ezt.max(), sum(r["indet"] for r in rec)))
+        sys.exit(0)
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     stride = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     laps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
@@ -71,8 +31,9 @@ if __name__ == "__main__":
     rec, err, cert, out, n = probe(seed, stride, laps, NH)
     lap = np.array([r["lap"] for r in rec]); w = int(np.argmax(err))
     print("N = %d, seed %d: %d laps, %d QPs, %d sampled; last lap %d steps" % (NH, seed, len(out), n, len(rec), out[-1]["steps"]))
-    print("worst |xu - z*| / (1 + |z*|) %.2e (lap %d, %d iterations), oracle certificates <= %.1e; by lap thirds: %s; n > 5e-7: %d" % (
-        err.max(), rec[w]["lap"], rec[w]["it"], cert.max(), [float("%.2e" % err[(lap >= a) & (lap < b)].max()) for a, b in ((0, 13), (13, 27), (27, 99))], int((err > 5e-7).sum())))
+    print("worst |xu - z*| / (1 + |z*|) %.2e (lap %d, %d iterations), oracle certificates <= %.1e; by lap thirds: %s; n > 3e-7: %d" % (
+        err.max(), rec[w]["lap"], rec[w]["it"], cert.max(), [float("%.2e" % err[(lap >= a) & (lap < b)].max()) for a, b in ((0, 13), (13, 27), (27, 99))], int((err > 3e-7).sum())))
+    ezt = np.array([r["ezt"] for r in rec]); print("worst |zt - Succ lambda*| / (1 + |zt|) where lambda* is determinate %.2e (%d QPs with more than one optimal lambda)" % (ezt.max(), sum(r["indet"] for r in rec)))
     bad = np.argsort(-err)[:6]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.savez_compressed(os.path.join(ROOT, "gpurun_out", "closed_loop_probe_worst_N%d_seed%d.npz" % (NH, seed)), err=err[bad],

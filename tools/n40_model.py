@@ -19,12 +19,8 @@ OUT = os.path.join(ROOT, "build_tmp", "n40_set.npz")
 
 
 def inputs(g, N, B):
-    xP, uP = np.array(g["xPID"]), np.array(g["uPID"])
-    tb = (37 * np.arange(B)) % 900
-    rng = np.random.default_rng(1234)
-    return dict(x0=xP[tb] + rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02]),
-                xLin=np.stack([xP[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uP[t + 1:t + N + 1] for t in tb]),
-                uOld=uP[tb].copy(), zt=xP[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
+    from tests import common
+    return common.synthetic_inputs(g, N, B)
 
 
 def build(N=40, B=1024):
