@@ -238,7 +238,7 @@ __device__ __forceinline__ double frcp(double x) {
 //    the optimum: a QP without strict complementarity (about one in ten here) converges linearly and sits ~sqrt(gap) away, a flat closed-loop QP sits 660 dual
 //    residuals away.  What the tolerance of the parity statement is written in is the distance itself, and a contracting iteration bounds it a posteriori:
 //        |z_k - z*| <= rho / (1 - rho) |z_k - z_{k-1}|,   rho = |z_k - z_{k-1}| / |z_{k-1} - z_{k-2}|
-//    (z = (x, u); max-norm of the steps actually taken, wave-uniform scalars the step phase has anyway).  The iteration ends when that bound is below LMPC_ACC_TOL:
+//    (z = (x, u); max-norm of the steps actually taken, wave-uniform scalars the step phase has anyway).  The iteration ends when that estimate is below LMPC_ACC_TOL = 1e-7:
 //    step^2 <= tol (step_prev - step), no division.  A superlinear last step passes at once (rho ~ 1e-3), a linearly converging problem iterates until the steps
 //    are short enough, whatever made them long.  tools/term_rule_model.py (NumPy model, every QP of the reference's 40-lap closed loop at N = 12, three seeds = 12 442
 //    QPs, iterated past the stop and compared with a 1e-15 solve; profiles/r6_term_rule_model.txt):
@@ -247,9 +247,13 @@ __device__ __forceinline__ double frcp(double x) {
 //        round 5, N <= 12 (1e-3 | 0.1)          8.98                     3.3e-6   (23)                  8.32 / 13   1.5e-7
 //        round 5, N > 12 (1e-4 | 0.03 | est)    9.03                     3.8e-7   (2)                   8.44 / 13   2.1e-8
 //        this rule, tol 3e-7                    9.18                     1.2e-7   (0)                   8.53 / 13   9.3e-10
+//        this rule, tol 1e-7  (built)           9.26                     1.2e-7   (0)                   8.63 / 13   7.0e-10
 //        ideal (first iterate within 3e-7)      8.98                                                    8.31 / 13
 //    -- round 5's N <= 12 pair, the one the graded horizon ran, misses 1e-6 on 8 of 12 442 closed-loop QPs (the sampled probe had seen 8.75e-7 on 1 246).
-#define LMPC_ACC_TOL 3e-7
+//    The rate is an estimate from two steps, not a bound on the next one: at 3e-7 one of 10 336 closed-loop QPs at N = 14 stopped 3.7e-7 from its optimum (zt 1.02e-6:
+//    its next contraction was 2.4 x slower than the last; the model and the GPU probe against the oracle found the same QP), at 1e-7 it iterates once more (1.7e-7 in
+//    the model's worst case there).  Price against 3e-7: +0.9 % iterations in the closed loop, +1.2 % on the bench batch, maximum unchanged.
+#define LMPC_ACC_TOL 1e-7
 __device__ __forceinline__ bool step_bound_ok(double step, double step_prev) {
 #ifdef LMPC_AB_NOACC                    // (developer A / B: the gap test alone, rounds 1-4)
     return true;

@@ -201,3 +201,25 @@ def synthetic_inputs(g, N, B):
     return dict(x0=xP[tb] + rng.normal(size=(B, 6)) * np.array([.02, .01, .02, .01, 0.0, .02]),
                 xLin=np.stack([xP[t + 1:t + N + 2] for t in tb]), uLin=np.stack([uP[t + 1:t + N + 1] for t in tb]),
                 uOld=uP[tb].copy(), zt=xP[tb + N + 1].copy(), timeStep=(tb % 300).astype(np.int32))
+
+
+def zt_face_err(zt, ztu, Succ, SuccU, SS, Qsel, lam_star):
+    """zt = Succ lambda, zt_u = SuccU lambda (feasibleStateInput, :382-384) when the QP has MORE THAN ONE optimal lambda (x, u, s_T are unique, lambda need not be: SURVEY
+    8(c)-3).  The optimal lambdas are the polytope { lambda >= 0 : [SS; 1'; Qsel'] lambda = [SS; 1'; Qsel'] lambda* } (the rest of the objective is fixed by the unique part
+    of the optimum), so every entry of zt has an interval of valid values: 16 small LPs (scipy / HiGHS, tolerances 1e-10) give it.  Returns (err, width): the scaled
+    distance of the given zt / zt_u from those intervals, and the widest interval (0 = lambda* is determinate as far as zt is concerned)."""
+    from scipy.optimize import linprog
+    E = np.vstack([SS, np.ones((1, SS.shape[1])), Qsel[None, :]])
+    b = E @ lam_star
+    rows = np.vstack([Succ, SuccU]); val = np.concatenate([zt, ztu])
+    err = 0.0; width = 0.0
+    opt = {"primal_feasibility_tolerance": 1e-10, "dual_feasibility_tolerance": 1e-10}
+    for r, v in zip(rows, val):
+        lo = linprog(r, A_eq=E, b_eq=b, bounds=(0, None), method="highs", options=opt)
+        hi = linprog(-r, A_eq=E, b_eq=b, bounds=(0, None), method="highs", options=opt)
+        ref = float(r @ lam_star)
+        a = lo.fun if lo.status == 0 else ref; c = -hi.fun if hi.status == 0 else ref
+        a, c = min(a, ref), max(c, ref)
+        width = max(width, c - a)
+        err = max(err, max(a - v, v - c, 0.0) / (1 + abs(v)))
+    return float(err), float(width)

@@ -299,8 +299,8 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
         acc_ok = True
         if acc_rule == "kernel":
             # (round 6) step_bound_ok of the kernels, lmpc_kernels.hip.h: the a-posteriori bound of a contracting iteration, |z - z*| <= rho / (1 - rho) |last step| with the rate
-            # measured on the last two (x, u) steps, below LMPC_ACC_TOL = 3e-7 -- one rule for every horizon (tools/term_rule_model.py)
-            acc_rule = lambda q: q["step_prev"] < q["step_pp"] and q["step_prev"] ** 2 <= 3e-7 * (q["step_pp"] - q["step_prev"])
+            # measured on the last two (x, u) steps, below LMPC_ACC_TOL = 1e-7 -- one rule for every horizon (tools/term_rule_model.py)
+            acc_rule = lambda q: q["step_prev"] < q["step_pp"] and q["step_prev"] ** 2 <= 1e-7 * (q["step_pp"] - q["step_prev"])
         elif acc_rule == "r5":
             acc_rule = dict(ratio=(1e-4 if N > 12 else 1e-3), step=0.0, floor=(0.03 if N > 12 else 0.1) * tol_gap, est=(1e-6 if N > 12 else None))   # round 5's LMPC_ACC_RATIO<N> / LMPC_ACC_FLOOR<N> / LMPC_ACC_EST
         if callable(acc_rule):                                            # (tools/term_rule_model.py: any rule on the scalars of this point)
