@@ -89,6 +89,13 @@ typedef struct {
 
 int lmpc_config_default(lmpc_config *cfg);                       /* reference defaults, N = 12 */
 int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out);         /* MPC/LMPC.__init__, :63-107, :293-338 */
+int lmpc_create_ex(const lmpc_config *cfg, unsigned flags, lmpc_ctx **out);
+        /* lmpc_create with flags.  LMPC_CREATE_RUNTIME_KERNEL: an (N, numSS_points) pair that is neither built in nor available as a variant library is served by
+         * the runtime-(N, S) solve kernel (any horizon without a compiler on the box, several times slower) instead of LMPC_E_VARIANT -- MPCParams.N is a plain
+         * parameter in the reference (:63-107, main.py:43).  LMPC_CREATE_FORCE_RUNTIME_KERNEL: use that kernel even where a fast one exists (tests) */
+#define LMPC_CREATE_RUNTIME_KERNEL 1u
+#define LMPC_CREATE_FORCE_RUNTIME_KERNEL 2u
+int lmpc_solver_kind(lmpc_ctx *);                                /* 0: built-in solve kernels, 1: variant library, 2: runtime-(N, S) kernel */
 int lmpc_destroy(lmpc_ctx *ctx);
 const char *lmpc_last_error(void);
 const char *lmpc_active_knobs(void);                             /* developer environment variables this process has acted on ("NAME=value;..."; "" = none): LMPC_K1_QG,

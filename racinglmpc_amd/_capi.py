@@ -5,6 +5,8 @@ without a working HIP device, raises -- there is no CPU fallback.
 """
 import ctypes as C
 import os
+import subprocess
+import warnings
 
 import numpy as np
 
@@ -15,6 +17,7 @@ MAX_TRACK_ROWS = 16
 MAX_USED_LAPS = 32
 COMM_ID_BYTES = 128
 E_VARIANT = -5
+CREATE_RUNTIME_KERNEL, CREATE_FORCE_RUNTIME_KERNEL = 1, 2
 
 ST_MAXITER, ST_REG_SINGULAR, ST_NO_SEGMENT, ST_WINDOW, ST_NUMERIC, ST_NOT_INTERIOR, ST_INEXACT, ST_INFEASIBLE = 1, 2, 4, 8, 16, 32, 64, 128
 
@@ -44,7 +47,7 @@ class StepDevArgs(C.Structure):
 
 
 EXPORTS = [
-    "lmpc_config_default", "lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_active_knobs", "lmpc_version",
+    "lmpc_config_default", "lmpc_create", "lmpc_create_ex", "lmpc_solver_kind", "lmpc_destroy", "lmpc_last_error", "lmpc_active_knobs", "lmpc_version",
     "lmpc_model_add_trajectory", "lmpc_model_num_laps", "lmpc_model_replace_lap",
     "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun", "lmpc_ss_get_laptime",
     "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
@@ -144,7 +147,7 @@ def set_arr(field, values):
 class Context:
     """One lmpc_ctx: device lap stores + batched solver for a fixed (N, safe-set size) configuration."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, runtime_kernel=False):
         self.lib = load()
         self.cfg = cfg
         self.N = cfg.N
@@ -152,12 +155,22 @@ class Context:
         self.M = 8 * self.N + self.S
         self._step_plan = {}
         self._h = C.c_void_p()
-        rc = self.lib.lmpc_create(C.byref(cfg), C.byref(self._h))
-        if rc == E_VARIANT:             # (N, numSS_points) outside the built-in set: compile its shared object once (hipcc, ~20 s), then retry
-            from . import build
-            build.build_variant(self.N, self.S)
+        if runtime_kernel:              # (tests: the runtime-(N, S) kernel even where a fast one exists)
+            rc = self.lib.lmpc_create_ex(C.byref(cfg), C.c_uint(CREATE_FORCE_RUNTIME_KERNEL), C.byref(self._h))
+        else:
             rc = self.lib.lmpc_create(C.byref(cfg), C.byref(self._h))
+        if rc == E_VARIANT:             # (N, numSS_points) outside the built-in set: compile its shared object once (hipcc, ~20 s), then retry ...
+            from . import build
+            try:
+                build.build_variant(self.N, self.S)
+                rc = self.lib.lmpc_create(C.byref(cfg), C.byref(self._h))
+            except (OSError, RuntimeError, ValueError, subprocess.SubprocessError) as e:
+                # ... and where that is not possible (no hipcc on the box, a failed build): the runtime-(N, S) kernel serves the horizon, several times slower.
+                # MPCParams.N is a plain parameter in the reference (PredictiveControllers.py:63-107, main.py:43): LMPC_E_VARIANT never reaches a user.
+                warnings.warn("no solve-kernel variant for N = %d, numSS_points = %d (%s): using the runtime-(N, S) kernel" % (self.N, self.S, str(e).splitlines()[0][:120]))
+                rc = self.lib.lmpc_create_ex(C.byref(cfg), C.c_uint(CREATE_RUNTIME_KERNEL), C.byref(self._h))
         _chk(rc)
+        self.solver_kind = int(self.lib.lmpc_solver_kind(self._h))      # 0 built-in, 1 variant library, 2 runtime-(N, S) kernel
 
     def close(self):
         if self._h:

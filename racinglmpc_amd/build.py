@@ -4,7 +4,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "lmpc_capi.hip")
-KDEPS = [os.path.join(_HERE, "csrc", f) for f in ("lmpc_kernels.hip.h", "lmpc_solve_mw.hip.h", "lmpc_solve_cd.hip.h", "lmpc_variant.hip.h")] + [os.path.join(os.path.dirname(_HERE), "include", "lmpc_hip.h")]
+KDEPS = [os.path.join(_HERE, "csrc", f) for f in ("lmpc_kernels.hip.h", "lmpc_solve_mw.hip.h", "lmpc_solve_cd.hip.h", "lmpc_solve_rt.hip.h", "lmpc_variant.hip.h")] + [os.path.join(os.path.dirname(_HERE), "include", "lmpc_hip.h")]
 DEPS = [SRC, os.path.join(_HERE, "csrc", "lmpc_comm.hip.h")] + KDEPS
 VSRC = os.path.join(_HERE, "csrc", "lmpc_variant.hip")
 # (N, numSS_points) pairs compiled into liblmpc_hip.so itself (lmpc_capi.hip: builtin_variant) and the extra ones build() prepares as

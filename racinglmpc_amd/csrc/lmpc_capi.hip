@@ -110,6 +110,7 @@ struct lmpc_ctx {
     int *w_selStart;                         // lmpc_select_batch: window starts, max_batch x numSS_it
     void *scr_dev; size_t scr_bytes;         // pooled scratch of the small host-buffer entry points (plant step, global position)
     std::vector<char *> gaps;                // guard builds: the 256-byte zones between the work-buffer ranges of the slabs
+    unsigned create_flags; int solver_kind;  // lmpc_create_ex flags; which solve kernels serve this context: 0 built-in, 1 variant library, 2 the runtime-(N, S) kernel
     int dbg_capture;                         // lmpc_debug_rollout_capture: rollout sessions also keep the selected safe-set points of the last step (parity probes of the closed loop)
     double *dbg_trace;                       // developer builds (-DLMPC_TRACE): device buffer of the per-iteration side channel, see lmpc_debug_set_trace
     double tr_s[4]; long long tr_n;          // developer trace of lmpc_step_batch's one-QP path (lmpc_debug_step_trace): seconds spent staging / launching / waiting / unstaging
@@ -154,8 +155,17 @@ static int load_variant(lmpc_ctx *c, int n, int s) {
 }
 static int pick_solver(lmpc_ctx *c) {
     const int n = c->cfg.N, s = c->cfg.numSS_it > 0 ? c->cfg.numSS_points : 0;
-    if (builtin_variant(&c->var, n, s)) return LMPC_OK;
-    return load_variant(c, n, s);
+    c->solver_kind = 0;
+    if (!(c->create_flags & LMPC_CREATE_FORCE_RUNTIME_KERNEL)) {
+        if (builtin_variant(&c->var, n, s)) return LMPC_OK;
+        c->solver_kind = 1;
+        const int rc = load_variant(c, n, s);
+        if (rc == LMPC_OK || !(c->create_flags & LMPC_CREATE_RUNTIME_KERNEL)) return rc;
+    }
+    // no built-in instantiation, no variant library (and nobody to compile one): the runtime-(N, S) kernel (lmpc_solve_rt.hip.h)
+    c->solver_kind = 2;
+    if (!lmpc_variant_fill_rt(&c->var, n, s)) return set_err(LMPC_E_ARG, "runtime solve kernel", "this (N, numSS_points) exceeds the LDS of a CU");
+    return LMPC_OK;
 }
 
 extern "C" {
@@ -309,7 +319,10 @@ static int create_body(lmpc_ctx *c) {
 
 extern "C" {
 int lmpc_destroy(lmpc_ctx *c);
-int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
+int lmpc_create_ex(const lmpc_config *cfg, unsigned flags, lmpc_ctx **out);
+int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) { return lmpc_create_ex(cfg, 0u, out); }
+int lmpc_solver_kind(lmpc_ctx *c) { return c ? c->solver_kind : LMPC_E_ARG; }
+int lmpc_create_ex(const lmpc_config *cfg, unsigned flags, lmpc_ctx **out) {
     ARGCHK(cfg && out);
     ARGCHK(cfg->N >= 2 && cfg->N <= LMPC_MAX_N);
     ARGCHK(cfg->numSS_it >= 0 && cfg->numSS_it <= LMPC_MAX_USED_LAPS && cfg->trToUse >= 0 && cfg->trToUse <= LMPC_MAX_USED_LAPS);
@@ -323,7 +336,7 @@ int lmpc_create(const lmpc_config *cfg, lmpc_ctx **out) {
     ARGCHK(cfg->slacks || cfg->numSS_it == 0);          // hard lane rows: plain MPC only (the reference's LMPC.unpackSolution mis-slices without slack variables)
     ARGCHK(cfg->max_batch >= 1 && cfg->max_laps >= 1 && cfg->max_lap_len >= 8);
     lmpc_ctx *c = new lmpc_ctx();                      // value-initialised: every pointer starts as nullptr, so lmpc_destroy is safe at any point
-    c->cfg = *cfg; c->profiling = 0; c->ro = nullptr; c->var_dl = nullptr; c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    c->cfg = *cfg; c->create_flags = flags; c->profiling = 0; c->ro = nullptr; c->var_dl = nullptr; c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
     memset(&c->stats, 0, sizeof(c->stats));
     int rc = create_body(c);
     if (rc != LMPC_OK) { const std::string keep = g_err; lmpc_destroy(c); g_err = keep; return rc; }

@@ -8,6 +8,9 @@
 #pragma once
 #include "lmpc_kernels.hip.h"
 #include "lmpc_solve_mw.hip.h"
+#ifndef LMPC_VARIANT_TU
+#include "lmpc_solve_rt.hip.h"       // the runtime-(N, S) fallback kernel lives in the library only
+#endif
 #ifdef LMPC_WITH_CD                  // the condensed kernel is a measured alternative (not faster), kept out of the default build: racinglmpc_amd.build.build_flavour("cd", ["LMPC_WITH_CD"])
 #include "lmpc_solve_cd.hip.h"
 #endif
@@ -105,3 +108,18 @@ template <int N, int S> static bool lmpc_variant_fill(lmpc_variant_api *v) {
 #endif
     return true;
 }
+
+#ifndef LMPC_VARIANT_TU
+// The runtime-(N, S) kernel behind the same table (lmpc_solve_rt.hip.h): one wave per QP whatever the batch size, no multi-wave / condensed / fused forms.
+// false if the footprint of this (N, S) exceeds the LDS of a CU (N = 64 with 384 safe-set points does: 171 KB).
+static bool lmpc_variant_fill_rt(lmpc_variant_api *v, int N, int S) {
+    if (N < 2 || N > LMPC_MAX_N || S < 0 || S > LMPC_MAX_SS_POINTS) return false;
+    const size_t lds = (size_t)rt_layout(N, S).tot * sizeof(double);
+    if (lds + 1024 > (size_t)160 * 1024) return false;
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_rt<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void *)lmpc_solve_kernel_rt<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    v->N = N; v->S = S; v->lds_mw = 0; v->lds_1w = lds; v->lds_1w_abg = 0; v->lds_cd = 0; v->lds_cd_q = 0; v->occ_mw2 = 0;
+    v->launch_1w = &lmpc_rt_launch; v->launch_retry = &lmpc_rt_launch_retry; v->launch_mw4 = &lmpc_rt_launch; v->launch_mw2 = &lmpc_rt_launch; v->launch_cd = &lmpc_rt_launch_cd;
+    return true;
+}
+#endif

@@ -107,10 +107,10 @@ def stores_at_lap(g, lap):
     return model, ss
 
 
-def make_lmpc_ctx(g, lap, max_batch=64, **kw):
+def make_lmpc_ctx(g, lap, max_batch=64, runtime_kernel=False, **kw):
     from racinglmpc_amd import _capi
     cfg, par = lmpc_config(g, 12, max_batch=max_batch, **kw)
-    ctx = _capi.Context(cfg)
+    ctx = _capi.Context(cfg, runtime_kernel=runtime_kernel)
     model, ss = stores_at_lap(g, lap)
     for x, u in model:
         ctx.model_add_trajectory(x, u)
@@ -146,7 +146,7 @@ def replay_lap(g, lap, ctx, on_record, max_records=None):
     return n
 
 
-def run_golden_step_check(max_records=None, dev_every=0):
+def run_golden_step_check(max_records=None, dev_every=0, runtime_kernel=False):
     """Replay the recorded reference laps through the HIP path (lmpc_step_batch, B = 1 per recorded step, addPoint
     in between) and compare with the certified optimum of the reference-assembled QP.  Used by smoke() and tests."""
     g = load_lmpc_golden()
@@ -155,7 +155,7 @@ def run_golden_step_check(max_records=None, dev_every=0):
     for lap in (4, 5):
         if left is not None and left <= 0:
             break
-        ctx, par = make_lmpc_ctx(g, lap, max_batch=4)
+        ctx, par = make_lmpc_ctx(g, lap, max_batch=4, runtime_kernel=runtime_kernel)
 
         def on_record(r):
             out = ctx.step_batch(g["rec_x0"][r][None], g["rec_xLin"][r][None], g["rec_uLin"][r][None], g["rec_OldInput"][r][None],
