@@ -744,31 +744,27 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         }
         __syncthreads();
         TSMW(14);
-        double apmax = 1.0, admax = 1.0, dma_r[RPL];
+        // One pass over the rows, one reduction round (round 6; two before): besides the step lengths of the affine direction every thread sums  dt mu,  t dmu  and  dt dmu
+        // over its rows -- the complementarity gap after the affine step is  gap + (a_p sum dt mu + a_d sum t dmu + a_p a_d sum dt dmu) / M  for whatever a_p, a_d the
+        // reduction then yields, so sigma needs no second pass (and no second barrier) behind the step lengths.  (Slots 0 and 1 are phase 1's, dead since barrier B1.)
+        double apmax = 1.0, admax = 1.0, s_dtm = 0.0, s_tdm = 0.0, s_dd = 0.0;
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-            const int r = slot_row(j); dma_r[j] = 0.0;
+            const int r = slot_row(j);
             if (r >= 0) {
                 const double dta = -rowF(r, dx, du, ds, dl), mr = m[r];
                 const double dma = -h[r] - th[r] * dta;
-                dt_r[j] = dta; dma_r[j] = dma;
+                dt_r[j] = dta; tp_r[j] = dta * dma;
+                s_dtm = fma(dta, mr, s_dtm); s_tdm = fma(t_r[j], dma, s_tdm); s_dd += tp_r[j];
                 if (dta < 0.0) apmax = fmin(apmax, -t_r[j] * frcp(dta));
                 if (dma < 0.0) admax = fmin(admax, -mr * frcp(dma));
             }
         }
-        red_put(4, wmin<BCF>(apmax)); red_put(5, wmin<BCF>(admax));
+        red_put(4, wmin<BCF>(apmax)); red_put(5, wmin<BCF>(admax)); red_put(6, wsum<BCF>(s_dtm)); red_put(0, wsum<BCF>(s_tdm)); red_put(1, wsum<BCF>(s_dd));
         __syncthreads();
         apmax = red_min(4); admax = red_min(5);
         if (!sep) { apmax = fmin(apmax, admax); admax = apmax; }
-        double gaff = 0.0;
-#pragma unroll
-        for (int j = 0; j < RPL; j++) {
-            const int r = slot_row(j);
-            if (r >= 0) { gaff = fma(t_r[j] + apmax * dt_r[j], m[r] + admax * dma_r[j], gaff); tp_r[j] = dt_r[j] * dma_r[j]; }
-        }
-        red_put(6, wsum<BCF>(gaff));
-        __syncthreads();
-        gaff = SWEEP_BF<N> ? red_sum(6) * (1.0 / (double)M) : red_sum(6) / (double)M;
+        const double gaff = gap + (apmax * red_sum(6) + admax * red_sum(0) + apmax * admax * red_sum(1)) * (SWEEP_BF<N> ? (1.0 / (double)M) : 1.0 / (double)M);
         double sig = SWEEP_BF<N> ? gaff * frcp(gap) : gaff / gap; sig = sig * sig * sig;
         const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);
         TSMW(15);
@@ -823,10 +819,12 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         // terms above, the third is sum_j T_j ds_T[j] (sum_c SS[j][c]) with the row sums of SS formed once (every thread: same value)
         double deta = 0.0;
         if constexpr (term) {
-            deta = red_sum(9);
+            if (wave == WCL(2)) {                              // (eta_m is read by the lambda rows of phase 1 only: the wave that owns them keeps it -- not the critical wave)
+                deta = red_sum(9);
 #pragma unroll
-            for (int j = 0; j < 6; j++) deta -= T2p[j] * w7[j] * ss_rowsum[j];
-            if constexpr (SWEEP_BF<N>) deta *= 1.0 / (double)S; else deta /= (double)S;
+                for (int j = 0; j < 6; j++) deta -= T2p[j] * w7[j] * ss_rowsum[j];
+                if constexpr (SWEEP_BF<N>) deta *= 1.0 / (double)S; else deta /= (double)S;
+            }
         }
         {                                                      // (the step, and the length of its (x, u) part for step_bound_ok: slot 6 is free from the predictor's
             double smax = 0.0;                                 //  sigma to the next iteration's, and is read at the top of that iteration, behind this phase's barrier)
@@ -847,7 +845,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
             }
         }
         if (w0) gs0[lane] = gsum_c;
-        if constexpr (term) { if (tid < 6) sT[tid] = fma(al, w7[tid], sT[tid]); }
+        if constexpr (term) { if (tid >= NT - 6) sT[tid - (NT - 6)] = fma(al, w7[tid - (NT - 6)], sT[tid - (NT - 6)]); }      // (the last wave's spare lanes, not wave 0's)
         if constexpr (TEARLY) {
             // the next iteration's terminal factor, part A: wave 0 owns the lambda rows, so the weights it has just written are all it needs
             // (its own LDS writes are visible to it after the wait); the Gram matrix is in Wl when the barrier below falls

@@ -28,17 +28,13 @@ def _work(args):
         ex, cert1 = orc.osqp_solve_exact(P, q, Ao, l, u, want=1e-8)      # error = 660 x residual on one of these -- either answer can itself be 1e-6 off; the kernel is compared
         opts.append(ex.x); cert = max(cert, cert1)                     # with the nearer one, as in the tests
     exu = min(float((np.abs(r["xu"] - o[:n]) / (1 + np.abs(o[:n]))).max()) for o in opts)
-    ezt = 0.0; indet = 0
+    ezt = 0.0; lam_star = None
     if r.get("zt") is not None:
-        # zt = Succ lambda, zt_u = SuccU lambda (feasibleStateInput, :382-384) against the oracle's lambda*.  x, u, s_T are unique, lambda need not be: a QP
-        # whose zt is more than 2e-7 off gets the interval of VALID values of every zt entry over all optimal lambdas (common.zt_face_err: 16 small LPs); the kernel's zt is
-        # measured against that interval, and the QP is counted as one with more than one optimal lambda when an interval is wider than 1e-7.
         S = r["Qsel"].shape[0]; sl = slice(n + 2 * NH, n + 2 * NH + S)
         ezt = min(common.zt_err(r["zt"], r["ztu"], r["Succ"], r["SuccU"], o[sl]) for o in opts)
         if ezt > 2e-7:
-            ezt, width = common.zt_face_err(r["zt"], r["ztu"], r["Succ"], r["SuccU"], r["SS"], r["Qsel"], r2.x[sl])
-            indet = int(width > 1e-7)
-    return exu, float(cert), ezt, indet
+            lam_star = r2.x[sl].copy()                       # (the parent looks at this QP again: _solve_all)
+    return exu, float(cert), ezt, lam_star
 
 
 def _solve_all(rec, NH, fast):
@@ -54,7 +50,17 @@ def _solve_all(rec, NH, fast):
     finally:
         if lim is not None and hasattr(lim, "restore_original_limits"):
             lim.restore_original_limits()
-    return np.array([a[0] for a in res]), np.array([a[1] for a in res]), np.array([a[2] for a in res]), np.array([a[3] for a in res])
+    # zt = Succ lambda, zt_u = SuccU lambda (feasibleStateInput, :382-384) against the oracle's lambda*.  x, u, s_T are unique, lambda need not be: a QP
+    # whose zt is more than 2e-7 off gets the interval of VALID values of every zt entry over all optimal lambdas (common.zt_face_err: 16 small LPs); the kernel's zt is
+    # measured against that interval, and the QP is counted as one with more than one optimal lambda when an interval is wider than 1e-7.  (In THIS process: the LP
+    # solver is multi-threaded, and a forked pool worker that inherits its state can deadlock -- it did, once, on the GPU box.)
+    ezt = np.array([a[2] for a in res]); indet = np.zeros(len(res), int)
+    for i, a in enumerate(res):
+        if a[3] is not None:
+            r = rec[i]
+            ezt[i], width = common.zt_face_err(r["zt"], r["ztu"], r["Succ"], r["SuccU"], r["SS"], r["Qsel"], a[3])
+            indet[i] = int(width > 1e-7)
+    return np.array([a[0] for a in res]), np.array([a[1] for a in res]), ezt, indet
 
 
 def probe(seed=5, stride=10, laps=40, NH=14, fast=False):

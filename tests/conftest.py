@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A test that hangs (a deadlocked worker pool, a kernel that never returns) must fail, not stall the round: every test gets a per-test limit where the
+    pytest-timeout plug-in is installed (it is in this image), unless the command line or the test set one."""
+    if not config.pluginmanager.hasplugin("timeout") or config.getoption("timeout", None):
+        return
+    for it in items:
+        if it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(900 if it.get_closest_marker("gpu") is None else 600))
+
+
 @pytest.fixture(scope="session")
 def built():
     import __graft_entry__ as g

@@ -53,6 +53,7 @@ def tri_inv_upper(R):
 
 
 TERM_LATE_GAP = 1e-4
+SEP_STICKY = 0.5
 SEP_RULE = "kernel"       # "kernel": separate primal / dual steps after an iteration whose gap shrank by less than 10x; "noinc", "off": experiments
 TERM_LATE = False          # set by ipm_solve per iteration: the iterate is in its final phase (gap below 1e-4)
 TERM_FACTOR = "cholqr2_fo_late"        # (round 5: what the kernels do)   how kkt_factor factorises the terminal block: "mgs" (two passes of modified Gram-Schmidt on M'), "gram" (Cholesky of M M', the kernels' way), "gram_scaled"
@@ -258,6 +259,14 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
                 sep = sep and gap < gap_prev       # that repair it -- a two-cycle of up to 20 iterations on 1 in 3 400 closed-loop QPs (tools/capture_slow_qps.py)
             elif SEP_RULE == "off":
                 sep = False
+            elif SEP_RULE == "sticky":             # (round 6) separate steps are switched off for the rest of the solve by the first separate-step iteration that fails to
+                if sep_before and gap > SEP_STICKY * gp_before:      # contract the gap by SEP_STICKY: what breaks the two-cycle (separate step shrinks the gap 3x, the next one
+                    info["sep_dead"] = True                          # grows it 3x) before it starts
+                sep = sep and not info.get("sep_dead", False)
+            elif SEP_RULE == "guard":              # (round 6) ... and from then on equal steps INSIDE a wide neighbourhood of the central path (the retry kernels' safeguard: the step
+                if sep_before and gap > SEP_STICKY * gp_before:      # is shortened until every complementarity product keeps 1 % of the mean)
+                    info["sep_dead"] = True
+                sep = sep and not info.get("sep_dead", False)
         gap_prev = gap
         # ---- residuals
         rx, ru, rs, rl, re_dyn, re_sum, rd, re = residuals(x, u, s, lam, nu, eta_m, m_lane, m_u, m_s, m_l)
@@ -429,6 +438,12 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
         al = min(1.0, frac * maxstep(ts, dt)); ald = min(1.0, frac * maxstep(ms, dm))
         if not sep:
             al = ald = min(al, ald)
+        if SEP_RULE == "guard" and info.get("sep_dead", False):
+            for _ in range(8):
+                pr = np.concatenate([((t + al * d) * (m + ald * dm_)).ravel() for t, d, m, dm_ in zip(ts, dt, ms, dm)])
+                if pr.min() >= 1e-2 * pr.sum() / mtot:
+                    break
+                al *= 0.7; ald *= 0.7
         # costates (delta): dnu_N from terminal, then backwards
         dnu = np.zeros((N, 6))
         # dnu_N (row x_N): stationarity of the Newton system in x_N
