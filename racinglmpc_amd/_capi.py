@@ -562,3 +562,42 @@ def config_from(N, Q, R, Qf, dR, Qslack, Fx, bx, Fu, bu, xRef, QterminalSlack=No
     for k, v in solver.items():
         setattr(cfg, k, v)
     return cfg
+
+
+class ContextPool:
+    """`depth` contexts on one device -- one HIP stream, one set of work buffers, one copy of the (small) lap stores each -- for callers that keep several INDEPENDENT
+    batches in flight.  Inside one launch the CUs whose QP has converged idle until the slowest QP of the batch has (mean 8.6 against a maximum of 13 iterations at batch
+    256); with the next batch queued on another stream its work-groups start on those CUs: 1.21 -> 1.66 M solves/s at batch 256 with three in flight, 1.84 -> 3.14 M at
+    batch 512 (tools/pipelined_bench.py).  Store edits go to every member; `step_batch_dev` deals the steps to the members in turn and returns the member it used.
+    A closed loop -- step t + 1 needs step t -- cannot use it; batched requests can."""
+
+    def __init__(self, cfg, depth=2):
+        self.members = [Context(cfg) for _ in range(int(depth))]
+        self._next = 0
+
+    def __getattr__(self, name):                       # lap-store edits (model_add_trajectory, ss_add_trajectory, ss_add_point, ss_set_selected, ...): the same call on every member
+        if name.startswith(("model_", "ss_")) and not name.startswith(("ss_get", "ss_num", "ss_lap", "model_num")):
+            def forward(*a, **kw):
+                out = None
+                for m in self.members:
+                    out = getattr(m, name)(*a, **kw)
+                return out
+            return forward
+        return getattr(self.members[0], name)
+
+    def step_dev_buffers(self, inp, diagnostics=True):
+        """One set of device buffers per member: [(args, allocations)], in member order."""
+        return [m.step_dev_buffers(inp, diagnostics=diagnostics) for m in self.members]
+
+    def step_batch_dev(self, B, args_per_member):
+        i = self._next; self._next = (i + 1) % len(self.members)
+        self.members[i].step_batch_dev(B, args_per_member[i][0])
+        return i
+
+    def sync(self):
+        for m in self.members:
+            m.sync()
+
+    def close(self):
+        for m in self.members:
+            m.close()

@@ -1451,7 +1451,11 @@ __device__ __forceinline__ void k2_select(const lmpc_dev_params &p, const lmpc_s
 template <int N, int S, bool EQ = false, bool ABG = false>
 // (two waves per SIMD -- at most 256 registers -- only where the LDS footprint lets more than four QPs share a CU and the terminal
 // block keeps one column per lane)
+#ifdef LMPC_AB_OCC3     // (developer A / B, tools/resource_usage.py: what a third resident wave per SIMD -- at most 168 registers -- would cost this kernel; profiles/r6_onewave_occ3_resource_usage.txt)
+__global__ __launch_bounds__(WAVE, 3) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
+#else
 __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 1024 && solve_lds1<N, S, ABG>::CH == 1) ? 2 : 1) void lmpc_solve_kernel(lmpc_dev_params p, int B, lmpc_solve_io io) {
+#endif
     extern __shared__ double sm[];
     using LL = solve_lds1<N, S, ABG>;
     constexpr int M = LL::M;

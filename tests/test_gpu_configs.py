@@ -609,3 +609,29 @@ def test_closed_loop_singular_regressions_match_the_oracle(built):
     #  condition numbers beyond the 1e5 .. 1e8 TOL_ABC is stated for: measured 1.1e-9, the Cholesky here against the oracle's LU)
     assert worst < 10 * common.TOL_ABC
     ctx.close()
+
+
+def test_context_pool_gives_the_single_context_answers(built):
+    """racinglmpc_amd._capi.ContextPool (several independent batches in flight, one HIP stream each): every member returns what a single context returns for the same
+    batch, bit for bit, however the launches interleave on the device."""
+    import bench
+    from racinglmpc_amd import _capi
+    g = common.load_lmpc_golden()
+    B = 256
+    inp = bench.synth_batch(g, B, 12)
+    ref_ctx = bench.make_ctx(g, 12, B, 0)
+    a, keep = ref_ctx.step_dev_buffers(inp, diagnostics=False)
+    ref_ctx.step_batch_dev(B, a)
+    ref = ref_ctx.step_dev_fetch(a, B)
+    pool = bench.make_ctx(g, 12, B, 0, pool_depth=3)
+    assert isinstance(pool, _capi.ContextPool) and len(pool.members) == 3 and all(m.ss_num_laps() == 4 for m in pool.members)
+    bufs = pool.step_dev_buffers(inp, diagnostics=False)
+    used = [pool.step_batch_dev(B, bufs) for _ in range(9)]
+    assert used == [0, 1, 2] * 3
+    pool.sync()
+    for m, (am, _) in zip(pool.members, bufs):
+        got = m.step_dev_fetch(am, B)
+        for k in ("xPred", "uPred", "slack", "lambd", "sTerm", "ztNext", "ztuNext", "status", "iters"):
+            assert np.array_equal(got[k], ref[k]), k
+    assert np.all(ref["status"] == 0)
+    pool.close(); ref_ctx.close()
