@@ -338,6 +338,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sweep / extra configurations / rollout leg")
     ap.add_argument("--rollouts-per-gpu", type=int, default=1024)
+    ap.add_argument("--rollouts-only", action="store_true", help="of the extras, run the closed-loop rollout leg only (developer runs)")
     ap.add_argument("--dry-run", action="store_true", help="start the ranks and the rendezvous only (no GPU needed): proves the N-rank launch path")
     ap.add_argument("--dry-run-rccl", action="store_true", help="communicator set-up, one barrier and one gather only -- on a box with fewer GPUs than ranks the ranks share "
                     "device 0 and RCCL refuses: the failure path of lmpc_comm_init with world > 1 (one JSON line with rccl_error, exit status 3)")
@@ -482,7 +483,7 @@ def main():
         host_event = world > 1 and parallel._is_local(addr)
         if rank != 0 and host_event:
             parallel.host_wait("extras", port)
-        if rank == 0:
+        if rank == 0 and not args.rollouts_only:
             try:                                       # (an extra configuration that fails must not cost the headline line)
                 sweep = {}
                 for bb in (1, 8, 64, 256, 512, 1024, 2048, 4096, 8192):
@@ -504,6 +505,7 @@ def main():
                 out["pipelined_batches"] = {"2": pipelined_leg(g, N, B, local, steps=20, warmup=3, depth=2), "3": pipelined_leg(g, N, B, local, steps=20, warmup=3, depth=3)}
             except Exception as e:                     # noqa: BLE001
                 out["extras_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+        if rank == 0:
             if host_event:
                 sig_path = parallel.host_signal("extras", port)
         # The multi-rank form of this leg (one all-gather per lap between different devices) has never run on hardware before the driver's own

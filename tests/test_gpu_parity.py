@@ -658,3 +658,4 @@ def test_lti_regression_kernel_matches_reference(built):
     print("LTI regression worst rel err", worst)
     with pytest.raises(np.linalg.LinAlgError):
         Utilities.Regression(np.zeros((30, 6)), np.zeros((30, 2)), 0.0)
+
