@@ -127,6 +127,8 @@ int lmpc_ss_get_laptime(lmpc_ctx *, int lap, int *T);
 int lmpc_regress_batch(lmpc_ctx *, int B, const double *xLin /*B x N x 6 (first N rows used)*/, int xLinRowStride /* (N+1)*6 or N*6 */,
                        const double *uLin /*B x N x 2*/,
                        double *A /*B x N x 36*/, double *Bm /*B x N x 12*/, double *C /*B x N x 6*/, int *status /*B x N*/);
+int lmpc_regress_points(lmpc_ctx *, int n, const double *x /*n x 6*/, const double *u /*n x 2*/, double *A /*n x 6 x 6*/, double *B /*n x 6 x 2*/, double *C /*n x 6*/, int *status /*n*/);
+        /* PredictiveModel.regressionAndLinearization, PredictiveModel.py:48-197, for n independent points (the reference calls it with one): no horizon around them */
         /* MPC.computeLTVdynamics -> PredictiveModel.regressionAndLinearization, :140-145 / PredictiveModel.py:48-197 */
 
 int lmpc_select_batch(lmpc_ctx *, int B, const double *x0 /*B x 6*/, const double *zt /*B x 6*/,

@@ -49,14 +49,12 @@ class PredictiveModel():
     def regressionAndLinearization(self, x, u):
         """(A_i, B_i, C_i) with x_{k+1} = A_i x_k + B_i u_k + C_i around (x, u).  One GPU launch."""
         ctx = self._any_ctx()
-        N = ctx.N
-        xl = np.tile(np.asarray(x, float).reshape(1, 1, 6), (1, N, 1)); ul = np.tile(np.asarray(u, float).reshape(1, 1, 2), (1, N, 1))
-        A, B, C, st = ctx.regress_batch(xl, ul)
-        if st[0, 0] & _capi.ST_REG_SINGULAR:
+        A, B, C, st = ctx.regress_points(np.asarray(x, float).reshape(1, 6), np.asarray(u, float).reshape(1, 2))      # one query, one work-group (no horizon tiled around it)
+        if st[0] & _capi.ST_REG_SINGULAR:
             raise ArithmeticError("local regression is singular (fewer than 5 independent neighbours within h)")
-        if st[0, 0] & _capi.ST_NO_SEGMENT:
+        if st[0] & _capi.ST_NO_SEGMENT:
             raise ValueError("curvature(): s = %r is on no track segment" % (x[4],))
-        return A[0, 0], B[0, 0], C[0, 0]
+        return A[0], B[0], C[0]
 
     # -- glue ----------------------------------------------------------------------------------------------
     def _attach(self, ctx):

@@ -50,7 +50,7 @@ EXPORTS = [
     "lmpc_config_default", "lmpc_create", "lmpc_create_ex", "lmpc_solver_kind", "lmpc_destroy", "lmpc_last_error", "lmpc_active_knobs", "lmpc_version",
     "lmpc_model_add_trajectory", "lmpc_model_num_laps", "lmpc_model_replace_lap",
     "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun", "lmpc_ss_get_laptime",
-    "lmpc_regress_batch", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
+    "lmpc_regress_batch", "lmpc_regress_points", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
     "lmpc_lti_regression", "lmpc_comm_unique_id", "lmpc_comm_init", "lmpc_comm_destroy", "lmpc_comm_info", "lmpc_comm_allgather_dev", "lmpc_comm_allgather",
     "lmpc_comm_allreduce_max", "lmpc_comm_barrier", "lmpc_rollout_exchange",
@@ -223,6 +223,13 @@ class Context:
         stride = xLin.shape[1] * 6
         A = np.zeros((B, N, 6, 6)); Bm = np.zeros((B, N, 6, 2)); Cc = np.zeros((B, N, 6)); st = np.zeros((B, N), np.int32)
         _chk(self.lib.lmpc_regress_batch(self._h, C.c_int(B), _d(xLin), C.c_int(stride), _d(uLin), _d(A), _d(Bm), _d(Cc), _d(st)))
+        return A, Bm, Cc, st
+
+    def regress_points(self, x, u):
+        """PredictiveModel.regressionAndLinearization for n independent points: (A (n, 6, 6), B (n, 6, 2), C (n, 6), status (n,))."""
+        x = _f64(x).reshape(-1, 6); u = _f64(u).reshape(-1, 2); n = x.shape[0]
+        A = np.zeros((n, 6, 6)); Bm = np.zeros((n, 6, 2)); Cc = np.zeros((n, 6)); st = np.zeros(n, np.int32)
+        _chk(self.lib.lmpc_regress_points(self._h, C.c_int(n), _d(x), _d(u), _d(A), _d(Bm), _d(Cc), _d(st)))
         return A, Bm, Cc, st
 
     def select_batch(self, x0, zt, xPredPrev=None, hasPred=None, timeStep=None):

@@ -735,6 +735,28 @@ int lmpc_regress_batch(lmpc_ctx *c, int B, const double *xLin, int xLinRowStride
     return LMPC_OK;
 }
 
+int lmpc_regress_points(lmpc_ctx *c, int n, const double *x, const double *u, double *A, double *Bm, double *C, int *status) {
+    // PredictiveModel.regressionAndLinearization (PredictiveModel.py:48-197) for n independent linearisation points (x (n x 6), u (n x 2)): the reference's own call
+    // shape -- one point per call -- without a horizon around it.  The regression kernel runs with a parameter block whose horizon is 1: one query per work-group.
+    ARGCHK(c && x && u && A && Bm && C && n >= 1 && (long long)n <= (long long)c->cfg.max_batch * c->cfg.N);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    H2D(c->w_xLin, x, (size_t)n * 6); H2D(c->w_uLin, u, (size_t)n * 2);
+    int rc = refresh_params(c, true, false); if (rc) return rc;
+    {
+        const lmpc_dev_params keep = c->dp;
+        c->dp.N = 1;                                                     // (launch_k1 passes c->dp by value)
+        ev_begin(c, 0);
+        launch_k1(c, n, n, 1, c->w_xLin, 6, c->w_uLin, c->w_A, c->w_B, c->w_C, c->w_rstatus);
+        ev_end(c);
+        c->dp = keep;
+    }
+    HIPCHK(hipGetLastError());
+    c->stats.n_regress++;
+    D2H(A, c->w_A, (size_t)n * 36); D2H(Bm, c->w_B, (size_t)n * 12); D2H(C, c->w_C, (size_t)n * 6); D2H(status, c->w_rstatus, (size_t)n);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LMPC_OK;
+}
+
 int lmpc_select_batch(lmpc_ctx *c, int B, const double *x0, const double *zt, const double *xPredPrev, const int *hasPred, const int *timeStep,
                       double *ssSel, double *qSel, double *succ, double *succU, double *ztUsed, int *selStart, int *status) {
     ARGCHK(c && x0 && zt && B >= 1 && B <= c->cfg.max_batch && c->cfg.numSS_it > 0);

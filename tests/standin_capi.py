@@ -92,6 +92,13 @@ class Context:
         A, B, C = orc.compute_ltv_dynamics(xs, us, used, pt, np.asarray(xLin, float)[0], np.asarray(uLin, float)[0], self.N)
         return A[None], B[None], C[None], np.zeros((1, self.N), np.int32)
 
+    def regress_points(self, x, u):
+        _rec("regress_points")
+        xs, us, used, pt = self._model()
+        x = np.asarray(x, float).reshape(-1, 6); u = np.asarray(u, float).reshape(-1, 2)
+        out = [orc.regression_and_linearization(xs, us, used, pt, xi, ui) for xi, ui in zip(x, u)]
+        return np.array([o[0] for o in out]), np.array([o[1] for o in out]), np.array([o[2] for o in out]), np.zeros(x.shape[0], np.int32)
+
     def _select(self, x0, zt, xPredPrev, hasPred, timeStep):
         TL = self.cfg.trackLength
         z = np.array(zt, float)

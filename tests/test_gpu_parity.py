@@ -33,6 +33,28 @@ def test_regression_matches_reference(g):
     assert worst < common.TOL_ABC
 
 
+def test_regress_points_is_the_batch_regression_point_by_point(g):
+    """lmpc_regress_points (the reference's own call shape: PredictiveModel.regressionAndLinearization(x, u) for ONE point, no horizon around it) returns, for every
+    horizon point of the recorded steps, bit for bit what the batched regression returns for it; the drop-in PredictiveModel goes through it."""
+    from racinglmpc_amd.PredictiveModel import PredictiveModel
+    from tests import closed_loop
+    ctx, par = common.make_lmpc_ctx(g, 5, max_batch=64)
+    idx = np.where(g["rec_lap"] == 5)[0][:16]
+    A, B, C, st = ctx.regress_batch(g["rec_xLin"][idx], g["rec_uLin"][idx])
+    xq = g["rec_xLin"][idx][:, :12].reshape(-1, 6); uq = g["rec_uLin"][idx].reshape(-1, 2)
+    Ap, Bp, Cp, stp = ctx.regress_points(xq, uq)
+    assert np.array_equal(Ap, A.reshape(-1, 6, 6)) and np.array_equal(Bp, B.reshape(-1, 6, 2)) and np.array_equal(Cp, C.reshape(-1, 6)) and np.all(stp == 0)
+    ctx.close()
+    pm = PredictiveModel(6, 2, closed_loop.TrackMap(g), 4)
+    for _ in range(4):
+        pm.addTrajectory(g["xPID"], g["uPID"])
+    Ai, Bi, Ci = pm.regressionAndLinearization(g["xPID"][100], g["uPID"][100])
+    from oracle import lmpc_oracle as orc
+    Ao, Bo, Co = orc.regression_and_linearization([g["xPID"]] * 4, [g["uPID"]] * 4, [0, 1, 2, 3], np.array(g["track"]), g["xPID"][100], g["uPID"][100])
+    for got, ref in ((Ai, Ao), (Bi, Bo), (Ci, Co)):
+        assert (np.abs(got - ref) / (1 + np.abs(ref))).max() < common.TOL_ABC
+
+
 def test_selection_bit_exact(g):
     """K2 vs the reference's selectPoints/addTerminalComponents output, store state replayed step by step."""
     checked = 0
