@@ -120,6 +120,9 @@ int lmpc_ss_set_selected(lmpc_ctx *, const int *laps, int n);
         /* override of argsort(LapTime)[0:numSS_it] (:395,402); n = 0 restores the built-in stable sort */
 int lmpc_ss_num_laps(lmpc_ctx *, int *n);
 int lmpc_ss_get_qfun(lmpc_ctx *, int lap, double *qfun /*T*/, int *T);
+int lmpc_store_read_lap(lmpc_ctx *, int store /*0: regression store (sorted position), 1: safe set*/, int lap, double *x /*T x 6*/, double *u /*T x 2*/, double *qfun /*T, safe set only*/, int *T);
+        /* checkpoint / resume: one stored lap back on the host, safe-set laps with the rows LMPC.addPoint appended (the reference imports pickle for this and never uses it,
+         * main.py:36; racinglmpc_amd._capi.Context.save_stores / restore_stores write and read an .npz).  Any of x, u, qfun may be NULL */
 int lmpc_ss_get_laptime(lmpc_ctx *, int lap, int *T);
         /* LMPC.LapTime[lap] (:420): rows of the lap when it was added (without addPoint extensions) -- what argsort(LapTime) sorts */
 

@@ -49,7 +49,7 @@ class StepDevArgs(C.Structure):
 EXPORTS = [
     "lmpc_config_default", "lmpc_create", "lmpc_create_ex", "lmpc_solver_kind", "lmpc_destroy", "lmpc_last_error", "lmpc_active_knobs", "lmpc_version",
     "lmpc_model_add_trajectory", "lmpc_model_num_laps", "lmpc_model_replace_lap",
-    "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun", "lmpc_ss_get_laptime",
+    "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun", "lmpc_ss_get_laptime", "lmpc_store_read_lap",
     "lmpc_regress_batch", "lmpc_regress_points", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
     "lmpc_dev_alloc", "lmpc_dev_free", "lmpc_dev_upload", "lmpc_dev_download", "lmpc_dev_sync", "lmpc_step_batch_dev",
     "lmpc_lti_regression", "lmpc_comm_unique_id", "lmpc_comm_init", "lmpc_comm_destroy", "lmpc_comm_info", "lmpc_comm_allgather_dev", "lmpc_comm_allgather",
@@ -403,6 +403,41 @@ class Context:
 
     def rollout_end(self):
         _chk(self.lib.lmpc_rollout_end(self._h))
+
+    # ---- checkpoint / resume of the lap stores (optional .npz dump; no reference counterpart beyond an unused `import pickle`, main.py:36) ----
+    def store_read_lap(self, store, lap):
+        """(x (T, 6), u (T, 2), qfun (T,) or None) of one stored lap: store 0 = regression store in its sorted order, 1 = safe set in addTrajectory order."""
+        T = C.c_int()
+        _chk(self.lib.lmpc_store_read_lap(self._h, C.c_int(store), C.c_int(int(lap)), None, None, None, C.byref(T)))
+        x = np.zeros((T.value, 6)); u = np.zeros((T.value, 2)); q = np.zeros(T.value) if store == 1 else None
+        _chk(self.lib.lmpc_store_read_lap(self._h, C.c_int(store), C.c_int(int(lap)), _d(x), _d(u), _d(q), C.byref(T)))
+        return x, u, q
+
+    def save_stores(self, path):
+        """Both lap stores (and the explicit safe-set selection, if one is set by the caller: not stored -- it is per-step state of the controller) as one .npz."""
+        out = {}
+        nm = C.c_int(); _chk(self.lib.lmpc_model_num_laps(self._h, C.byref(nm)))
+        for i in range(nm.value):
+            x, u, _ = self.store_read_lap(0, i); out["model_x%d" % i] = x; out["model_u%d" % i] = u
+        ns = self.ss_num_laps()
+        for i in range(ns):
+            x, u, q = self.store_read_lap(1, i); out["ss_x%d" % i] = x; out["ss_u%d" % i] = u; out["ss_q%d" % i] = q
+            out["ss_laptime%d" % i] = np.int64(self.ss_lap_time(i))
+        np.savez_compressed(path, n_model=np.int64(nm.value), n_ss=np.int64(ns), N=np.int64(self.N), **out)
+
+    def restore_stores(self, path):
+        """Into a context whose stores are EMPTY: the regression laps in their sorted order (a stable sorted insert keeps it), the safe-set laps at their addTrajectory-time
+        length followed by the rows addPoint had appended and their Q-function.  The restored context answers every later call bit for bit like the one that was saved."""
+        with np.load(path) as d:
+            nm = C.c_int(); _chk(self.lib.lmpc_model_num_laps(self._h, C.byref(nm)))
+            if nm.value or self.ss_num_laps():
+                raise LmpcError("restore_stores needs a context with empty lap stores")
+            for i in range(int(d["n_model"])):
+                self.model_add_trajectory(d["model_x%d" % i], d["model_u%d" % i])
+            for i in range(int(d["n_ss"])):
+                x, u, q, T0 = d["ss_x%d" % i], d["ss_u%d" % i], d["ss_q%d" % i], int(d["ss_laptime%d" % i])
+                self.ss_add_trajectory(x[:T0], u[:T0])
+                self.ss_replace_lap(i, x, u, q)          # (always: the saved rows and Q-function, whatever computeCost makes of the first T0 rows)
 
     def rollout_release(self):
         """Free the device buffers a finished session keeps for the next lap (lmpc_rollout_release)."""

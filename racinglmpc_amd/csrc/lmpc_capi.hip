@@ -557,6 +557,27 @@ int lmpc_ss_get_qfun(lmpc_ctx *c, int lap, double *qfun, int *T) {
     return LMPC_OK;
 }
 
+int lmpc_store_read_lap(lmpc_ctx *c, int store, int lap, double *x, double *u, double *qfun, int *T) {
+    // checkpoint / resume ("optional: dump lap stores as .npz"; the reference imports pickle for it and never uses it, main.py:36): rows of one stored lap back on
+    // the host.  store 0: regression store, `lap` = position in its sorted order (PredictiveModel.xStored[lap]); store 1: safe set, `lap` = index in addTrajectory order, with
+    // the rows LMPC.addPoint appended and the Q-function.  T is always set; x (T x 6), u (T x 2), qfun (T) may be NULL.
+    ARGCHK(c && T && (store == 0 || store == 1));
+    HIPCHK(hipSetDevice(c->cfg.device)); RESOLVE_PENDING(); HIPCHK(hipStreamSynchronize(c->stream));
+    int slot, rows; const double *base;
+    if (store == 0) { ARGCHK(lap >= 0 && lap < (int)c->m_order.size()); slot = c->m_order[lap]; rows = c->m_len[slot]; base = c->mstore; }
+    else { ARGCHK(lap >= 0 && lap < (int)c->s_len.size()); slot = lap; rows = c->s_len[lap]; base = c->sstore; }
+    *T = rows;
+    if (!x && !u && !qfun) return LMPC_OK;
+    const size_t ls = c->cfg.max_lap_len;
+    std::vector<double> col(rows);
+    for (int j = 0; j < LMPC_COLS; j++) {
+        if ((j < 6 && !x) || (j >= 6 && j < 8 && !u) || (j == 8 && (!qfun || store == 0))) continue;
+        HIPCHK(hipMemcpy(col.data(), base + ((size_t)slot * LMPC_COLS + j) * ls, sizeof(double) * rows, hipMemcpyDeviceToHost));
+        for (int r = 0; r < rows; r++) { if (j < 6) x[(size_t)r * 6 + j] = col[r]; else if (j < 8) u[(size_t)r * 2 + (j - 6)] = col[r]; else qfun[r] = col[r]; }
+    }
+    return LMPC_OK;
+}
+
 int lmpc_ss_get_laptime(lmpc_ctx *c, int lap, int *T) { ARGCHK(c && T && lap >= 0 && lap < (int)c->s_laptime.size()); *T = c->s_laptime[lap]; return LMPC_OK; }
 
 // refresh the per-launch part of the device parameter block

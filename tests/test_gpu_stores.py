@@ -36,3 +36,38 @@ def test_lap_stores_grow_like_the_reference_lists(built):
         assert np.all(ra["status"] == 0)
         for k in ra:
             assert np.array_equal(ra[k], rb[k]), k                          # bit-identical answers whatever the initial capacity
+
+
+def test_lap_stores_checkpoint_and_resume(built, tmp_path):
+    """the lap stores as an .npz and back.  A context restored from the file holds the same rows (regression store in its sorted order, safe-set laps
+    with the rows addPoint appended and their Q-function) and answers a recorded step bit for bit like the one that was saved."""
+    import numpy as np
+    from racinglmpc_amd import _capi
+    from tests import common
+    g = common.load_lmpc_golden()
+    ctx, par = common.make_lmpc_ctx(g, 5, max_batch=4)                 # lap 5 of the fixture: five regression laps, a safe-set lap extended by addPoint, one replaced lap
+    r = int(np.where(g["rec_lap"] == 5)[0][3])
+    for t in range(3):                                                   # a few more addPoint rows on the last lap
+        ctx.ss_add_point(g["all_x0"][t], g["all_u0"][t])
+    args = (g["rec_x0"][r][None], g["rec_xLin"][r][None], g["rec_uLin"][r][None], g["rec_OldInput"][r][None])
+    kw = dict(zt=g["rec_zt"][r][None], xPredPrev=g["rec_xPredPrev"][r][None], hasPred=np.array([g["rec_hasPred"][r]]), timeStep=np.array([g["rec_t"][r]]))
+    ref = ctx.step_batch(*args, **kw)
+    path = str(tmp_path / "stores.npz")
+    ctx.save_stores(path)
+    cfg, _ = common.lmpc_config(g, 12, max_batch=4)
+    ctx2 = _capi.Context(cfg)
+    ctx2.restore_stores(path)
+    assert ctx2.ss_num_laps() == ctx.ss_num_laps()
+    for i in range(ctx.ss_num_laps()):
+        a, b = ctx.store_read_lap(1, i), ctx2.store_read_lap(1, i)
+        assert all(np.array_equal(p, q) for p, q in zip(a, b)) and ctx.ss_lap_time(i) == ctx2.ss_lap_time(i)
+    for i in range(5):
+        a, b = ctx.store_read_lap(0, i), ctx2.store_read_lap(0, i)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    got = ctx2.step_batch(*args, **kw)
+    for k in ("xPred", "uPred", "slack", "lambd", "sTerm", "ztNext", "ztuNext", "ssSel", "qSel", "A", "B", "C", "status", "iters"):
+        assert np.array_equal(got[k], ref[k]), k
+    import pytest
+    with pytest.raises(_capi.LmpcError):
+        ctx2.restore_stores(path)                                        # only into empty stores
+    ctx.close(); ctx2.close()
