@@ -227,12 +227,18 @@ __device__ __forceinline__ double frcp(double x) {
     return r;
 }
 // Step rules of the interior-point iteration (both solve kernels; tests/ipm_model.py mirrors them).
-//  * fraction to the boundary: 0.995, and once the predictor says the iteration is in its final phase (centring parameter sigma < 1e-3,
+//  * round 6: three constants of these rules re-tuned on EVERY closed-loop QP of the reference's 40-lap experiment in the NumPy model (tools/knob_model.py, 12 442 QPs at N = 12,
+//    10 336 at N = 14, the bench batches at N = 12 / 14 / 40; profiles/r6_knob_model.txt) instead of the few hundred problems of rounds 1-3: centring parameter
+//    sigma = (gap_aff / gap)^5 (was ^3), fraction to the boundary 0.99 (was 0.995), separate steps after an iteration whose gap shrank by less than 20x (was 10x).  Closed loop
+//    9.25 -> 8.98 iterations at N = 12 and 9.86 -> 9.49 at N = 14, QPs above 14 iterations halved (55 -> 28 of 12 442; 124 -> 64 of 10 336), and the 24-31-iteration two-cycle
+//    QPs (1 in ~3 400: maxima 26 / 31 / 25 per seed) end at 17-18; bench batch 8.63 -> 8.44 (maximum 13 unchanged), N = 40 bench 10.91 / 18 -> 10.72 / 16.
+//  * fraction to the boundary: LMPC_FRAC0, and once the predictor says the iteration is in its final phase (centring parameter sigma < 1e-3,
 //    i.e. the affine step alone removes > 90 % of the gap) 1 - 10 gap: the gap then contracts quadratically instead of by 1 / 200 per
 //    step (about one iteration less per solve).  Ungated, the longer step lets single complementarity products collapse while the
 //    iterate is still far from the path (one 38-iteration stall in 1024 problems of the NumPy model); gated it never fired there.
-//  * separate primal / dual step lengths after an iteration whose gap shrank by less than 1 / LMPC_SEP_THRESHOLD.
-#define LMPC_SEP_THRESHOLD 0.1
+//  * separate primal / dual step lengths after an iteration whose gap shrank by less than 1 / LMPC_SEP_THRESHOLD (20x).
+#define LMPC_SEP_THRESHOLD 0.05
+#define LMPC_FRAC0 0.99
 //  * termination (round 6: ONE rule for every horizon and every kernel route; it replaces round 5's stack of gap-ratio / gap-floor / dual-residual thresholds, each
 //    of which had been fitted to the last miss found).  The gap and residual tolerances say the KKT conditions hold; they do not say how far the iterate is from
 //    the optimum: a QP without strict complementarity (about one in ten here) converges linearly and sits ~sqrt(gap) away, a flat closed-loop QP sits 660 dual
@@ -267,7 +273,8 @@ __device__ __forceinline__ bool step_bound_ok(double step, double step_prev) {
 // part of the cost-to-go to rounding: the dual residual stalls at 1e-7 and the iteration wanders off (tests/ipm_model.py, tools/ipm_model_sets.py).
 #define LMPC_TH_INV 1e-11
 __device__ __forceinline__ double barrier_rt(double t, double mu) { return frcp(fmax(t, mu * LMPC_TH_INV)); }
-__device__ __forceinline__ double step_fraction(double sig, double gap) { return sig < 1e-3 ? fmax(0.995, 1.0 - 10.0 * gap) : 0.995; }
+__device__ __forceinline__ double step_fraction(double sig, double gap) { return sig < 1e-3 ? fmax(LMPC_FRAC0, 1.0 - 10.0 * gap) : LMPC_FRAC0; }
+__device__ __forceinline__ double centring_sigma(double r) { const double r2 = r * r; return r2 * r2 * r; }       // (gap_aff / gap)^5
 
 __device__ __forceinline__ double frsqrt(double x) {
     double y = __builtin_amdgcn_rsq(x);
@@ -2042,7 +2049,7 @@ __global__ __launch_bounds__(WAVE, (solve_lds1<N, S, ABG>::tot * 8 * 5 <= 160 * 
             if (r < M) { gaff = fma(t_r[j] + apmax * dt_r[j], m[r] + admax * dma_r[j], gaff); tp_r[j] = dt_r[j] * dma_r[j]; }
         }
         gaff = SWEEP_BF<N> ? wsum(gaff) * (1.0 / (double)M) : wsum(gaff) / (double)M;
-        double sig = SWEEP_BF<N> ? gaff * frcp(gap) : gaff / gap; sig = sig * sig * sig;
+        double sig = SWEEP_BF<N> ? gaff * frcp(gap) : gaff / gap; sig = centring_sigma(sig);
         const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);   // keep the complementarity products off the rounding floor
         // ---- corrector: h = (t mu - sigma gap + dt_aff dmu_aff) / t ----------------------------------------
         __syncthreads();

@@ -565,7 +565,7 @@ __global__ __launch_bounds__(WAVE, 2) void lmpc_solve_kernel_cd(lmpc_dev_params 
             if (r < M) { gaff = fma(t_r[j] + apmax * dt_r[j], m[r] + admax * dma_r[j], gaff); tp_r[j] = dt_r[j] * dma_r[j]; }
         }
         gaff = wsum(gaff) / (double)M;
-        double sig = gaff / gap; sig = sig * sig * sig;
+        double sig = gaff / gap; sig = centring_sigma(sig);
         const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);
         __syncthreads();
 #pragma unroll

@@ -765,7 +765,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         apmax = red_min(4); admax = red_min(5);
         if (!sep) { apmax = fmin(apmax, admax); admax = apmax; }
         const double gaff = gap + (apmax * red_sum(6) + admax * red_sum(0) + apmax * admax * red_sum(1)) * (SWEEP_BF<N> ? (1.0 / (double)M) : 1.0 / (double)M);
-        double sig = SWEEP_BF<N> ? gaff * frcp(gap) : gaff / gap; sig = sig * sig * sig;
+        double sig = SWEEP_BF<N> ? gaff * frcp(gap) : gaff / gap; sig = centring_sigma(sig);
         const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);
         TSMW(15);
         // ---- corrector ---------------------------------------------------------------------------------------

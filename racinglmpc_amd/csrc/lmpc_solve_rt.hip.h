@@ -450,7 +450,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel_rt(lmpc_dev_params p, 
         double gaff = 0.0;
         RT_FOR(r, M) { gaff = fma(t[r] + apmax * dt[r], m[r] + admax * dm[r], gaff); tp[r] = dt[r] * dm[r]; }
         gaff = wsum(gaff) / (double)M;
-        double sig = gaff / gap; sig = sig * sig * sig;
+        double sig = gaff / gap; sig = centring_sigma(sig);
         const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);
         // ---- corrector ----------------------------------------------------------------------------------------------------------------------
         RT_SYNC();

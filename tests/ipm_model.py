@@ -54,6 +54,7 @@ def tri_inv_upper(R):
 
 TERM_LATE_GAP = 1e-4
 SEP_STICKY = 0.5
+SIG_EXP, FRAC0, FRAC_SIG, SEP_THR = 5, 0.99, 1e-3, 0.05      # (tools/knob_model.py: experiments on the step rules; the values the kernels use -- rounds 1-5: 3, 0.995, 1e-3, 0.1)
 SEP_RULE = "kernel"       # "kernel": separate primal / dual steps after an iteration whose gap shrank by less than 10x; "noinc", "off": experiments
 TERM_LATE = False          # set by ipm_solve per iteration: the iterate is in its final phase (gap below 1e-4)
 TERM_FACTOR = "cholqr2_fo_late"        # (round 5: what the kernels do)   how kkt_factor factorises the terminal block: "mgs" (two passes of modified Gram-Schmidt on M'), "gram" (Cholesky of M M', the kernels' way), "gram_scaled"
@@ -254,7 +255,7 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
         gap = (t_lane.ravel() @ m_lane.ravel() + t_u.ravel() @ m_u.ravel() + t_s.ravel() @ m_s.ravel() + t_l @ m_l) / mtot
         gp_before, sep_before = gap_prev, sep
         if gap_prev is not None:
-            sep = gap > 0.1 * gap_prev
+            sep = gap > SEP_THR * gap_prev
             if SEP_RULE == "noinc":                # (round 5) ... and not after an iteration that INCREASED the gap: separate steps that do, alternate with equal steps
                 sep = sep and gap < gap_prev       # that repair it -- a two-cycle of up to 20 iterations on 1 in 3 400 closed-loop QPs (tools/capture_slow_qps.py)
             elif SEP_RULE == "off":
@@ -417,7 +418,7 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
         if not sep:
             aap = aad = min(aap, aad)
         gap_aff = sum(((t + aap * d).ravel() @ (m + aad * dm).ravel()) for t, d, m, dm in zip(ts, dt, ms, dma)) / mtot
-        sig = (gap_aff / gap) ** 3
+        sig = (gap_aff / gap) ** SIG_EXP
         tgt = max(sig * gap, 0.01 * tol_gap)          # keep the complementarity products off the rounding floor
         rc = [t * m - tgt + so_w * d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]      # (so_w = 0: no second-order term -- affine + centring only, what a two-right-hand-side single sweep could deliver)
         hs = [r * rt for r, rt in zip(rc, rts)]
@@ -434,7 +435,7 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
                 dt = ineq_steps(dx, du, ds, dl)
                 dm = [-h_ - th * d for h_, th, d in zip(hs, ths, dt)]
                 info["ncorr"] = info.get("ncorr", 0) + 1
-        frac = max(0.995, 1.0 - 10.0 * gap) if sig < 1e-3 else 0.995      # longer steps in the final phase only (step_fraction in the kernel)
+        frac = max(FRAC0, 1.0 - 10.0 * gap) if sig < FRAC_SIG else FRAC0      # longer steps in the final phase only (step_fraction in the kernel)
         al = min(1.0, frac * maxstep(ts, dt)); ald = min(1.0, frac * maxstep(ms, dm))
         if not sep:
             al = ald = min(al, ald)
@@ -546,7 +547,7 @@ def ipm_solve_cd(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=
         ts = (t_lane, t_u, t_s, t_l); ms = (m_lane, m_u, m_s, m_l)
         gap = sum(t.ravel() @ m.ravel() for t, m in zip(ts, ms)) / mtot
         if gap_prev is not None:
-            sep = gap > 0.1 * gap_prev
+            sep = gap > SEP_THR * gap_prev
         gap_prev = gap
         # ---- residuals: adjoint recursion p_k = w_k + A_k' p_{k+1} gives the state part of the u rows
         sT = qp.SS @ lam - x[N] if qp.term else None
@@ -623,14 +624,14 @@ def ipm_solve_cd(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=
         if not sep:
             aap = aad = min(aap, aad)
         gap_aff = sum(((t + aap * d).ravel() @ (m + aad * dm).ravel()) for t, d, m, dm in zip(ts, dt, ms, dma)) / mtot
-        sig = (gap_aff / gap) ** 3
+        sig = (gap_aff / gap) ** SIG_EXP
         tgt = max(sig * gap, 0.01 * tol_gap)
         rc = [t * m - tgt + d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]
         hs = [r * rt for r, rt in zip(rc, rts)]
         du, fl, ds, dl, dxN = solve(*hs)
         dt = steps(du, fl, ds, dl)
         dm = [-h_ - th * d for h_, th, d in zip(hs, ths, dt)]
-        frac = max(0.995, 1.0 - 10.0 * gap) if sig < 1e-3 else 0.995
+        frac = max(FRAC0, 1.0 - 10.0 * gap) if sig < FRAC_SIG else FRAC0
         al = min(1.0, frac * maxstep(ts, dt)); ald = min(1.0, frac * maxstep(ms, dm))
         if not sep:
             al = ald = min(al, ald)

@@ -51,11 +51,11 @@ def test_forty_laps_at_main_py_horizon(built):
         _clean(recs)                                                    # zero NUMERIC / MAXITER / REG_SINGULAR / INEXACT over the whole experiment
         runs[seed] = np.array([r["steps"] for r in recs])
         print("seed %s: %s  (executed reference: %s)  IPM iterations max %d" % (seed, runs[seed].tolist(), ref[seed], max(r["iters_max"] for r in recs)))
-        # Iteration gates (measured on the round-5 kernels, ~3 430 QPs per seed: mean 9.5-9.6; 0-1 lap per seed holds a QP above 20 iterations -- 31 and 24, a
-        # two-cycle of the separate / equal step rule the NumPy model reproduces iteration for iteration, tools/capture_slow_qps.py; nothing reaches the limit of 40)
-        assert max(r["iters_max"] for r in recs) <= 35
-        assert sum(r["iters_max"] > 20 for r in recs) <= 2 and sum(r["iters_max"] > 16 for r in recs) <= 8
-        assert np.mean([r["iters_mean"] for r in recs]) <= 10.8
+        # Iteration gates.  Rounds 1-5: 0-1 lap per seed held a QP above 20 iterations (31 and 24: a two-cycle of the separate / equal step rule).  Round 6 re-tuned three
+        # constants of the step rules on every closed-loop QP in the NumPy model (tools/knob_model.py): measured here 17 / 17 / 18 at most over ~3 430 QPs per seed, mean 9.5.
+        assert max(r["iters_max"] for r in recs) <= 20
+        assert sum(r["iters_max"] > 16 for r in recs) <= 6
+        assert np.mean([r["iters_mean"] for r in recs]) <= 10.4
         assert max(r["vx_max"] for r in recs) > 3.0                     # the regime the reference ends up in was actually reached
     gpu = np.mean([runs[s] for s in seeds], axis=0); cpu = np.mean([ref[s] for s in seeds], axis=0)
     print("three-seed means, GPU - executed reference, lap by lap:", np.round(gpu - cpu, 1).tolist())
