@@ -155,6 +155,7 @@ class Context:
         self.M = 8 * self.N + self.S
         self._step_plan = {}
         self._h = C.c_void_p()
+        self._pid = os.getpid()         # the process that owns the device context (see close)
         if runtime_kernel:              # (tests: the runtime-(N, S) kernel even where a fast one exists)
             rc = self.lib.lmpc_create_ex(C.byref(cfg), C.c_uint(CREATE_FORCE_RUNTIME_KERNEL), C.byref(self._h))
         else:
@@ -173,9 +174,12 @@ class Context:
         self.solver_kind = int(self.lib.lmpc_solver_kind(self._h))      # 0 built-in, 1 variant library, 2 runtime-(N, S) kernel
 
     def close(self):
-        if self._h:
+        # A forked child inherits this object but not a usable HIP runtime: when the child's garbage collector finalises its copy, lmpc_destroy would run HIP calls
+        # in a process that must not make any (a segmentation fault in a multiprocessing worker, and a parent waiting for ever on the dead worker: it happened in the
+        # oracle pools of the GPU tests).  Only the creating process destroys the context.
+        if self._h and getattr(self, "_pid", None) == os.getpid():
             self.lib.lmpc_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:

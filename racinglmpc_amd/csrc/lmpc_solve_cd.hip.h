@@ -569,7 +569,7 @@ __global__ __launch_bounds__(WAVE, 2) void lmpc_solve_kernel_cd(lmpc_dev_params 
         const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) { const double mr = m[r]; h[r] = (fma(t_r[j], mr, tp_r[j]) - tgt) * barrier_rt(t_r[j], mr); } }
+        for (int j = 0; j < RPL; j++) { const int r = lane + WAVE * j; if (r < M) { const double mr = m[r]; h[r] = (fma(t_r[j], mr, LMPC_SO_W * tp_r[j]) - tgt) * barrier_rt(t_r[j], mr); } }
         __syncthreads();
         TSTAMP(16);
         const double xiN = kkt_solve(re_sum);

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
         TSMW(15);
         // ---- corrector ---------------------------------------------------------------------------------------
 #pragma unroll
-        for (int j = 0; j < RPL; j++) { const int r = slot_row(j); if (r >= 0) h[r] = (fma(t_r[j], m[r], tp_r[j]) - tgt) * rt_r[j]; }
+        for (int j = 0; j < RPL; j++) { const int r = slot_row(j); if (r >= 0) h[r] = (fma(t_r[j], m[r], LMPC_SO_W * tp_r[j]) - tgt) * rt_r[j]; }
         __syncthreads();
         kkt_solve(re_sum);
         TSMW(16);

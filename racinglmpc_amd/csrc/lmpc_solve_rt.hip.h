@@ -454,7 +454,7 @@ __global__ __launch_bounds__(WAVE) void lmpc_solve_kernel_rt(lmpc_dev_params p, 
         const double tgt = fmax(sig * gap, 0.01 * p.tol_gap);
         // ---- corrector ----------------------------------------------------------------------------------------------------------------------
         RT_SYNC();
-        RT_FOR(r, M) h[r] = (fma(t[r], m[r], tp[r]) - tgt) * rt[r];
+        RT_FOR(r, M) h[r] = (fma(t[r], m[r], LMPC_SO_W * tp[r]) - tgt) * rt[r];
         RT_SYNC();
         kkt_solve(re_sum);
         double apx = INFINITY, adx = INFINITY;

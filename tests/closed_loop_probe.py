@@ -46,7 +46,7 @@ def _solve_all(rec, NH, fast):
         lim = None
     try:
         with mp.get_context("fork").Pool(max(1, min(64, (os.cpu_count() or 2) - 2, len(rec)))) as pool:          # (children never touch HIP: NumPy only)
-            res = pool.map(_work, [(r, NH, fast) for r in rec], chunksize=1)
+            res = pool.map_async(_work, [(r, NH, fast) for r in rec], chunksize=1).get(timeout=420)      # (a worker that dies leaves map() waiting for ever: fail instead)
     finally:
         if lim is not None and hasattr(lim, "restore_original_limits"):
             lim.restore_original_limits()

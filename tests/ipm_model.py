@@ -162,7 +162,7 @@ def kkt_solve(qp, f, th_lane, th_s, gx, gu, gs, h_lane, h_u, h_s, gl, re_dyn, re
     return dx, du, ds, dl
 
 
-def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True, polish=None, pex=None, so_w=1.0, start=None, trace=None, degen_tol=None, acc_rule="kernel", snaps=None):
+def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=False, th_max=1e11, carry_t=True, exact_nu=True, polish=None, pex=None, so_w=1.1, start=None, trace=None, degen_tol=None, acc_rule="kernel", snaps=None):
     """Returns dict(x,u,s,lam,sT, mu (ineq duals in reference row order), iters, gap, rd, re).
     exact_nu (round 3): the multipliers of the dynamics rows are not iterates of their own; every iteration takes them from the adjoint recursion
     nu_{k-1} = A_k' nu_k - w_k (w_k: gradient of the state rows' other terms), so the x rows of the dual residual vanish identically and the
@@ -626,7 +626,7 @@ def ipm_solve_cd(qp, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6, verbose=
         gap_aff = sum(((t + aap * d).ravel() @ (m + aad * dm).ravel()) for t, d, m, dm in zip(ts, dt, ms, dma)) / mtot
         sig = (gap_aff / gap) ** SIG_EXP
         tgt = max(sig * gap, 0.01 * tol_gap)
-        rc = [t * m - tgt + d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]
+        rc = [t * m - tgt + 1.1 * d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]          # (LMPC_SO_W)
         hs = [r * rt for r, rt in zip(rc, rts)]
         du, fl, ds, dl, dxN = solve(*hs)
         dt = steps(du, fl, ds, dl)

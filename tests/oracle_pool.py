@@ -57,7 +57,7 @@ def oracle_batch(par, pt, TL, laps, N, inp, idx, solve_idx=(), procs=None):
             out = [_work(b) for b in idx]
         else:
             with mp.get_context("fork").Pool(n) as pool:
-                out = pool.map(_work, idx, chunksize=max(1, len(idx) // (4 * n)))
+                out = pool.map_async(_work, idx, chunksize=max(1, len(idx) // (4 * n))).get(timeout=420)     # (a worker that dies leaves map() waiting for ever: fail instead)
         for r in out:
             if "Pq" in r:
                 r["objf"] = _objf(*r.pop("Pq"))

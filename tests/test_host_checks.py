@@ -93,3 +93,35 @@ def test_noise_prefetch_keeps_the_draw_order():
     b = mk(); b.prefetch_noise(10, 4, wait=True); got = [b._draw_noise(10, 4), b._draw_noise(10, 4), b._draw_noise(7, 4)]
     assert all(np.array_equal(x, y) for x, y in zip(want, got))
     c = mk(); c.prefetch_noise(9, 4); assert np.array_equal(c._draw_noise(10, 4), want[0])          # wrong shape prefetched: discarded, state restored
+
+
+def test_context_is_not_destroyed_by_a_forked_child():
+    """A multiprocessing worker inherits the parent's Context objects; when its garbage collector finalises the copies, lmpc_destroy must NOT run there (HIP calls in a
+    forked child: a segmentation fault in the worker and a parent waiting for ever -- it happened in the oracle pools of the GPU tests, round 6).  No GPU needed: the
+    object is built around a recording stand-in for the library."""
+    import ctypes as C
+    import os
+    from racinglmpc_amd import _capi
+
+    class _Lib:
+        def __init__(self):
+            self.destroyed = 0
+
+        def lmpc_destroy(self, h):
+            self.destroyed += 1
+
+    ctx = _capi.Context.__new__(_capi.Context)
+    ctx.lib = _Lib(); ctx._h = C.c_void_p(1234); ctx._pid = os.getpid()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:                                       # the child: finalise the inherited copy, report how often the library was called
+        os.close(r)
+        ctx.close()
+        os.write(w, b"%d" % ctx.lib.destroyed)
+        os._exit(0)
+    os.close(w)
+    got = os.read(r, 16); os.waitpid(pid, 0); os.close(r)
+    assert got == b"0"
+    assert ctx._h.value == 1234 and ctx.lib.destroyed == 0     # the parent's handle is untouched ...
+    ctx.close()
+    assert ctx.lib.destroyed == 1 and not ctx._h              # ... and the parent destroys it once

@@ -10,15 +10,18 @@ def _one(args):
     from oracle import lmpc_oracle as orc
     from tests import ipm_model
     start = {}
-    ipm_model.SIG_EXP, ipm_model.FRAC0, ipm_model.FRAC_SIG, ipm_model.SEP_THR = 3, 0.995, 1e-3, 0.1      # (pool workers live across specs: start from the values of rounds 1-5 every time; "dict()" = those)
+    ipm_model.SIG_EXP, ipm_model.FRAC0, ipm_model.FRAC_SIG, ipm_model.SEP_THR = (3, 0.995, 1e-3, 0.1) if os.environ.get("BASE_R5") else (5, 0.99, 1e-3, 0.05)      # (pool workers live across specs: start from the values of rounds 1-5 every time; "dict()" = those)
+    kwargs = {}
     for k, v in kn.items():
         if k == "mu_scale":
             start["mu_scale"] = v
+        elif k in ("so_w", "ncorr", "reg_l", "th_max"):      # keyword arguments of ipm_solve
+            kwargs[k] = v
         else:
             setattr(ipm_model, k, v)
     qp = ipm_model.StructQP(orc.QPParams.lmpc_default(N), *rec)
     with np.errstate(all="ignore"):
-        r = ipm_model.ipm_solve(qp, exact_nu=False, start=start or None)
+        r = ipm_model.ipm_solve(qp, exact_nu=False, start=start or None, **kwargs)
     ok = np.isfinite(r["gap"]) and r["gap"] < 1e-11 and r["rd"] < 1e-9 * max(1.0, np.abs(rec[6]).max()) and r["re"] < 1e-9
     return r["iters"], ok
 
