@@ -176,7 +176,7 @@ class Context:
     def close(self):
         # A forked child inherits this object but not a usable HIP runtime: when the child's garbage collector finalises its copy, lmpc_destroy would run HIP calls
         # in a process that must not make any (a segmentation fault in a multiprocessing worker, and a parent waiting for ever on the dead worker: it happened in the
-        # oracle pools of the GPU tests).  Only the creating process destroys the context.
+        # worker pools of the GPU tests).  Only the creating process destroys the context.
         if self._h and getattr(self, "_pid", None) == os.getpid():
             self.lib.lmpc_destroy(self._h)
         self._h = C.c_void_p()
