@@ -158,6 +158,7 @@ __global__ __launch_bounds__(WAVE *NW, (NW == 4 || solve_lds<N, S>::tot * 8 * 3 
     // terminal block's, belong to the FIRST S threads: to wave 0 when S <= 64.  The wave that factorises the terminal block then knows the new
     // weights the moment it has updated its own rows, and starts the next iteration's terminal factor (Gram matrix part) inside the step phase
     // instead of behind the barrier that ends it (TEARLY; four waves per QP, one terminal-block column per lane).
+    // (round 6, A / B on the GPU: the same for two waves per QP -- wave 0 owns the lambda rows there too -- changes nothing: 1.692 vs 1.694 M/s at batch 512, 2.98 vs 3.00 M/s at 1024)
     constexpr bool TEARLY = term && NW == 4 && LL::CH == 1 && S <= WAVE;
     // (ROWS_OFF_W0: the other rows start at thread 64.  Wave 0's spare lanes used to take the first 64 - S lane rows, so every pass over the rows
     //  made the critical wave run the lane rows' code as well as the lambda rows' -- divergent paths cost the sum of both -- on a wave that is bound by
