@@ -100,3 +100,55 @@ def test_runtime_kernel_agrees_with_the_fast_kernels(built):
     w = np.concatenate([res[1]["xPred"].reshape(12, -1), res[1]["uPred"].reshape(12, -1)], axis=1)
     assert np.all(res[1]["status"] == 0) and np.abs(w - gl["sol_opt"][:, :102]).max() < common.TOL_XU
     assert np.array_equal(res[1]["ztNext"], res[1]["xPred"][:, -1, :])
+
+
+@pytest.mark.parametrize("name", ["lmpc_wide_n12", "lmpc_n14", "lmpc_n40"])
+def test_runtime_kernel_on_the_other_reference_fixtures(built, name):
+    """The runtime-(N, S) kernel (forced) on the steps recorded from the executed reference in the other configurations: 72 safe-set points from 6 laps (more
+    terminal-block columns than a wavefront has lanes), main.py's N = 14, BASELINE's N = 40 -- selection bit-exact, (x, u) and zt at the stated tolerances, KKT certificate."""
+    from racinglmpc_amd import _capi
+    g = common.load_variant_golden(name)
+    N, S, L = int(g["N"]), int(g["numSS_Points"]), int(g["numSS_it"])
+    gl = common.load_lmpc_golden()
+    cfg, par = common.lmpc_config(gl, N, max_batch=16, numSS_it=L, numSS_Points=S)
+    ctx = _capi.Context(cfg, runtime_kernel=True)
+    assert ctx.solver_kind == 2
+    for _ in range(4):
+        ctx.model_add_trajectory(g["xPID"], g["uPID"])
+    for l in range(L):
+        ctx.ss_add_trajectory(g["xPID"], g["uPID"])
+        ctx.ss_replace_lap(l, g["SS"][l], g["uSS"][l], g["Qf"][l])
+    out = ctx.step_batch(g["x0"], g["xLin"], g["uLin"], g["OldInput"], zt=g["zt"], xPredPrev=g["xPredPrev"], hasPred=g["hasPred"].astype(np.int32), timeStep=g["t"].astype(np.int32))
+    assert np.all(out["status"] == 0), out["status"]
+    assert np.array_equal(out["ssSel"], np.transpose(g["SSsel"], (0, 2, 1))) and np.array_equal(out["qSel"], g["Qsel"])
+    nxu = 6 * (N + 1) + 2 * N; worst = worst_zt = 0.0
+    for r in range(g["x0"].shape[0]):
+        w = np.concatenate([out["xPred"][r].ravel(), out["uPred"][r].ravel(), out["slack"][r], out["lambd"][r], out["sTerm"][r]])
+        worst = max(worst, np.abs(w[:nxu] - g["sol_opt"][r][:nxu]).max())
+        lam = g["sol_opt"][r][nxu + 2 * N:nxu + 2 * N + S]
+        worst_zt = max(worst_zt, common.zt_err(out["ztNext"][r], out["ztuNext"][r], g["Succ"][r], g["SuccU"][r], lam))
+        Pr, qr, Ar, lr, ur = common.dense_from_csc(g, r, prefix="")
+        assert max(common.certificate(Pr, qr, Ar, lr, ur, w, out["mu"][r], 8 * N + S).values()) < common.TOL_KKT
+    print("%s through the runtime kernel: worst |xu - certified optimum| %.2e, zt %.2e, iterations max %d" % (name, worst, worst_zt, out["iters"].max()))
+    assert worst < common.TOL_XU and worst_zt < common.TOL_ZT
+    ctx.close()
+
+
+def test_runtime_kernel_on_the_360_point_stress_configuration(built):
+    """SURVEY 8(d)'s stress variant (numSS_it = trToUse = 30, 360 safe-set points: 12 points per lap, 366 terminal-block rows) through the runtime kernel: 97 KB of LDS per QP."""
+    from racinglmpc_amd import _capi
+    g = common.load_30laps_golden("lmpc_30laps_stress_n12")
+    gl = common.load_lmpc_golden()
+    N = int(g["N"]); nl = int(g["nLaps"]); S = int(g["numSS_Points"])
+    cfg, par = common.lmpc_config(gl, N, max_batch=16, max_laps=40, max_lap_len=1024, numSS_it=int(g["numSS_it"]), trToUse=int(g["trToUse"]))
+    ctx = _capi.Context(cfg, runtime_kernel=True)
+    for i in range(nl):
+        ctx.model_add_trajectory(g["lapx%d" % i], g["lapu%d" % i]); ctx.ss_add_trajectory(g["lapx%d" % i], g["lapu%d" % i])
+    out = ctx.step_batch(g["x0"], g["xLin"], g["uLin"], g["OldInput"], zt=g["zt"], xPredPrev=g["xPredPrev"], hasPred=g["hasPred"].astype(np.int32), timeStep=g["t"].astype(np.int32))
+    assert np.all(out["status"] == 0), out["status"]
+    assert np.array_equal(out["ssSel"], np.transpose(g["SSsel"], (0, 2, 1))) and np.array_equal(out["qSel"], g["Qsel"])
+    nxu = 6 * (N + 1) + 2 * N
+    worst = max(np.abs(np.concatenate([out["xPred"][r].ravel(), out["uPred"][r].ravel()]) - g["sol_opt"][r][:nxu]).max() for r in range(g["x0"].shape[0]))
+    print("30 laps / %d points through the runtime kernel: worst |xu - certified optimum| %.2e, iterations max %d" % (S, worst, out["iters"].max()))
+    assert worst < common.TOL_XU
+    ctx.close()
