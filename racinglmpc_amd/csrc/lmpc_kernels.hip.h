@@ -1022,7 +1022,11 @@ template <int CH> __device__ __forceinline__ void gram8_mfma(const double *Mt, d
 // comes from the same 16 matrix-core instructions as the first, and I + E = (I + U)'(I + U) + O(E^2) with U = triu(E, 1) + diag(E) / 2 corrects both factors:
 // q <- q (I - U) per lane, R^-1 <- R1^-1 (I - U) (column j in lane j).  What matters is that q is kept EXPLICITLY (the lanes' mcol registers) where it multiplies z;
 // R^-1 alone, however accurate, brings nothing (modelled: "cholqr2" with Q = M' R^-1: 8.63 / 13).  Model with this scheme: 8.34 / 12, 10.76 / 17.
-#define LMPC_QX_GAP 1e-4
+// Gate (round 6): gap < 1e-8 (was 1e-4).  On the whole closed-loop population the pass buys nothing at all (tools/knob_model.py, TERM_FACTOR = "gram": 9.004 against 9.001
+// iterations on 12 442 QPs -- distinct laps in the safe set, a well-conditioned terminal block); it pays on the bench batches (four IDENTICAL laps: duplicate columns in M),
+// 8.38 against 8.52 at N = 12, 8.69 / 8.87 at N = 14, 10.65 / 10.83 at N = 40 -- and nearly all of that in the last iterations: gated at 1e-8 the model gives 8.40, 8.70, 10.68
+// while the pass (3 k cycles) runs in about two iterations per solve instead of four.
+#define LMPC_QX_GAP 1e-8
 // mcol: this lane's columns of M on entry, of Q on exit.  Ri: R1^-1 on entry (7 x 7 row-major, zeros below the diagonal), R^-1 on exit.  Qt: 8 x 64 CH doubles of
 // LDS in gram8_mfma's operand layout (may be the tile M was multiplied from), Wl: 64 doubles.  One wave; WG: work-group barrier (one-wave kernel) or waitcnt only;
 // CORR = false: no LDS tile to spare for the second Gram matrix -- the routine is a no-op and the solves keep the form of rounds 1-4.

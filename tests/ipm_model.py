@@ -52,7 +52,8 @@ def tri_inv_upper(R):
     return X
 
 
-TERM_LATE_GAP = 1e-4
+MW_LATE_FACTOR = 10            # (what lmpc_solve_kernel_mw does; None: this iterate's own gap, as the one-wave kernel)
+TERM_LATE_GAP = 1e-8          # (LMPC_QX_GAP of the kernels; rounds 5: 1e-4)
 SEP_STICKY = 0.5
 SIG_EXP, FRAC0, FRAC_SIG, SEP_THR = 5, 0.99, 1e-3, 0.05      # (tools/knob_model.py: experiments on the step rules; the values the kernels use -- rounds 1-5: 3, 0.995, 1e-3, 0.1)
 SEP_RULE = "kernel"       # "kernel": separate primal / dual steps after an iteration whose gap shrank by less than 10x; "noinc", "off": experiments
@@ -376,7 +377,8 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
         cap = (lambda t, m: np.maximum(t, m / th_max)) if th_max is not None else (lambda t, m: t)
         rts = [1.0 / cap(t, m) if t.size else t for t, m in zip(ts, ms)]
         th_lane, th_u, th_s, th_l = ths = [m * rt for m, rt in zip(ms, rts)]
-        globals()["TERM_LATE"] = gap < TERM_LATE_GAP
+        # (the multi-wave kernels decide while the helper waves are still summing this iterate's gap: they look at the PREVIOUS iterate's, MW_LATE_FACTOR times the gate)
+        globals()["TERM_LATE"] = gap < TERM_LATE_GAP if (exact_nu or MW_LATE_FACTOR is None) else (gp_before is not None and gp_before < MW_LATE_FACTOR * TERM_LATE_GAP)
         f = kkt_factor(qp, th_lane, th_u, th_s, th_l, reg_l); nfact += 1
         # terminal slack eliminated: its Hessian T enters W7 through T^-1 (kept in factor)
         def solve(h_lane, h_u, h_s, h_l):
