@@ -52,6 +52,7 @@ def tri_inv_upper(R):
     return X
 
 
+TGT_FLOOR = 0.01
 MW_LATE_FACTOR = 10            # (what lmpc_solve_kernel_mw does; None: this iterate's own gap, as the one-wave kernel)
 TERM_LATE_GAP = 1e-8          # (LMPC_QX_GAP of the kernels; rounds 5: 1e-4)
 SEP_STICKY = 0.5
@@ -421,7 +422,7 @@ def ipm_solve(qp, ncorr=None, tol_gap=1e-11, tol_res=1e-9, maxit=40, reg_l=1e-6,
             aap = aad = min(aap, aad)
         gap_aff = sum(((t + aap * d).ravel() @ (m + aad * dm).ravel()) for t, d, m, dm in zip(ts, dt, ms, dma)) / mtot
         sig = (gap_aff / gap) ** SIG_EXP
-        tgt = max(sig * gap, 0.01 * tol_gap)          # keep the complementarity products off the rounding floor
+        tgt = max(sig * gap, TGT_FLOOR * tol_gap)          # keep the complementarity products off the rounding floor
         rc = [t * m - tgt + so_w * d * dm for t, m, d, dm in zip(ts, ms, dt, dma)]      # (so_w = 0: no second-order term -- affine + centring only, what a two-right-hand-side single sweep could deliver)
         hs = [r * rt for r, rt in zip(rc, rts)]
         dx, du, ds, dl = solve(*hs)
