@@ -21,7 +21,7 @@ def _one(args):
             setattr(ipm_model, k, v)
     qp = ipm_model.StructQP(orc.QPParams.lmpc_default(N), *rec)
     with np.errstate(all="ignore"):
-        r = ipm_model.ipm_solve(qp, exact_nu=False, start=start or None, **kwargs)
+        r = ipm_model.ipm_solve(qp, exact_nu=bool(os.environ.get("EXACT_NU")), start=start or None, **kwargs)
     ok = np.isfinite(r["gap"]) and r["gap"] < 1e-11 and r["rd"] < 1e-9 * max(1.0, np.abs(rec[6]).max()) and r["re"] < 1e-9
     return r["iters"], ok
 
