@@ -187,6 +187,12 @@ class Context:
         except Exception:
             pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     # ---- stores
     def model_add_trajectory(self, x, u):
         x = _f64(x); u = _f64(u)
@@ -618,10 +624,19 @@ class ContextPool:
     A closed loop -- step t + 1 needs step t -- cannot use it; batched requests can."""
 
     def __init__(self, cfg, depth=2):
-        self.members = [Context(cfg) for _ in range(int(depth))]
-        self._next = 0
+        if int(depth) < 1:
+            raise ValueError("ContextPool: depth must be at least 1")
+        self.members = []; self._next = 0
+        try:
+            for _ in range(int(depth)):
+                self.members.append(Context(cfg))
+        except Exception:
+            self.close()                               # (a member that failed to come up does not leave the earlier ones' device memory behind)
+            raise
 
     def __getattr__(self, name):                       # lap-store edits (model_add_trajectory, ss_add_trajectory, ss_add_point, ss_set_selected, ...): the same call on every member
+        if name in ("members", "_next"):               # (not set yet: a failed __init__ must not recurse through this hook)
+            raise AttributeError(name)
         if name.startswith(("model_", "ss_")) and not name.startswith(("ss_get", "ss_num", "ss_lap", "model_num")):
             def forward(*a, **kw):
                 out = None
@@ -647,3 +662,9 @@ class ContextPool:
     def close(self):
         for m in self.members:
             m.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

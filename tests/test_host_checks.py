@@ -125,3 +125,38 @@ def test_context_is_not_destroyed_by_a_forked_child():
     assert ctx._h.value == 1234 and ctx.lib.destroyed == 0     # the parent's handle is untouched ...
     ctx.close()
     assert ctx.lib.destroyed == 1 and not ctx._h              # ... and the parent destroys it once
+
+
+def test_context_pool_releases_its_members_when_one_fails(monkeypatch):
+    """ContextPool: a member that fails to come up closes the ones before it and the error is the member's own (not a recursion through the pool's attribute hook);
+    `with` closes every member.  No GPU needed: Context is replaced by a recording stand-in."""
+    import pytest
+    from racinglmpc_amd import _capi
+    made = []
+
+    class _Ctx:
+        def __init__(self, cfg):
+            if len(made) == 2:
+                raise _capi.LmpcError("no device memory")
+            self.closed = 0; self.calls = []; made.append(self)
+
+        def close(self):
+            self.closed += 1
+
+        def ss_add_point(self, *a):
+            self.calls.append(a); return len(self.calls)
+
+        def ss_num_laps(self):
+            return 7
+
+    monkeypatch.setattr(_capi, "Context", _Ctx)
+    with pytest.raises(_capi.LmpcError, match="no device memory"):
+        _capi.ContextPool(None, depth=3)
+    assert [m.closed for m in made] == [1, 1]
+    with pytest.raises(ValueError):
+        _capi.ContextPool(None, depth=0)
+    del made[:]
+    with _capi.ContextPool(None, depth=2) as pool:
+        assert pool.ss_add_point(1.0, 2.0) == 1 and [m.calls for m in made] == [[(1.0, 2.0)]] * 2      # store edits reach every member
+        assert pool.ss_num_laps() == 7                                                                    # queries go to the first
+    assert [m.closed for m in made] == [1, 1]
