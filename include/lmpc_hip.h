@@ -102,6 +102,9 @@ const char *lmpc_active_knobs(void);                             /* developer en
                                                                     LMPC_K1_RPL16, LMPC_MW_MAX_BATCH, LMPC_MW2_MAX_BATCH, LMPC_FUSE, LMPC_CD, LMPC_NO_ABG -- route / grid choices
                                                                     with identical results, each announced once on stderr; no reference counterpart */
 int lmpc_version(void);
+int lmpc_device_memory(int device, unsigned long long *free_bytes, unsigned long long *total_bytes);
+        /* hipMemGetInfo of `device`: what is left of the 288 GB for max_batch, the lap stores (lmpc_config: max_laps x max_points) and rollout sessions -- and what a
+         * destroyed context has given back (tests/test_gpu_stores.py).  No reference counterpart (the reference holds its stores in Python lists) */
 
 /* ---- lap stores -------------------------------------------------------------------------------
  * Two separate stores, as in the reference: the regression store (PredictiveModel.xStored/uStored)

@@ -47,7 +47,7 @@ class StepDevArgs(C.Structure):
 
 
 EXPORTS = [
-    "lmpc_config_default", "lmpc_create", "lmpc_create_ex", "lmpc_solver_kind", "lmpc_destroy", "lmpc_last_error", "lmpc_active_knobs", "lmpc_version",
+    "lmpc_config_default", "lmpc_create", "lmpc_create_ex", "lmpc_solver_kind", "lmpc_destroy", "lmpc_last_error", "lmpc_active_knobs", "lmpc_version", "lmpc_device_memory",
     "lmpc_model_add_trajectory", "lmpc_model_num_laps", "lmpc_model_replace_lap",
     "lmpc_ss_add_trajectory", "lmpc_ss_add_point", "lmpc_ss_replace_lap", "lmpc_ss_set_selected", "lmpc_ss_num_laps", "lmpc_ss_get_qfun", "lmpc_ss_get_laptime", "lmpc_store_read_lap",
     "lmpc_regress_batch", "lmpc_regress_points", "lmpc_select_batch", "lmpc_qp_solve_batch", "lmpc_step_batch", "lmpc_assemble_batch", "lmpc_qp_dims",
@@ -87,6 +87,13 @@ def active_knobs():
     """Developer environment variables the library has acted on in this process ([] = none): route / grid choices, results identical."""
     v = load().lmpc_active_knobs().decode()
     return v.split(";") if v else []
+
+
+def device_memory(device=0):
+    """(free, total) bytes of HBM on `device` (hipMemGetInfo)."""
+    f, t = C.c_ulonglong(), C.c_ulonglong()
+    _chk(load().lmpc_device_memory(C.c_int(device), C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
 
 
 def comm_unique_id():

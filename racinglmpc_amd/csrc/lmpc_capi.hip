@@ -173,6 +173,13 @@ extern "C" {
 const char *lmpc_last_error(void) { return g_err.c_str(); }
 const char *lmpc_active_knobs(void) { std::lock_guard<std::mutex> lk(g_knob_mu); static thread_local std::string copy; copy = g_knobs; return copy.c_str(); }
 int lmpc_version(void) { return 100; }
+int lmpc_device_memory(int device, unsigned long long *free_bytes, unsigned long long *total_bytes) {
+    ARGCHK(free_bytes && total_bytes && device >= 0);
+    size_t f = 0, t = 0;
+    HIPCHK(hipSetDevice(device)); HIPCHK(hipMemGetInfo(&f, &t));
+    *free_bytes = (unsigned long long)f; *total_bytes = (unsigned long long)t;
+    return LMPC_OK;
+}
 
 int lmpc_config_default(lmpc_config *c) {
     if (!c) return LMPC_E_ARG;

@@ -71,3 +71,32 @@ def test_lap_stores_checkpoint_and_resume(built, tmp_path):
     with pytest.raises(_capi.LmpcError):
         ctx2.restore_stores(path)                                        # only into empty stores
     ctx.close(); ctx2.close()
+
+
+def test_contexts_and_rollout_sessions_return_their_device_memory(built):
+    """Create -> solve a batch -> a closed-loop rollout session -> destroy, a dozen times over: the device's free memory ends where it was after the first cycle
+    (lmpc_destroy / lmpc_rollout_end release every buffer of the context, its work space, the host-mapped retry ring and the session; a long-lived service that
+    re-creates contexts per (N, numSS_points) must not creep towards 288 GB).  Free memory: lmpc_device_memory (hipMemGetInfo in the library's own HIP runtime)."""
+    from racinglmpc_amd import _capi, rollout
+    g = common.load_lmpc_golden()
+    inp = common.synthetic_inputs(g, 12, 64)
+
+    def cycle(seed):
+        ctx, par = common.make_lmpc_ctx(g, 4, max_batch=2048)
+        out = ctx.step_batch(**inp)
+        assert np.all(out["status"] == 0)
+        ro = rollout.BatchedRollouts(ctx, g["track"], seed=seed)
+        x0 = np.tile(np.array([0.5, 0, 0, 0, 0, 0.0]), (16, 1)); x0[:, 5] = np.linspace(-0.05, 0.05, 16)
+        best = rollout.lap_and_exchange(ro, x0, g["SS0"][1:14], g["uSS0"][1:13], K=2, T_max=400)
+        assert len(best) == 2
+        alive = _capi.device_memory(0)[0]
+        ro.close(); ctx.close()
+        return alive
+
+    cycle(0)
+    free0 = _capi.device_memory(0)[0]
+    alive = [cycle(1 + i) for i in range(12)]
+    free1 = _capi.device_memory(0)[0]
+    print("free device memory after the first cycle %.1f MB, after twelve more %.1f MB; with a context and a session alive %.1f MB less" % (free0 / 2**20, free1 / 2**20, (free0 - min(alive)) / 2**20))
+    assert free0 - max(alive) > 8 * 2**20          # (the reading moves with the allocations: the check below is not vacuous)
+    assert free0 - free1 < 4 * 2**20, (free0, free1)
