@@ -638,3 +638,38 @@ def test_context_pool_gives_the_single_context_answers(built):
             assert np.array_equal(got[k], ref[k]), k
     assert np.all(ref["status"] == 0)
     pool.close(); ref_ctx.close()
+
+
+def test_two_host_threads_with_their_own_contexts(built):
+    """The C ABI keeps no state outside a context (the last error is thread-local, the knob list is behind a mutex): two host threads, each with its own context and
+    HIP stream, solve different batches concurrently (ctypes releases the interpreter lock for the length of a call) and each gets, bit for bit, what it gets alone."""
+    import threading
+    import bench
+    g = common.load_lmpc_golden()
+    B = 128
+    inps = [bench.synth_batch(g, B, 12, seed=s) for s in (11, 12)]
+    KEYS = ("xPred", "uPred", "lambd", "ztNext", "status", "iters")
+
+    def solve(inp, reps, out):
+        ctx = bench.make_ctx(g, 12, B, 0)
+        try:
+            for _ in range(reps):
+                r = ctx.step_batch(**inp)
+            out.append({k: np.array(r[k]) for k in KEYS})
+        finally:
+            ctx.close()
+
+    alone = []
+    for inp in inps:
+        solve(inp, 1, alone)
+    got = [[], []]
+    ths = [threading.Thread(target=solve, args=(inps[i], 25, got[i])) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert all(not t.is_alive() for t in ths) and all(len(x) == 1 for x in got)
+    for i in range(2):
+        assert np.all(alone[i]["status"] == 0)
+        for k in KEYS:
+            assert np.array_equal(got[i][0][k], alone[i][k]), (i, k)
