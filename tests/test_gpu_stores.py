@@ -100,3 +100,20 @@ def test_contexts_and_rollout_sessions_return_their_device_memory(built):
     print("free device memory after the first cycle %.1f MB, after twelve more %.1f MB; with a context and a session alive %.1f MB less" % (free0 / 2**20, free1 / 2**20, (free0 - min(alive)) / 2**20))
     assert free0 - max(alive) > 8 * 2**20          # (the reading moves with the allocations: the check below is not vacuous)
     assert free0 - free1 < 4 * 2**20, (free0, free1)
+
+
+def test_create_that_cannot_get_its_memory_fails_cleanly(built):
+    """lmpc_create for a batch whose work buffers exceed the device (hundreds of millions of QPs) returns LMPC_E_HIP with hipMalloc's message and gives back
+    what it had allocated before the failing buffer."""
+    from racinglmpc_amd import _capi
+    g = common.load_lmpc_golden()
+    free0, total = _capi.device_memory(0)
+    cfg, _ = common.lmpc_config(g, N=12, max_batch=400_000_000)
+    with pytest.raises(_capi.LmpcError, match="(?i)memory|hipMalloc"):
+        _capi.Context(cfg)
+    free1 = _capi.device_memory(0)[0]
+    print("total %.0f GB; free before %.1f MB, after the failed create %.1f MB" % (total / 2**30, free0 / 2**20, free1 / 2**20))
+    assert abs(free0 - free1) < 4 * 2**20
+    ctx, par = common.make_lmpc_ctx(g, 4, max_batch=8)          # ... and the library is as usable as before
+    assert ctx.ss_num_laps() == 4
+    ctx.close()
