@@ -68,6 +68,9 @@ __device__ inline void k2_select_rt(const lmpc_dev_params &p, const lmpc_solve_i
                 if (nrm < best) { best = nrm; bi = r; }
             }
             wave_argmin(best, bi);                                              // np.argmin: first minimum
+            if ((unsigned)bi >= (unsigned)T) {                                  // no row compares below +inf: zt or x0 is not finite (np.argmin would go on with row 0 or the first NaN).
+                bi = 0; if (lane == 0) atomicOr(st_sh, LMPC_ST_NUMERIC);        // The window arithmetic below must not see the sentinel (start + lane overflowed: a fault on the device)
+            }
             const int MinNorm = bi;
             const int start = ((double)MinNorm - (double)npw / 2.0 >= 0.0) ? MinNorm - npw / 2 : MinNorm;   // :492-495
             if (lane == 0) { sel_start[l] = start; if (io.selStartOut) io.selStartOut[(size_t)b * p.L + l] = start; if (start + npw > T) atomicOr(st_sh, LMPC_ST_WINDOW); }

@@ -681,3 +681,24 @@ def test_lti_regression_kernel_matches_reference(built):
     with pytest.raises(np.linalg.LinAlgError):
         Utilities.Regression(np.zeros((30, 6)), np.zeros((30, 2)), 0.0)
 
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("runtime_kernel", [False, True])
+def test_non_finite_inputs_stay_inside_their_problem(g, runtime_kernel):
+    """NaN / inf in one problem's x0, linearisation points or previous input: the launch returns (the iteration is bounded), THAT problem carries a status bit,
+    and every other problem of the batch gets, bit for bit, what it gets in a clean batch (the reference would raise inside cvxopt / OSQP for the whole call).
+    Round 6: zt = -inf left the selection's arg-min at its sentinel and the window arithmetic overflowed -- a memory access fault on the device; fixed in k2_select."""
+    ctx, par = common.make_lmpc_ctx(g, 4, max_batch=16, runtime_kernel=runtime_kernel)
+    inp = common.synthetic_inputs(g, 12, 16)
+    clean = ctx.step_batch(**inp)
+    assert np.all(clean["status"] == 0)
+    bad = {k: np.array(v, copy=True) for k, v in inp.items()}
+    bad["x0"][3, 0] = np.nan; bad["x0"][7, 5] = np.inf; bad["uOld"][11, 1] = np.nan; bad["xLin"][13, 4, 1] = np.nan; bad["zt"][14, 2] = -np.inf
+    out = ctx.step_batch(**bad)
+    hit = [3, 7, 11, 13, 14]; rest = [b for b in range(16) if b not in hit]
+    print("status of the poisoned problems:", [hex(int(out["status"][b])) for b in hit], "regression status:", [hex(int(np.bitwise_or.reduce(out["rstatus"][b]))) for b in hit] if "rstatus" in out else "")
+    assert all(out["status"][b] != 0 for b in hit)
+    for k in ("xPred", "uPred", "lambd", "ztNext", "status", "iters"):
+        assert np.array_equal(np.asarray(out[k])[rest], np.asarray(clean[k])[rest]), k
+    ctx.close()
