@@ -117,3 +117,16 @@ def test_create_that_cannot_get_its_memory_fails_cleanly(built):
     ctx, par = common.make_lmpc_ctx(g, 4, max_batch=8)          # ... and the library is as usable as before
     assert ctx.ss_num_laps() == 4
     ctx.close()
+
+
+@pytest.mark.timeout(600)
+def test_hostile_inputs_never_take_the_process_down(built):
+    """tools/adversarial_probe.py: NaN / inf / 1e300 in predictions, time steps, QP data, stored laps and rollout start states, empty and 20-row stores -- one process
+    per case (a device fault would kill it).  Every case returns: a status bit on the hostile problem or an LmpcError from the argument checks, never a fault or a hang."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "adversarial_probe.py")], capture_output=True, text=True, timeout=560, cwd=root)
+    print(r.stdout)
+    heads = [l for l in r.stdout.splitlines() if l.startswith("== ")]
+    assert len(heads) >= 8 and r.returncode == 0
+    assert all(l.endswith("exit status 0") for l in heads), [l for l in heads if not l.endswith("exit status 0")]
