@@ -141,7 +141,8 @@ int lmpc_select_batch(lmpc_ctx *, int B, const double *x0 /*B x 6*/, const doubl
                       const double *xPredPrev /*B x (N+1) x 6*/, const int *hasPred /*B*/, const int *timeStep /*B*/,
                       double *ssSel /*B x S x 6*/, double *qSel /*B x S*/, double *succ /*B x S x 6*/, double *succU /*B x S x 2*/,
                       double *ztUsed /*B x 6*/, int *selStart /*B x numSS_it: first row of each lap's window, or NULL*/, int *status /*B*/);
-        /* LMPC.addTerminalComponents (selection part) + selectPoints, :386-412, :478-514 */
+        /* LMPC.addTerminalComponents (selection part) + selectPoints, :386-412, :478-514.  xPredPrev, hasPred, timeStep may be NULL (a first step);
+         * a set hasPred[b] without xPredPrev is LMPC_E_ARG -- here, in lmpc_step_batch and (any hasPred array) in lmpc_step_batch_dev */
 
 int lmpc_qp_solve_batch(lmpc_ctx *, int B, const double *A, const double *Bm, const double *C,
                         const double *x0 /*B x 6*/, const double *uOld /*B x 2*/,

@@ -763,6 +763,13 @@ int lmpc_regress_batch(lmpc_ctx *c, int B, const double *xLin, int xLinRowStride
     return LMPC_OK;
 }
 
+// hasPred without xPredPrev: the selection's Q-function shift (:502-512) would read predictions nobody supplied -- stale rows of the work buffer through the host entry
+// points, a null pointer on the device through lmpc_step_batch_dev.  Host arrays are scanned (an all-zero hasPred is what callers pass on a first step); device arrays cannot be.
+static bool pred_args_ok(int B, const double *xPredPrev, const int *hasPred) {
+    if (!hasPred || xPredPrev) return true;
+    for (int i = 0; i < B; i++) if (hasPred[i]) return false;
+    return true;
+}
 int lmpc_regress_points(lmpc_ctx *c, int n, const double *x, const double *u, double *A, double *Bm, double *C, int *status) {
     // PredictiveModel.regressionAndLinearization (PredictiveModel.py:48-197) for n independent linearisation points (x (n x 6), u (n x 2)): the reference's own call
     // shape -- one point per call -- without a horizon around it.  The regression kernel runs with a parameter block whose horizon is 1: one query per work-group.
@@ -788,6 +795,7 @@ int lmpc_regress_points(lmpc_ctx *c, int n, const double *x, const double *u, do
 int lmpc_select_batch(lmpc_ctx *c, int B, const double *x0, const double *zt, const double *xPredPrev, const int *hasPred, const int *timeStep,
                       double *ssSel, double *qSel, double *succ, double *succU, double *ztUsed, int *selStart, int *status) {
     ARGCHK(c && x0 && zt && B >= 1 && B <= c->cfg.max_batch && c->cfg.numSS_it > 0);
+    ARGCHK(pred_args_ok(B, xPredPrev, hasPred));
     const int N = c->cfg.N, S = c->cfg.numSS_points;
     HIPCHK(hipSetDevice(c->cfg.device));
     H2D(c->w_x0, x0, (size_t)B * 6); H2D(c->w_zt, zt, (size_t)B * 6);
@@ -832,6 +840,7 @@ int lmpc_step_batch_dev(lmpc_ctx *c, int B, const lmpc_step_dev_args *a) {
     ARGCHK(c && a && B >= 1 && a->x0 && a->xLin && a->uLin && a->uOld && a->xPred && a->uPred && a->status && a->iters);
     const int N = c->cfg.N; const bool term = c->cfg.numSS_it > 0;
     if (term) ARGCHK(a->zt != nullptr);
+    ARGCHK(!a->hasPred || a->xPredPrev);                 // (device arrays: a set hasPred[b] would dereference the missing predictions inside the kernel)
     HIPCHK(hipSetDevice(c->cfg.device));
     ARGCHK(B <= c->cfg.max_batch);                      // the work buffers (per-point regression status, A, B, C hand-over) are sized for max_batch
     lmpc_solve_io io; memset(&io, 0, sizeof(io));
@@ -861,6 +870,7 @@ int lmpc_step_batch(lmpc_ctx *c, int B, const double *x0, const double *xLin, co
                     double *sTerm, double *ztNext, double *ztuNext, double *ssSel, double *qSel, double *mu, double *Aout, double *Bout, double *Cout,
                     int *status, int *iters, double *resid) {
     ARGCHK(c && x0 && xLin && uLin && uOld && xPred && uPred && B >= 1 && B <= c->cfg.max_batch);
+    ARGCHK(pred_args_ok(B, xPredPrev, hasPred));
     const int N = c->cfg.N; const bool term = c->cfg.numSS_it > 0; const int S = term ? c->cfg.numSS_points : 0;
     if (term) ARGCHK(zt != nullptr);
     HIPCHK(hipSetDevice(c->cfg.device));

@@ -107,6 +107,24 @@ def case_rollout_nan():
     ro.close()
 
 
+def case_haspred_without_predictions():
+    from racinglmpc_amd import _capi
+    g, ctx, inp = _ctx()
+    inp["hasPred"] = np.ones(16, np.int32)
+    for what, call in (("step_batch", lambda: ctx.step_batch(**inp)), ("select_batch", lambda: ctx.select_batch(inp["x0"], inp["zt"], hasPred=inp["hasPred"]))):
+        try:
+            call(); print("hasPred = 1 without xPredPrev,", what, "RETURNED (stale predictions were read)", flush=True)
+        except _capi.LmpcError as e:
+            print("hasPred = 1 without xPredPrev,", what, "raised LmpcError:", str(e)[:90], flush=True)
+    try:
+        a, keep = ctx.step_dev_buffers(inp, diagnostics=False); a.xPredPrev = None; ctx.step_batch_dev(16, a); ctx.sync()      # (the C caller's mistake: a NULL the kernel would dereference)
+        print("hasPred on the device without xPredPrev: RETURNED", flush=True)
+    except _capi.LmpcError as e:
+        print("hasPred on the device without xPredPrev raised LmpcError:", str(e)[:90], flush=True)
+    inp["hasPred"] = np.zeros(16, np.int32)
+    _show("hasPred all zero without xPredPrev (a first step):", ctx.step_batch(**inp), (0,))
+
+
 CASES = {k[5:]: v for k, v in globals().items() if k.startswith("case_")}
 
 if __name__ == "__main__":
