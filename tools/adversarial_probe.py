@@ -125,6 +125,19 @@ def case_haspred_without_predictions():
     _show("hasPred all zero without xPredPrev (a first step):", ctx.step_batch(**inp), (0,))
 
 
+def case_minimal_dev_args():
+    g, ctx, inp = _ctx()
+    ref = ctx.step_batch(**inp)
+    a, keep = ctx.step_dev_buffers(inp, diagnostics=False)
+    for f in ("slack", "lambda_", "sTerm", "ztNext", "ztuNext", "ssSel", "A", "Bm", "C", "timeStep", "hasPred", "xPredPrev"):
+        setattr(a, f, None)                                  # every optional pointer of lmpc_step_dev_args NULL: the kernels skip those stores
+    ctx.step_batch_dev(16, a); ctx.sync()
+    xp = np.zeros((16, 13, 6)); st = np.zeros(16, np.int32); ctx.dev_download(a.xPred, xp); ctx.dev_download(a.status, st)
+    inp2 = dict(inp); inp2["timeStep"] = np.zeros(16, np.int32)
+    ref0 = ctx.step_batch(**inp2)
+    print("device step with only the required pointers: status", sorted(set(hex(int(s_)) for s_ in st)), "| xPred equals the host entry point's (timeStep = 0):", bool(np.array_equal(xp, ref0["xPred"])), flush=True)
+
+
 CASES = {k[5:]: v for k, v in globals().items() if k.startswith("case_")}
 
 if __name__ == "__main__":
