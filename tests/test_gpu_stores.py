@@ -128,5 +128,5 @@ def test_hostile_inputs_never_take_the_process_down(built):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "adversarial_probe.py")], capture_output=True, text=True, timeout=560, cwd=root)
     print(r.stdout)
     heads = [l for l in r.stdout.splitlines() if l.startswith("== ")]
-    assert len(heads) >= 10 and r.returncode == 0
+    assert len(heads) >= 12 and r.returncode == 0
     assert all(l.endswith("exit status 0") for l in heads), [l for l in heads if not l.endswith("exit status 0")]

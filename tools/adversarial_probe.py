@@ -138,6 +138,60 @@ def case_minimal_dev_args():
     print("device step with only the required pointers: status", sorted(set(hex(int(s_)) for s_ in st)), "| xPred equals the host entry point's (timeStep = 0):", bool(np.array_equal(xp, ref0["xPred"])), flush=True)
 
 
+def case_hostile_config():
+    from racinglmpc_amd import _capi
+    from tests import common
+    g = common.load_lmpc_golden()
+    inp = common.synthetic_inputs(g, 12, 16)
+    model, ss = common.stores_at_lap(g, 4)
+
+    def run(tag, edit):
+        cfg, par = common.lmpc_config(g, 12, max_batch=16)
+        edit(cfg)
+        try:
+            ctx = _capi.Context(cfg)
+        except _capi.LmpcError as e:
+            print("config %-34s lmpc_create refused: %s" % (tag, str(e)[:80]), flush=True); return
+        for x, u in model: ctx.model_add_trajectory(x, u)
+        for x, u, qf in ss: ctx.ss_add_trajectory(x, u)
+        out = ctx.step_batch(**inp)
+        print("config %-34s status values %s, iterations max %d" % (tag, sorted(set(hex(int(s_)) for s_ in out["status"])), int(np.max(out["iters"]))), flush=True)
+        ctx.close()
+
+    def setv(name, idx, v):
+        def f(cfg): getattr(cfg, name)[idx] = v
+        return f
+    run("Q[0][0] = NaN", setv("Q", 0, float("nan")))
+    run("R = 0 and dR = 0", lambda cfg: [cfg.R.__setitem__(i, 0.0) for i in range(4)] + [cfg.dR.__setitem__(i, 0.0) for i in range(2)])
+    run("R[0][0] = -1 (indefinite)", setv("R", 0, -1.0))
+    run("bx = -1 (lane of negative width)", lambda cfg: [cfg.bx.__setitem__(i, -1.0) for i in range(2)])
+    run("bu = 0 (no input authority)", lambda cfg: [cfg.bu.__setitem__(i, 0.0) for i in range(4)])
+    run("Qslack = 0", lambda cfg: [cfg.Qslack.__setitem__(i, 0.0) for i in range(2)])
+    run("hard lane rows, lane of width 0.02", lambda cfg: (setattr(cfg, "slacks", 0), [cfg.bx.__setitem__(i, 0.01) for i in range(2)]))
+    run("QtermSlack = inf", lambda cfg: [cfg.QtermSlack.__setitem__(7 * i, float("inf")) for i in range(6)])
+    run("trackLength = 0", lambda cfg: setattr(cfg, "trackLength", 0.0))
+    run("xRef = 1e200", lambda cfg: [cfg.xRef.__setitem__(i, 1e200) for i in range(6)])
+
+
+def case_rollouts_nobody_finishes():
+    from racinglmpc_amd import rollout, _capi
+    g, ctx, inp = _ctx(B=16)
+    ro = rollout.BatchedRollouts(ctx, g["track"], seed=3)
+    x0 = np.tile(np.array([0.5, 0, 0, 0, 0, 0.0]), (16, 1)); x0[:, 5] = np.linspace(-0.05, 0.05, 16)
+    try:
+        best = rollout.lap_and_exchange(ro, x0, g["SS0"][1:14], g["uSS0"][1:13], K=2, T_max=40)
+        print("40 simulated steps, nobody finishes: exchange returned", len(best), "laps of", [b[4] for b in best], "steps", flush=True)
+    except (_capi.LmpcError, RuntimeError, ValueError) as e:
+        print("40 simulated steps, nobody finishes:", type(e).__name__, str(e)[:120], flush=True)
+    x0[:] = np.nan
+    try:
+        best = rollout.lap_and_exchange(ro, x0, g["SS0"][1:14], g["uSS0"][1:13], K=2, T_max=120)
+        print("every start state NaN: exchange returned", len(best), "laps", flush=True)
+    except (_capi.LmpcError, RuntimeError, ValueError) as e:
+        print("every start state NaN:", type(e).__name__, str(e)[:120], flush=True)
+    ro.close()
+
+
 CASES = {k[5:]: v for k, v in globals().items() if k.startswith("case_")}
 
 if __name__ == "__main__":
@@ -147,7 +201,7 @@ if __name__ == "__main__":
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), name], capture_output=True, text=True, timeout=120)
             lines = [l for l in (r.stdout + r.stderr).splitlines() if l.strip() and not l.startswith("  File") and "Warning" not in l and "warnings.warn" not in l]
-            print("== %s: exit status %d" % (name, r.returncode)); [print("   " + l[:300]) for l in (lines[:8] if r.returncode else lines[-6:])]
+            print("== %s: exit status %d" % (name, r.returncode)); [print("   " + l[:300]) for l in (lines[:8] if r.returncode else lines[-14:])]
         except subprocess.TimeoutExpired:
             print("== %s: TIMEOUT (120 s)" % name)
         sys.stdout.flush()
